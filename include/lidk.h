@@ -1,0 +1,175 @@
+/* lidk — C-ABI of the MI355X-native spoken-LID training hot path (gfx950 only).
+ *
+ * The reference (kouyt5/speech-lid) has no native code: every op below is what its Python reaches
+ * through torch / torchaudio.  Each entry point names the reference call site it
+ * replaces.  Conventions:
+ *   - extern "C", plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*), never synchronise, never allocate;
+ *   - return 0 (LIDK_OK) or a negative LIDK_ERR_* code; no exceptions cross the ABI; caller owns buffers;
+ *   - `dtype` selects the storage type "T" of activations: LIDK_F32 (parity mode) or LIDK_BF16 (fast mode).
+ *     The residual stream, statistics, losses, parameters (master copy) and gradients are always f32.
+ *   - row-major everywhere; activations are [M, C] with M = B*T (utterance-major, then time).
+ *   - outputs documented "+=" accumulate into the destination (gradient arena, zeroed once per step).
+ */
+#ifndef LIDK_H
+#define LIDK_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIDK_OK 0
+#define LIDK_ERR_ARG (-1)
+#define LIDK_ERR_LAUNCH (-2)
+#define LIDK_ERR_UNSUPPORTED (-3)
+
+enum { LIDK_F32 = 0, LIDK_BF16 = 1 };
+enum { LIDK_ACT_NONE = 0, LIDK_ACT_SWISH = 1, LIDK_ACT_RELU = 2, LIDK_ACT_SWISH_GRAD = 3 };
+
+#define LIDK_N_FFT 512
+#define LIDK_N_FREQ 257
+#define LIDK_LN_PARTIAL_BLOCKS 256   /* rows of the column-reduction scratch used by *_bwd kernels */
+
+int lidk_version(void);
+
+/* ------------------------------------------------------------------ feature path (rows a1-a5) */
+/* lid/audio_processor.py:108-115 normalize_wav: (x-mean)/(std_unbiased+1e-6) per utterance. in/out [B][L]. */
+int lidk_normalize_wav(const float* wav, float* out, int B, int L, void* stream);
+/* lid/audio_processor.py:128-134 wav_augment dither + pre-emphasis: x += dither*U[0,1); y[0]=x[0], y[t]=x[t]-coef*x[t-1].
+ * noise: optional [B][L] U[0,1) draws (parity tests); NULL -> counter-based generator keyed by (seed, index). */
+int lidk_dither_preemph(const float* wav, float* out, const float* noise, int B, int L, float coef, float dither,
+                        uint64_t seed, void* stream);
+/* lid/audio_processor.py:72-105 _internal_wav2mel (torchaudio MelSpectrogram + AmplitudeToDB(top_db=80)) fused with
+ * lid/audio_processor.py:225-227 spectrogram_augment masks and lid/raw_datasets.py:345-365 collate layout.
+ * wav [B][L] -> out [B][F][n_mels] f32 dB, F = 1 + (L + 2*pad)/hop.  window [512] (hann(win) centred), twiddle [256][2]
+ * (cos,sin of 2*pi*k/512), melfb [257][n_mels].  utt_max [B] scratch (per-utterance dB max, used for the top_db floor).
+ * spans [B][mask_times][4] int32 = (t0,t1,f0,f1) filled with 0.0 dB, or NULL/mask_times=0 for none. */
+int lidk_logmel(const float* wav, const float* window, const float* twiddle, const float* melfb, float* out,
+                float* utt_max, int B, int L, int pad, int hop, int n_mels, const int32_t* spans, int mask_times,
+                float top_db, void* stream);
+
+/* ------------------------------------------------------------------ generic element-wise helpers */
+/* y = scale * x with dtype conversion (x_dtype/y_dtype in {LIDK_F32, LIDK_BF16}). */
+int lidk_scale_cast(const void* x, int x_dtype, void* y, int y_dtype, long n, float scale, void* stream);
+/* nn.Dropout (lid/conformer.py:491,590; lid/ConformerLangModel.py:349): y = x*keep/(1-p).  keep_in (uint8, optional)
+ * supplies the mask (backward pass / parity tests); otherwise it is generated from (seed, index) and, if keep_out is
+ * non-NULL, written there. */
+int lidk_dropout(const void* x, int x_dtype, void* y, int y_dtype, const uint8_t* keep_in, uint8_t* keep_out, long n,
+                 float p, uint64_t seed, void* stream);
+/* dx = dy * (y > 0)   (backward of nn.ReLU in Conv1dSubSampling2, lid/conformer.py:331-333). */
+int lidk_relu_bwd(const void* dy, const void* y, void* dx, long n, int dtype, void* stream);
+/* out[n] += scale * sum_m x[m][n]   (bias gradients).  partial: >= LIDK_LN_PARTIAL_BLOCKS*N floats. */
+int lidk_colsum(const void* x, int ldx, int x_dtype, float* out, float* partial, int M, int N, float scale, void* stream);
+/* out [C][R] = in [R][C]^T */
+int lidk_transpose(const void* in, int ldi, void* out, int ldo, int R, int C, int dtype, void* stream);
+/* out[c] = sum_p partial[p][c] in float64 (deterministic tree-free column sum of scratch partials). */
+int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double* out, void* stream);
+
+/* ------------------------------------------------------------------ LayerNorm (nn.LayerNorm eps=1e-5, lid/conformer.py:85,190,250) */
+/* x [M][C] f32 -> yT (T, may be NULL) and/or y32 (f32, may be NULL); mean/rstd [M] saved for backward (may be NULL). */
+int lidk_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* yT, float* y32, float* mean,
+                       float* rstd, int M, int C, float eps, int dtype, void* stream);
+/* dx = dres + LN'(dy);  dxT = dxT_scale*dx (T, optional);  dgamma/dbeta += column sums.  dy is T or f32 (dy_dtype).
+ * partial: >= LIDK_LN_PARTIAL_BLOCKS*2*C floats. */
+int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                       const float* gamma, const float* dres, float* dx, void* dxT, float dxT_scale, float* dgamma,
+                       float* dbeta, float* partial, int M, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ GEMM  C[M][N] = A[M][K] * B[N][K]^T  (+ fused epilogue)
+ * Replaces every nn.Linear / 1x1 nn.Conv1d on the path (lid/conformer.py:98-100,163-166,192,199,334; lid/ConformerLangModel.py:350)
+ * and their autograd (dgrad / wgrad run through the same kernel on transposed operands).
+ * v = acc (+bias[n]);  act: SWISH -> out2 = v (pre-activation, T, optional), v = v*sigmoid(v);  RELU -> max(v,0);
+ * SWISH_GRAD -> v *= swish'(aux[m][n]);  v *= alpha;  v += res[m][n] (f32, optional);
+ * out (T, or f32 when out_f32) = v; with splitk > 1 the K range is split over grid.z and out (f32) is accumulated atomically
+ * (out must be pre-zeroed or hold the running gradient; bias/res/act must be unset).  K % 8 == 0, lda/ldb % 8 == 0. */
+typedef struct lidk_gemm_args {
+  const void* A; const void* B;
+  int M, N, K, lda, ldb;
+  const float* bias;
+  int act;
+  float alpha;
+  const float* res; int ldres;
+  void* out; int ldo; int out_f32;
+  void* out2; int ldo2;
+  const void* aux; int ldaux;
+  int splitk;
+} lidk_gemm_args;
+int lidk_gemm_nt(const lidk_gemm_args* args, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ Attention core with Shaw relative positions (lid/conformer.py:117-148)
+ * qkv [B*T][3*heads*dh] (T): q | k | v column blocks, head h at columns h*dh.. within each.  rel_emb [2*max_pos+1][dh] f32.
+ * scores = (q.k^T + q.rel_emb[clamp(i-j)+max_pos]) * dh^-0.5 ; probs = softmax_j ; out = probs.v -> [B*T][heads*dh] (T).
+ * probs [B][heads][T][T] (T) is saved for backward. */
+int lidk_attn_fwd(const void* qkv, const float* rel_emb, void* out, void* probs, int B, int T, int heads, int dh,
+                  int max_pos, int dtype, void* stream);
+/* dqkv [B*T][3*heads*dh] (T) written; drel_emb += (atomic f32).  dscores: scratch [B][heads][T][T] f32. */
+int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* probs, const void* dout, void* dqkv,
+                  float* drel_emb, float* dscores, int B, int T, int heads, int dh, int max_pos, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ Conv module pieces (lid/conformer.py:47-65,174-205) */
+/* GLU over channels: y [M][2C] -> g [M][C] = y[:, :C] * sigmoid(y[:, C:]) */
+int lidk_glu_fwd(const void* y, void* g, int M, int C, int dtype, void* stream);
+int lidk_glu_bwd(const void* y, const void* dg, void* dy, int M, int C, int dtype, void* stream);
+/* DepthWiseConv1d, channel-last: c[b][t][ch] = bias[ch] + sum_k w[ch][k] * g[b][t+k-pad_left][ch], zero outside [0,T).
+ * stat_partial (optional) [B*ceil(T/32)][2][C]: per-block (sum, sum of squares) of c for the BatchNorm batch statistics. */
+int lidk_dwconv_fwd(const void* g, const float* w, const float* bias, void* c, float* stat_partial, int B, int T, int C,
+                    int K, int pad_left, int dtype, void* stream);
+int lidk_dwconv_stat_parts(int B, int T);
+int lidk_dwconv_bwd_input(const void* dc, const float* w, void* dg, int B, int T, int C, int K, int pad_left, int dtype,
+                          void* stream);
+/* dw [C][K] += , db [C] += ;  partial: >= B*C*(K+1) floats */
+int lidk_dwconv_bwd_weight(const void* dc, const void* g, float* dw, float* db, float* partial, int B, int T, int C,
+                           int K, int pad_left, int dtype, void* stream);
+/* BatchNorm1d training statistics (lid/conformer.py:197): sums [2][C] f64 = (sum x, sum x^2) over `count` rows (already
+ * all-reduced over ranks for SyncBatchNorm, ccml/trainer.py:428) -> mean, rstd (biased var); running stats momentum update
+ * with unbiased var; num_batches_tracked += 1. */
+int lidk_bn_train_stats(const double* sums, double count, float* mean, float* rstd, float* running_mean,
+                        float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int C, void* stream);
+int lidk_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* rstd, float eps, int C,
+                       void* stream);
+/* s = swish(gamma*(c-mean)*rstd + beta) */
+int lidk_bn_swish_fwd(const void* c, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                      void* s, int M, int C, int dtype, void* stream);
+/* backward pass 1: partial [LIDK_LN_PARTIAL_BLOCKS][2][C] of (sum dz, sum dz*xhat), dz = ds*swish'(z) */
+int lidk_bn_swish_bwd_reduce(const void* ds, const void* c, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, float* partial, int M, int C, int dtype, void* stream);
+/* backward pass 2: dc = gamma*rstd*(dz - sums[0]/count - xhat*sums[1]/count); dgamma += sums_local[1]; dbeta += sums_local[0].
+ * sums: all-rank totals [2][C] f64; sums_local: this rank's totals (== sums on one GPU). */
+int lidk_bn_swish_bwd_apply(const void* ds, const void* c, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, const double* sums, const double* sums_local, double count, void* dc,
+                            float* dgamma, float* dbeta, int M, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ Conv1dSubSampling2 im2col (lid/conformer.py:328-348)
+ * mel [B][F][C] f32 -> out [B*T][3*C] (T): row (b,t) = frames 2t-1, 2t, 2t+1 (zero outside), T = (F+2-3)/2+1. */
+int lidk_im2col_k3s2(const float* mel, void* out, int B, int F, int C, int T, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ CTC loss + LID score
+ * lid/LidModule_ASR_Supervised.py:162-168: CTCLoss(blank, reduction='none', zero_infinity)(log_softmax(logits).T, ...).
+ * logits [B][T][V1] f32; targets [B][Lmax] int64; in_len/tg_len [B] int64.  loss [B] f32 (per utterance).
+ * dlogits (optional) [B][T][V1] = grad_scale * d loss_b / d logits.  workspace: lidk_ctc_workspace_bytes(). */
+long lidk_ctc_workspace_bytes(int B, int T, int V1, int Lmax);
+int lidk_ctc_loss(const float* logits, const int64_t* targets, const int64_t* in_len, const int64_t* tg_len,
+                  float* loss, float* dlogits, void* workspace, int B, int T, int V1, int Lmax, int blank,
+                  float grad_scale, int zero_infinity, void* stream);
+/* LangDiscriminator.forward ASR half (lid/ConformerLangModel.py:386-393) for ONE language head:
+ * scores[b*score_stride] = sum_t [argmax!=blank] max_c log_softmax / (count*ln(blank) + 1e-5). */
+int lidk_lid_score(const float* logits, float* scores, int score_stride, int B, int T, int V1, int blank, void* stream);
+
+/* ------------------------------------------------------------------ fused clip + Novograd over the flat arenas
+ * ccml/trainer.py:541-543 clip_grad_norm_(max_norm) + ccml/optim/novograd.py:75-145 (amsgrad=False, luc=False).
+ * work [n_work][3] int64 = (tensor id, element offset into the flat arenas, length <= LIDK_OPT_CHUNK); items of one tensor
+ * are contiguous and tensors appear in ascending id order.  Only tensors present in `work` are touched ("grad is None" for
+ * the rest).  exp_avg_sq [n_tensors]; scratch >= n_work + n_tensors + 8 floats.  total_norm_out [1] (pre-clip norm). */
+#define LIDK_OPT_CHUNK 8192
+int lidk_novograd_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* work, int n_work,
+                       int n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int grad_averaging, float max_norm, float* scratch, float* total_norm_out, void* stream);
+/* Refresh the T-typed GEMM operands from the f32 master parameters: for each of n_mats entries
+ * mats [n][6] int64 = (src offset in `params`, rows, cols, dst offset of W [rows][cols] in wT or -1,
+ * dst offset of W^T [cols][rows] in wT or -1, reserved). */
+int lidk_cast_weights(const float* params, void* wT, const int64_t* mats_host, int n_mats, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,57 @@
+// Shared device helpers for the lidk kernels (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lidk.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LIDK_WAVE 64
+
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float x) { return (bf16)x; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// 4-wide load/store of activations held as T (float or bf16); p must be 4-element aligned.
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const bf16* p) {
+  uint2 r = *reinterpret_cast<const uint2*>(p);
+  float4 v;
+  v.x = __uint_as_float(r.x << 16); v.y = __uint_as_float(r.x & 0xffff0000u);
+  v.z = __uint_as_float(r.y << 16); v.w = __uint_as_float(r.y & 0xffff0000u);
+  return v;
+}
+__device__ __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16* p, float4 v) {
+  union { bf16 h[4]; uint2 u; } t;
+  t.h[0] = (bf16)v.x; t.h[1] = (bf16)v.y; t.h[2] = (bf16)v.z; t.h[3] = (bf16)v.w;
+  *reinterpret_cast<uint2*>(p) = t.u;
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? LIDK_OK : LIDK_ERR_LAUNCH; }
+
+#define LIDK_DISPATCH(dtype, ...)                         \
+  do {                                                    \
+    if ((dtype) == LIDK_F32) { using T = float; __VA_ARGS__; } \
+    else if ((dtype) == LIDK_BF16) { using T = bf16; __VA_ARGS__; } \
+    else return LIDK_ERR_ARG;                             \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,308 @@
+// ConformerConvModule pieces (lid/conformer.py:47-65,174-205), channel-last [B][T][C]:
+// GLU, depthwise Conv1d (k <= 32) with fused BatchNorm partial statistics, BatchNorm(+Swish) forward/backward.
+// All HBM-bound: lanes run over channels (coalesced), the time window slides through registers.
+#include "common.h"
+
+#define DW_TT 32      // output time steps per workgroup (4 waves x 8)
+#define DW_KMAX 32
+#define DW_ROWS (DW_TT + DW_KMAX)   // staged input rows (zero beyond the needed 32+K-1)
+
+// ------------------------------------------------------------------------------------ GLU
+template <typename T>
+__global__ void glu_fwd_kernel(const T* __restrict__ y, T* __restrict__ g, long M, int C) {
+  long n4 = M * C / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    long e = i * 4, m = e / C; int c = (int)(e - m * C);
+    float4 a = load4(y + m * 2 * C + c), b = load4(y + m * 2 * C + C + c), o;
+    o.x = a.x * sigmoidf_(b.x); o.y = a.y * sigmoidf_(b.y); o.z = a.z * sigmoidf_(b.z); o.w = a.w * sigmoidf_(b.w);
+    store4(g + e, o);
+  }
+}
+template <typename T>
+__global__ void glu_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dg, T* __restrict__ dy, long M, int C) {
+  long n4 = M * C / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    long e = i * 4, m = e / C; int c = (int)(e - m * C);
+    float4 a = load4(y + m * 2 * C + c), b = load4(y + m * 2 * C + C + c), d = load4(dg + e), oa, ob;
+    float s;
+    s = sigmoidf_(b.x); oa.x = d.x * s; ob.x = d.x * a.x * s * (1.f - s);
+    s = sigmoidf_(b.y); oa.y = d.y * s; ob.y = d.y * a.y * s * (1.f - s);
+    s = sigmoidf_(b.z); oa.z = d.z * s; ob.z = d.z * a.z * s * (1.f - s);
+    s = sigmoidf_(b.w); oa.w = d.w * s; ob.w = d.w * a.w * s * (1.f - s);
+    store4(dy + m * 2 * C + c, oa);
+    store4(dy + m * 2 * C + C + c, ob);
+  }
+}
+static int ew_blocks(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+
+extern "C" int lidk_glu_fwd(const void* y, void* g, int M, int C, int dtype, void* stream) {
+  if (!y || !g || M <= 0 || C <= 0 || (C & 3)) return LIDK_ERR_ARG;
+  LIDK_DISPATCH(dtype, glu_fwd_kernel<T><<<ew_blocks((long)M * C / 4), 256, 0, as_stream(stream)>>>((const T*)y, (T*)g, M, C));
+  return launch_status();
+}
+extern "C" int lidk_glu_bwd(const void* y, const void* dg, void* dy, int M, int C, int dtype, void* stream) {
+  if (!y || !dg || !dy || M <= 0 || C <= 0 || (C & 3)) return LIDK_ERR_ARG;
+  LIDK_DISPATCH(dtype, glu_bwd_kernel<T><<<ew_blocks((long)M * C / 4), 256, 0, as_stream(stream)>>>((const T*)y, (const T*)dg, (T*)dy, M, C));
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ depthwise conv (fwd and dgrad)
+// out[b][t][ch] = bias[ch] + sum_k w[ch][k] * in[b][t + k - pad_left][ch]   (flip=1: w[ch][K-1-k], used for dgrad)
+template <typename T>
+__global__ void __launch_bounds__(256)
+dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
+              float* __restrict__ stat_partial, int B, int T_, int C, int K, int pad_left, int flip) {
+  __shared__ T tile[DW_ROWS][64];
+  __shared__ float red[4][2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * 64, b = blockIdx.z;
+  const int ch = c0 + lane;
+  const bool chok = ch < C;
+  for (int r = wave; r < DW_ROWS; r += 4) {
+    int t = t0 - pad_left + r;
+    T v = from_f<T>(0.f);
+    if (chok && t >= 0 && t < T_ && r < DW_TT + K - 1) v = in[((size_t)b * T_ + t) * C + ch];
+    tile[r][lane] = v;
+  }
+  float wr[DW_KMAX];
+#pragma unroll
+  for (int k = 0; k < DW_KMAX; ++k) wr[k] = (chok && k < K) ? w[(size_t)ch * K + (flip ? K - 1 - k : k)] : 0.f;
+  const float bv = (bias && chok) ? bias[ch] : 0.f;
+  __syncthreads();
+  float x[8 + DW_KMAX - 1];
+#pragma unroll
+  for (int r = 0; r < 8 + DW_KMAX - 1; ++r) x[r] = to_f(tile[wave * 8 + r][lane]);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    float acc = bv;
+#pragma unroll
+    for (int k = 0; k < DW_KMAX; ++k) acc = fmaf(wr[k], x[o + k], acc);
+    int t = t0 + wave * 8 + o;
+    if (chok && t < T_) {
+      out[((size_t)b * T_ + t) * C + ch] = from_f<T>(acc);
+      s1 += acc; s2 = fmaf(acc, acc, s2);
+    }
+  }
+  if (stat_partial) {
+    red[wave][0][lane] = s1; red[wave][1][lane] = s2;
+    __syncthreads();
+    if (wave == 0 && chok) {
+      size_t p = (size_t)b * gridDim.x + blockIdx.x;
+      stat_partial[(p * 2 + 0) * C + ch] = red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane];
+      stat_partial[(p * 2 + 1) * C + ch] = red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane];
+    }
+  }
+}
+
+extern "C" int lidk_dwconv_stat_parts(int B, int T_) { return B * cdiv(T_, DW_TT); }
+
+extern "C" int lidk_dwconv_fwd(const void* g, const float* w, const float* bias, void* c, float* stat_partial, int B,
+                               int T_, int C, int K, int pad_left, int dtype, void* stream) {
+  if (!g || !w || !c || B <= 0 || T_ <= 0 || C <= 0 || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K) return LIDK_ERR_ARG;
+  dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
+  LIDK_DISPATCH(dtype, dwconv_kernel<T><<<grid, 256, 0, as_stream(stream)>>>((const T*)g, w, bias, (T*)c, stat_partial, B,
+                                                                            T_, C, K, pad_left, 0));
+  return launch_status();
+}
+
+extern "C" int lidk_dwconv_bwd_input(const void* dc, const float* w, void* dg, int B, int T_, int C, int K, int pad_left,
+                                     int dtype, void* stream) {
+  if (!dc || !w || !dg || B <= 0 || T_ <= 0 || C <= 0 || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K) return LIDK_ERR_ARG;
+  dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
+  LIDK_DISPATCH(dtype, dwconv_kernel<T><<<grid, 256, 0, as_stream(stream)>>>((const T*)dc, w, nullptr, (T*)dg, nullptr, B,
+                                                                            T_, C, K, K - 1 - pad_left, 1));
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ depthwise conv wgrad
+// partial[b][ch][k] = sum_t dc[b][t][ch] * g[b][t+k-pad_left][ch]  (k < K),  partial[b][ch][K] = sum_t dc[b][t][ch]
+template <typename T>
+__global__ void __launch_bounds__(256)
+dwconv_wgrad_kernel(const T* __restrict__ dc, const T* __restrict__ g, float* __restrict__ partial, int B, int T_, int C,
+                    int K, int pad_left) {
+  __shared__ T gt[DW_ROWS][64];
+  __shared__ T dt[DW_TT][64];
+  __shared__ float red[4][DW_KMAX + 1][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 64, b = blockIdx.y, ch = c0 + lane;
+  const bool chok = ch < C;
+  float acc[DW_KMAX + 1];
+#pragma unroll
+  for (int k = 0; k <= DW_KMAX; ++k) acc[k] = 0.f;
+  for (int t0 = 0; t0 < T_; t0 += DW_TT) {
+    __syncthreads();
+    for (int r = wave; r < DW_ROWS; r += 4) {
+      int t = t0 - pad_left + r;
+      gt[r][lane] = (chok && t >= 0 && t < T_) ? g[((size_t)b * T_ + t) * C + ch] : from_f<T>(0.f);
+    }
+    for (int r = wave; r < DW_TT; r += 4) {
+      int t = t0 + r;
+      dt[r][lane] = (chok && t < T_) ? dc[((size_t)b * T_ + t) * C + ch] : from_f<T>(0.f);
+    }
+    __syncthreads();
+    float x[8 + DW_KMAX - 1];
+#pragma unroll
+    for (int r = 0; r < 8 + DW_KMAX - 1; ++r) x[r] = to_f(gt[wave * 8 + r][lane]);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      float d = to_f(dt[wave * 8 + o][lane]);
+#pragma unroll
+      for (int k = 0; k < DW_KMAX; ++k) acc[k] = fmaf(d, x[o + k], acc[k]);
+      acc[DW_KMAX] += d;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k <= DW_KMAX; ++k) red[wave][k][lane] = acc[k];
+  __syncthreads();
+  if (wave == 0 && chok) {
+    float* p = partial + ((size_t)b * C + ch) * (K + 1);
+    for (int k = 0; k < K; ++k) p[k] = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
+    p[K] = red[0][DW_KMAX][lane] + red[1][DW_KMAX][lane] + red[2][DW_KMAX][lane] + red[3][DW_KMAX][lane];
+  }
+}
+
+__global__ void dwconv_wgrad_finalize_kernel(const float* __restrict__ partial, int B, int C, int K, float* __restrict__ dw,
+                                             float* __restrict__ db) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * (K + 1)) return;
+  int ch = idx / (K + 1), k = idx - ch * (K + 1);
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc += partial[((size_t)b * C + ch) * (K + 1) + k];
+  if (k < K) dw[(size_t)ch * K + k] += acc;
+  else if (db) db[ch] += acc;
+}
+
+extern "C" int lidk_dwconv_bwd_weight(const void* dc, const void* g, float* dw, float* db, float* partial, int B, int T_,
+                                      int C, int K, int pad_left, int dtype, void* stream) {
+  if (!dc || !g || !dw || !partial || B <= 0 || T_ <= 0 || C <= 0 || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  dim3 grid(cdiv(C, 64), B);
+  LIDK_DISPATCH(dtype, dwconv_wgrad_kernel<T><<<grid, 256, 0, s>>>((const T*)dc, (const T*)g, partial, B, T_, C, K, pad_left));
+  dwconv_wgrad_finalize_kernel<<<cdiv(C * (K + 1), 256), 256, 0, s>>>(partial, B, C, K, dw, db);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ BatchNorm statistics
+__global__ void bn_train_stats_kernel(const double* __restrict__ sums, double count, float* __restrict__ mean,
+                                      float* __restrict__ rstd, float* __restrict__ rmean, float* __restrict__ rvar,
+                                      int64_t* __restrict__ nbt, float momentum, float eps, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double mu = sums[c] / count;
+  double var = sums[C + c] / count - mu * mu;
+  if (var < 0) var = 0;
+  mean[c] = (float)mu;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * (count / (count > 1 ? count - 1 : 1)));
+}
+extern "C" int lidk_bn_train_stats(const double* sums, double count, float* mean, float* rstd, float* running_mean,
+                                   float* running_var, int64_t* nbt, float momentum, float eps, int C, void* stream) {
+  if (!sums || !mean || !rstd || count <= 0 || C <= 0) return LIDK_ERR_ARG;
+  bn_train_stats_kernel<<<cdiv(C, 256), 256, 0, as_stream(stream)>>>(sums, count, mean, rstd, running_mean, running_var,
+                                                                     nbt, momentum, eps, C);
+  return launch_status();
+}
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                     float* __restrict__ mean, float* __restrict__ rstd, float eps, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rmean[c];
+  rstd[c] = 1.0f / sqrtf(rvar[c] + eps);
+}
+extern "C" int lidk_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* rstd, float eps,
+                                  int C, void* stream) {
+  if (!running_mean || !running_var || !mean || !rstd || C <= 0) return LIDK_ERR_ARG;
+  bn_eval_stats_kernel<<<cdiv(C, 256), 256, 0, as_stream(stream)>>>(running_mean, running_var, mean, rstd, eps, C);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ BatchNorm + Swish forward
+template <typename T>
+__global__ void bn_swish_fwd_kernel(const T* __restrict__ c, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ s,
+                                    long M, int C) {
+  long n4 = M * C / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    long e = i * 4; int ch = (int)(e % C);
+    float4 x = load4(c + e), mu = load4(mean + ch), rs = load4(rstd + ch), g = load4(gamma + ch), b = load4(beta + ch), o;
+    float z;
+    z = (x.x - mu.x) * rs.x * g.x + b.x; o.x = z * sigmoidf_(z);
+    z = (x.y - mu.y) * rs.y * g.y + b.y; o.y = z * sigmoidf_(z);
+    z = (x.z - mu.z) * rs.z * g.z + b.z; o.z = z * sigmoidf_(z);
+    z = (x.w - mu.w) * rs.w * g.w + b.w; o.w = z * sigmoidf_(z);
+    store4(s + e, o);
+  }
+}
+extern "C" int lidk_bn_swish_fwd(const void* c, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                 void* s, int M, int C, int dtype, void* stream) {
+  if (!c || !mean || !rstd || !gamma || !beta || !s || M <= 0 || C <= 0 || (C & 3)) return LIDK_ERR_ARG;
+  LIDK_DISPATCH(dtype, bn_swish_fwd_kernel<T><<<ew_blocks((long)M * C / 4), 256, 0, as_stream(stream)>>>(
+                           (const T*)c, mean, rstd, gamma, beta, (T*)s, M, C));
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ BatchNorm + Swish backward
+__device__ __forceinline__ float swish_grad(float z) { float s = sigmoidf_(z); return s * (1.f + z * (1.f - s)); }
+
+template <typename T>
+__global__ void bn_swish_bwd_reduce_kernel(const T* __restrict__ ds, const T* __restrict__ c, const float* __restrict__ mean,
+                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, float* __restrict__ partial, int M, int C) {
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    const float mu = mean[ch], rs = rstd[ch], g = gamma[ch], b = beta[ch];
+    float a0 = 0.f, a1 = 0.f;
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+      float xh = (to_f(c[(size_t)m * C + ch]) - mu) * rs;
+      float dz = to_f(ds[(size_t)m * C + ch]) * swish_grad(xh * g + b);
+      a0 += dz; a1 = fmaf(dz, xh, a1);
+    }
+    partial[((size_t)blockIdx.x * 2 + 0) * C + ch] = a0;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + ch] = a1;
+  }
+}
+extern "C" int lidk_bn_swish_bwd_reduce(const void* ds, const void* c, const float* mean, const float* rstd,
+                                        const float* gamma, const float* beta, float* partial, int M, int C, int dtype,
+                                        void* stream) {
+  if (!ds || !c || !mean || !rstd || !gamma || !beta || !partial || M <= 0 || C <= 0) return LIDK_ERR_ARG;
+  // always LIDK_LN_PARTIAL_BLOCKS partial rows; blocks beyond M write zeros
+  LIDK_DISPATCH(dtype, bn_swish_bwd_reduce_kernel<T><<<LIDK_LN_PARTIAL_BLOCKS, 256, 0, as_stream(stream)>>>(
+                           (const T*)ds, (const T*)c, mean, rstd, gamma, beta, partial, M, C));
+  return launch_status();
+}
+
+template <typename T>
+__global__ void bn_swish_bwd_apply_kernel(const T* __restrict__ ds, const T* __restrict__ c, const float* __restrict__ mean,
+                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, const double* __restrict__ sums, double count,
+                                          T* __restrict__ dc, long M, int C) {
+  long n = M * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int ch = (int)(i % C);
+    float mu = mean[ch], rs = rstd[ch], g = gamma[ch];
+    float xh = (to_f(c[i]) - mu) * rs;
+    float dz = to_f(ds[i]) * swish_grad(xh * g + beta[ch]);
+    float m0 = (float)(sums[ch] / count), m1 = (float)(sums[C + ch] / count);
+    dc[i] = from_f<T>(g * rs * (dz - m0 - xh * m1));
+  }
+}
+__global__ void bn_param_grad_kernel(const double* __restrict__ sums_local, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int C) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  if (dbeta) dbeta[ch] += (float)sums_local[ch];
+  if (dgamma) dgamma[ch] += (float)sums_local[C + ch];
+}
+extern "C" int lidk_bn_swish_bwd_apply(const void* ds, const void* c, const float* mean, const float* rstd,
+                                       const float* gamma, const float* beta, const double* sums,
+                                       const double* sums_local, double count, void* dc, float* dgamma, float* dbeta,
+                                       int M, int C, int dtype, void* stream) {
+  if (!ds || !c || !mean || !rstd || !gamma || !beta || !sums || !sums_local || !dc || count <= 0 || M <= 0 || C <= 0) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  LIDK_DISPATCH(dtype, bn_swish_bwd_apply_kernel<T><<<ew_blocks((long)M * C), 256, 0, s>>>(
+                           (const T*)ds, (const T*)c, mean, rstd, gamma, beta, sums, count, (T*)dc, M, C));
+  bn_param_grad_kernel<<<cdiv(C, 256), 256, 0, s>>>(sums_local, dgamma, dbeta, C);
+  return launch_status();
+}

@@ -1,0 +1,309 @@
+// Element-wise helpers, column reductions, transpose and LayerNorm (HBM-bound kernels).
+// One wave (64 lanes) per row for row-wise ops, 16-byte accesses, wave-shuffle reductions.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------ scale_cast
+template <typename TI, typename TO>
+__global__ void scale_cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long n, float scale) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    float4 v = load4(x + i);
+    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    store4(y + i, v);
+  }
+  if (i < n) for (long j = i; j < n; ++j) y[j] = from_f<TO>(to_f(x[j]) * scale);
+}
+
+template <typename TI, typename TO>
+static int scale_cast_launch(const void* x, void* y, long n, float scale, hipStream_t s) {
+  int blocks = (int)((n / 4 + 255) / 256);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  scale_cast_kernel<TI, TO><<<blocks, 256, 0, s>>>((const TI*)x, (TO*)y, n, scale);
+  return launch_status();
+}
+
+extern "C" int lidk_scale_cast(const void* x, int xd, void* y, int yd, long n, float scale, void* stream) {
+  if (!x || !y || n < 0) return LIDK_ERR_ARG;
+  if (n == 0) return LIDK_OK;
+  hipStream_t s = as_stream(stream);
+  if (xd == LIDK_F32 && yd == LIDK_F32) return scale_cast_launch<float, float>(x, y, n, scale, s);
+  if (xd == LIDK_F32 && yd == LIDK_BF16) return scale_cast_launch<float, bf16>(x, y, n, scale, s);
+  if (xd == LIDK_BF16 && yd == LIDK_F32) return scale_cast_launch<bf16, float>(x, y, n, scale, s);
+  if (xd == LIDK_BF16 && yd == LIDK_BF16) return scale_cast_launch<bf16, bf16>(x, y, n, scale, s);
+  return LIDK_ERR_ARG;
+}
+
+// ------------------------------------------------------------------------------------ dropout
+// Counter-based generator: splitmix64 of (seed, element index) -> 24-bit uniform.  Stateless, so the same
+// (seed, index) gives the same decision on every rank and in the backward pass.
+__device__ __forceinline__ float uniform_from(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+template <typename TI, typename TO>
+__global__ void dropout_kernel(const TI* __restrict__ x, TO* __restrict__ y, const uint8_t* __restrict__ keep_in,
+                               uint8_t* __restrict__ keep_out, long n, float p, float inv_keep, uint64_t seed) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    bool keep = keep_in ? (keep_in[i] != 0) : (uniform_from(seed, (uint64_t)i) >= p);
+    if (keep_out) keep_out[i] = keep ? 1 : 0;
+    y[i] = from_f<TO>(keep ? to_f(x[i]) * inv_keep : 0.0f);
+  }
+}
+
+template <typename TI, typename TO>
+static int dropout_launch(const void* x, void* y, const uint8_t* ki, uint8_t* ko, long n, float p, uint64_t seed,
+                          hipStream_t s) {
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  dropout_kernel<TI, TO><<<blocks, 256, 0, s>>>((const TI*)x, (TO*)y, ki, ko, n, p, 1.0f / (1.0f - p), seed);
+  return launch_status();
+}
+
+extern "C" int lidk_dropout(const void* x, int xd, void* y, int yd, const uint8_t* keep_in, uint8_t* keep_out, long n,
+                            float p, uint64_t seed, void* stream) {
+  if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return LIDK_ERR_ARG;
+  if (n == 0) return LIDK_OK;
+  hipStream_t s = as_stream(stream);
+  if (xd == LIDK_F32 && yd == LIDK_F32) return dropout_launch<float, float>(x, y, keep_in, keep_out, n, p, seed, s);
+  if (xd == LIDK_F32 && yd == LIDK_BF16) return dropout_launch<float, bf16>(x, y, keep_in, keep_out, n, p, seed, s);
+  if (xd == LIDK_BF16 && yd == LIDK_F32) return dropout_launch<bf16, float>(x, y, keep_in, keep_out, n, p, seed, s);
+  if (xd == LIDK_BF16 && yd == LIDK_BF16) return dropout_launch<bf16, bf16>(x, y, keep_in, keep_out, n, p, seed, s);
+  return LIDK_ERR_ARG;
+}
+
+// ------------------------------------------------------------------------------------ relu backward
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dx[i] = to_f(y[i]) > 0.f ? dy[i] : from_f<T>(0.f);
+}
+
+extern "C" int lidk_relu_bwd(const void* dy, const void* y, void* dx, long n, int dtype, void* stream) {
+  if (!dy || !y || !dx || n < 0) return LIDK_ERR_ARG;
+  if (n == 0) return LIDK_OK;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  LIDK_DISPATCH(dtype, relu_bwd_kernel<T><<<blocks, 256, 0, as_stream(stream)>>>((const T*)dy, (const T*)y, (T*)dx, n));
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ column sums
+// Stage 1: block b sums rows b, b+G, ... for every column (lanes over columns -> coalesced); stage 2 adds the
+// G partial rows in fixed order (deterministic) into out[] with a scale.
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ x, int ldx, float* __restrict__ partial, int M, int N) {
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    float acc = 0.f;
+    for (int m = blockIdx.x; m < M; m += gridDim.x) acc += to_f(x[(size_t)m * ldx + n]);
+    partial[(size_t)blockIdx.x * N + n] = acc;
+  }
+}
+
+__global__ void partial_finalize_kernel(const float* __restrict__ partial, int nparts, int ncols, float* __restrict__ out,
+                                        float scale) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  float acc = 0.f;
+  for (int p = 0; p < nparts; ++p) acc += partial[(size_t)p * ncols + c];
+  out[c] += scale * acc;
+}
+
+extern "C" int lidk_colsum(const void* x, int ldx, int xd, float* out, float* partial, int M, int N, float scale,
+                           void* stream) {
+  if (!x || !out || !partial || M <= 0 || N <= 0) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  int G = M < LIDK_LN_PARTIAL_BLOCKS ? M : LIDK_LN_PARTIAL_BLOCKS;
+  LIDK_DISPATCH(xd, colsum_partial_kernel<T><<<G, 256, 0, s>>>((const T*)x, ldx, partial, M, N));
+  partial_finalize_kernel<<<cdiv(N, 256), 256, 0, s>>>(partial, G, N, out, scale);
+  return launch_status();
+}
+
+__global__ void reduce_partials_f64_kernel(const float* __restrict__ partial, int nparts, int ncols, double* __restrict__ out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  double acc = 0.0;
+  for (int p = 0; p < nparts; ++p) acc += (double)partial[(size_t)p * ncols + c];
+  out[c] = acc;
+}
+
+extern "C" int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double* out, void* stream) {
+  if (!partial || !out || nparts <= 0 || ncols <= 0) return LIDK_ERR_ARG;
+  reduce_partials_f64_kernel<<<cdiv(ncols, 256), 256, 0, as_stream(stream)>>>(partial, nparts, ncols, out);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ transpose
+template <typename T>
+__global__ void transpose_kernel(const T* __restrict__ in, int ldi, T* __restrict__ out, int ldo, int R, int C) {
+  __shared__ T tile[64][65];
+  int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 4 rows per pass
+  for (int i = ty; i < 64; i += 4) {
+    int r = r0 + i, c = c0 + tx;
+    if (r < R && c < C) tile[i][tx] = in[(size_t)r * ldi + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    int c = c0 + i, r = r0 + tx;
+    if (r < R && c < C) out[(size_t)c * ldo + r] = tile[tx][i];
+  }
+}
+
+extern "C" int lidk_transpose(const void* in, int ldi, void* out, int ldo, int R, int C, int dtype, void* stream) {
+  if (!in || !out || R <= 0 || C <= 0 || ldi < C || ldo < R) return LIDK_ERR_ARG;
+  dim3 grid(cdiv(C, 64), cdiv(R, 64));
+  LIDK_DISPATCH(dtype, transpose_kernel<T><<<grid, 256, 0, as_stream(stream)>>>((const T*)in, ldi, (T*)out, ldo, R, C));
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm forward
+#define LN_MAX_VEC 4   // up to 4 float4 per lane -> C <= 1024
+template <typename T>
+__global__ void __launch_bounds__(256)
+ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+              T* __restrict__ yT, float* __restrict__ y32, float* __restrict__ mean, float* __restrict__ rstd, int M,
+              int C, float eps) {
+  int lane = threadIdx.x & 63;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * C;
+  float4 v[LN_MAX_VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_VEC; ++k) {
+    int c = lane * 4 + k * 256;
+    if (c < C) { v[k] = load4(xr + c); s += v[k].x + v[k].y + v[k].z + v[k].w; }
+  }
+  float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_VEC; ++k) {
+    int c = lane * 4 + k * 256;
+    if (c < C) {
+      float a = v[k].x - mu, b = v[k].y - mu, d = v[k].z - mu, e = v[k].w - mu;
+      q += a * a + b * b + d * d + e * e;
+    }
+  }
+  float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+#pragma unroll
+  for (int k = 0; k < LN_MAX_VEC; ++k) {
+    int c = lane * 4 + k * 256;
+    if (c < C) {
+      float4 g = load4(gamma + c), b = load4(beta + c), o;
+      o.x = (v[k].x - mu) * rs * g.x + b.x; o.y = (v[k].y - mu) * rs * g.y + b.y;
+      o.z = (v[k].z - mu) * rs * g.z + b.z; o.w = (v[k].w - mu) * rs * g.w + b.w;
+      if (yT) store4(yT + (size_t)row * C + c, o);
+      if (y32) store4(y32 + (size_t)row * C + c, o);
+    }
+  }
+}
+
+extern "C" int lidk_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* yT, float* y32,
+                                  float* mean, float* rstd, int M, int C, float eps, int dtype, void* stream) {
+  if (!x || !gamma || !beta || (!yT && !y32) || M <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAX_VEC) return LIDK_ERR_ARG;
+  LIDK_DISPATCH(dtype, ln_fwd_kernel<T><<<cdiv(M, 4), 256, 0, as_stream(stream)>>>(x, gamma, beta, (T*)yT, y32, mean,
+                                                                                  rstd, M, C, eps));
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm backward
+// Each wave walks rows (grid-stride), keeps per-column dgamma/dbeta partials in registers, then the 4 waves of a
+// block combine through LDS and write one partial row; partial_finalize adds them into the gradient arena.
+template <typename T, typename TDY>
+__global__ void __launch_bounds__(256)
+ln_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+              const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ dres,
+              float* __restrict__ dx, T* __restrict__ dxT, float dxT_scale, float* __restrict__ partial, int M, int C) {
+  __shared__ float red[4][2 * 256 * LN_MAX_VEC];   // [wave][2*C], worst case C=1024 -> 2048 floats per wave (32 KiB)
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 dg[LN_MAX_VEC], db[LN_MAX_VEC], gm[LN_MAX_VEC];
+#pragma unroll
+  for (int k = 0; k < LN_MAX_VEC; ++k) {
+    dg[k] = make_float4(0, 0, 0, 0); db[k] = make_float4(0, 0, 0, 0);
+    int c = lane * 4 + k * 256;
+    gm[k] = c < C ? load4(gamma + c) : make_float4(0, 0, 0, 0);
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    float mu = mean[row], rs = rstd[row];
+    float4 xh[LN_MAX_VEC], g[LN_MAX_VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAX_VEC; ++k) {
+      int c = lane * 4 + k * 256;
+      if (c < C) {
+        float4 xv = load4(x + (size_t)row * C + c);
+        float4 d = load4(dy + (size_t)row * C + c);
+        xh[k].x = (xv.x - mu) * rs; xh[k].y = (xv.y - mu) * rs; xh[k].z = (xv.z - mu) * rs; xh[k].w = (xv.w - mu) * rs;
+        g[k].x = d.x * gm[k].x; g[k].y = d.y * gm[k].y; g[k].z = d.z * gm[k].z; g[k].w = d.w * gm[k].w;
+        s1 += g[k].x + g[k].y + g[k].z + g[k].w;
+        s2 += g[k].x * xh[k].x + g[k].y * xh[k].y + g[k].z * xh[k].z + g[k].w * xh[k].w;
+        dg[k].x += d.x * xh[k].x; dg[k].y += d.y * xh[k].y; dg[k].z += d.z * xh[k].z; dg[k].w += d.w * xh[k].w;
+        db[k].x += d.x; db[k].y += d.y; db[k].z += d.z; db[k].w += d.w;
+      }
+    }
+    float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int k = 0; k < LN_MAX_VEC; ++k) {
+      int c = lane * 4 + k * 256;
+      if (c < C) {
+        float4 o;
+        o.x = rs * (g[k].x - m1 - xh[k].x * m2); o.y = rs * (g[k].y - m1 - xh[k].y * m2);
+        o.z = rs * (g[k].z - m1 - xh[k].z * m2); o.w = rs * (g[k].w - m1 - xh[k].w * m2);
+        if (dres) { float4 r = load4(dres + (size_t)row * C + c); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        if (dx) store4(dx + (size_t)row * C + c, o);
+        if (dxT) {
+          o.x *= dxT_scale; o.y *= dxT_scale; o.z *= dxT_scale; o.w *= dxT_scale;
+          store4(dxT + (size_t)row * C + c, o);
+        }
+      }
+    }
+  }
+  // combine the block's 4 waves: red[wave][0..C) = dgamma, red[wave][C..2C) = dbeta
+#pragma unroll
+  for (int k = 0; k < LN_MAX_VEC; ++k) {
+    int c = lane * 4 + k * 256;
+    if (c < C) { store4(&red[wave][c], dg[k]); store4(&red[wave][C + c], db[k]); }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256)
+    partial[(size_t)blockIdx.x * 2 * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * C) return;
+  float acc = 0.f;
+  for (int p = 0; p < nparts; ++p) acc += partial[(size_t)p * 2 * C + c];
+  if (c < C) { if (dgamma) dgamma[c] += acc; } else { if (dbeta) dbeta[c - C] += acc; }
+}
+
+extern "C" int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                                  const float* gamma, const float* dres, float* dx, void* dxT, float dxT_scale,
+                                  float* dgamma, float* dbeta, float* partial, int M, int C, int dtype, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !partial || (!dx && !dxT) || M <= 0 || C <= 0 || (C & 3) ||
+      C > 256 * LN_MAX_VEC)
+    return LIDK_ERR_ARG;
+  if (dy_dtype != LIDK_F32 && dy_dtype != dtype) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  int G = cdiv(M, 4) < LIDK_LN_PARTIAL_BLOCKS ? cdiv(M, 4) : LIDK_LN_PARTIAL_BLOCKS;
+  if (dy_dtype == LIDK_F32) {
+    LIDK_DISPATCH(dtype, ln_bwd_kernel<T, float><<<G, 256, 0, s>>>((const float*)dy, x, mean, rstd, gamma, dres, dx,
+                                                                  (T*)dxT, dxT_scale, partial, M, C));
+  } else {
+    LIDK_DISPATCH(dtype, ln_bwd_kernel<T, T><<<G, 256, 0, s>>>((const T*)dy, x, mean, rstd, gamma, dres, dx, (T*)dxT,
+                                                              dxT_scale, partial, M, C));
+  }
+  ln_bwd_finalize_kernel<<<cdiv(2 * C, 256), 256, 0, s>>>(partial, G, C, dgamma, dbeta);
+  return launch_status();
+}

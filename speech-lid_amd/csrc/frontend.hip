@@ -1,0 +1,216 @@
+// Feature path: normalize_wav, dither + pre-emphasis, STFT -> |X|^2 -> mel -> dB -> top_db floor -> SpecAugment masks
+// (lid/audio_processor.py:72-134,198-228) and the Conv1dSubSampling2 im2col (lid/conformer.py:328-348).
+// The STFT is a 512-point radix-2 FFT per frame held entirely in LDS by ONE wave (4 butterflies per lane per
+// stage, 9 stages); power, mel projection and log are fused behind it so a frame's samples are read once and
+// only its 80 mel values are written (algorithmic bytes: 4*L in + 4*80*F out per utterance).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------ normalize_wav
+__global__ void __launch_bounds__(1024) normalize_wav_kernel(const float* __restrict__ wav, float* __restrict__ out, int L) {
+  __shared__ float red[16];
+  __shared__ float bc;
+  const float* x = wav + (size_t)blockIdx.x * L;
+  float* y = out + (size_t)blockIdx.x * L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) s += x[i];
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < 16; ++w) t += red[w]; bc = t / (float)L; }
+  __syncthreads();
+  const float mu = bc;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) { float d = x[i] - mu; q = fmaf(d, d, q); }
+  q = wave_sum(q);
+  __syncthreads();
+  if (lane == 0) red[wave] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < 16; ++w) t += red[w]; bc = 1.0f / (sqrtf(t / (float)(L - 1)) + 1e-6f); }
+  __syncthreads();
+  const float inv = bc;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) y[i] = (x[i] - mu) * inv;
+}
+
+extern "C" int lidk_normalize_wav(const float* wav, float* out, int B, int L, void* stream) {
+  if (!wav || !out || B <= 0 || L < 2) return LIDK_ERR_ARG;
+  normalize_wav_kernel<<<B, 1024, 0, as_stream(stream)>>>(wav, out, L);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ dither + pre-emphasis
+__device__ __forceinline__ float uniform_from(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ void dither_preemph_kernel(const float* __restrict__ wav, float* __restrict__ out, const float* __restrict__ noise,
+                                      int L, long n, float coef, float dither, uint64_t seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int t = (int)(i % L);
+    float u1 = dither != 0.f ? (noise ? noise[i] : uniform_from(seed, (uint64_t)i)) : 0.f;
+    float cur = wav[i] + dither * u1;
+    if (t > 0) {
+      float u0 = dither != 0.f ? (noise ? noise[i - 1] : uniform_from(seed, (uint64_t)(i - 1))) : 0.f;
+      cur -= coef * (wav[i - 1] + dither * u0);
+    }
+    out[i] = cur;
+  }
+}
+
+extern "C" int lidk_dither_preemph(const float* wav, float* out, const float* noise, int B, int L, float coef, float dither,
+                                   uint64_t seed, void* stream) {
+  if (!wav || !out || wav == out || B <= 0 || L <= 0) return LIDK_ERR_ARG;
+  long n = (long)B * L;
+  int blocks = (int)((n + 255) / 256); if (blocks > 8192) blocks = 8192;
+  dither_preemph_kernel<<<blocks, 256, 0, as_stream(stream)>>>(wav, out, noise, L, n, coef, dither, seed);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ log-mel
+__global__ void fill_kernel(float* p, int n, float v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+// One wave per frame.  LDS per wave: re[512], im[512]; shared twiddle[256][2], window[512].
+__global__ void __launch_bounds__(256)
+stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ twiddle,
+                const float* __restrict__ melfb, float* __restrict__ out, float* __restrict__ utt_max, int B, int L,
+                int pad, int hop, int F, int n_mels) {
+  __shared__ float s_re[4][LIDK_N_FFT];
+  __shared__ float s_im[4][LIDK_N_FFT];
+  __shared__ float s_tw[LIDK_N_FFT / 2][2];
+  __shared__ float s_win[LIDK_N_FFT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < LIDK_N_FFT; i += 256) s_win[i] = window[i];
+  for (int i = threadIdx.x; i < LIDK_N_FFT / 2; i += 256) { s_tw[i][0] = twiddle[2 * i]; s_tw[i][1] = twiddle[2 * i + 1]; }
+  __syncthreads();
+  float* re = s_re[wave];
+  float* im = s_im[wave];
+  const int Lp = L + 2 * pad;
+  const long nframes = (long)B * F;
+  for (long fr = (long)blockIdx.x * 4 + wave; fr < nframes; fr += (long)gridDim.x * 4) {
+    const int b = (int)(fr / F), f = (int)(fr - (long)b * F);
+    const float* x = wav + (size_t)b * L;
+    // windowed frame, bit-reversed placement
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      int n = lane + 64 * q;
+      int p = f * hop + n - LIDK_N_FFT / 2;
+      if (p < 0) p = -p;
+      if (p >= Lp) p = 2 * (Lp - 1) - p;
+      int s = p - pad;
+      float v = (s >= 0 && s < L) ? x[s] * s_win[n] : 0.f;
+      int r = (int)(__brev((unsigned)n) >> 23);
+      re[r] = v; im[r] = 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 9 radix-2 DIT stages
+#pragma unroll
+    for (int st = 1; st <= 9; ++st) {
+      const int half = 1 << (st - 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int idx = lane + 64 * q;
+        int pos = idx & (half - 1);
+        int i = ((idx >> (st - 1)) << st) + pos;
+        int j = i + half;
+        int tk = pos << (9 - st);
+        float wr = s_tw[tk][0], wi = -s_tw[tk][1];
+        float xr = re[j], xi = im[j];
+        float tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
+        float ur = re[i], ui = im[i];
+        re[j] = ur - tr; im[j] = ui - ti;
+        re[i] = ur + tr; im[i] = ui + ti;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // power spectrum into re[0..256]
+    float pw[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { int k = lane + 64 * q; pw[q] = (k <= LIDK_N_FFT / 2) ? re[k] * re[k] + im[k] * im[k] : 0.f; }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { int k = lane + 64 * q; if (k <= LIDK_N_FFT / 2) re[k] = pw[q]; }
+    __builtin_amdgcn_wave_barrier();
+    // mel projection + dB; lanes over mel bins (coalesced filterbank reads and output writes)
+    float vmax = -INFINITY;
+    for (int m = lane; m < n_mels; m += 64) {
+      float acc = 0.f;
+      for (int k = 0; k <= LIDK_N_FFT / 2; ++k) acc = fmaf(re[k], melfb[(size_t)k * n_mels + m], acc);
+      float db = 10.0f * log10f(fmaxf(acc, 1e-10f));
+      out[((size_t)b * F + f) * n_mels + m] = db;
+      vmax = fmaxf(vmax, db);
+    }
+    vmax = wave_max(vmax);
+    if (lane == 0) atomic_max_float(&utt_max[b], vmax);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ void db_floor_mask_kernel(float* __restrict__ out, const float* __restrict__ utt_max, const int32_t* __restrict__ spans,
+                                     int mask_times, int F, int n_mels, long n, float top_db) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int m = (int)(i % n_mels);
+    long bf = i / n_mels;
+    int f = (int)(bf % F), b = (int)(bf / F);
+    float v = fmaxf(out[i], utt_max[b] - top_db);
+    for (int r = 0; r < mask_times; ++r) {
+      const int32_t* sp = spans + ((size_t)b * mask_times + r) * 4;
+      if ((f >= sp[0] && f < sp[1]) || (m >= sp[2] && m < sp[3])) v = 0.f;
+    }
+    out[i] = v;
+  }
+}
+
+extern "C" int lidk_logmel(const float* wav, const float* window, const float* twiddle, const float* melfb, float* out,
+                           float* utt_max, int B, int L, int pad, int hop, int n_mels, const int32_t* spans, int mask_times,
+                           float top_db, void* stream) {
+  if (!wav || !window || !twiddle || !melfb || !out || !utt_max || B <= 0 || hop <= 0 || pad < 0 || n_mels <= 0) return LIDK_ERR_ARG;
+  if (L + 2 * pad <= LIDK_N_FFT / 2) return LIDK_ERR_ARG;         // reflect padding needs more than n_fft/2 samples
+  if (mask_times > 0 && !spans) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  const int F = 1 + (L + 2 * pad) / hop;
+  fill_kernel<<<cdiv(B, 256), 256, 0, s>>>(utt_max, B, -INFINITY);
+  long nframes = (long)B * F;
+  int blocks = (int)((nframes + 3) / 4); if (blocks > 2048) blocks = 2048;
+  stft_mel_kernel<<<blocks, 256, 0, s>>>(wav, window, twiddle, melfb, out, utt_max, B, L, pad, hop, F, n_mels);
+  long n = nframes * n_mels;
+  int eb = (int)((n + 255) / 256); if (eb > 8192) eb = 8192;
+  db_floor_mask_kernel<<<eb, 256, 0, s>>>(out, utt_max, spans, mask_times > 0 ? mask_times : 0, F, n_mels, n, top_db);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ im2col for Conv1d(k3, s2, p1)
+template <typename T>
+__global__ void im2col_k3s2_kernel(const float* __restrict__ mel, T* __restrict__ out, int B, int F, int C, int T_) {
+  const long n4 = (long)B * T_ * 3 * C / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    long e = i * 4;
+    int col = (int)(e % (3 * C));
+    long bt = e / (3 * C);
+    int t = (int)(bt % T_), b = (int)(bt / T_);
+    int k = col / C, ci = col - k * C;
+    int f = 2 * t + k - 1;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (f >= 0 && f < F) v = load4(mel + ((size_t)b * F + f) * C + ci);
+    store4(out + e, v);
+  }
+}
+
+extern "C" int lidk_im2col_k3s2(const float* mel, void* out, int B, int F, int C, int T_, int dtype, void* stream) {
+  if (!mel || !out || B <= 0 || F <= 0 || C <= 0 || (C & 3) || T_ != (F + 2 - 3) / 2 + 1) return LIDK_ERR_ARG;
+  long n4 = (long)B * T_ * 3 * C / 4;
+  int blocks = (int)((n4 + 255) / 256); if (blocks > 8192) blocks = 8192;
+  LIDK_DISPATCH(dtype, im2col_k3s2_kernel<T><<<blocks, 256, 0, as_stream(stream)>>>(mel, (T*)out, B, F, C, T_));
+  return launch_status();
+}

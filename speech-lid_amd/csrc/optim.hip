@@ -1,0 +1,141 @@
+// Fused gradient-norm clip + Novograd over flat f32 arenas, and the f32 -> T weight refresh.
+//   ccml/trainer.py:541-543      torch.nn.utils.clip_grad_norm_(params, max_norm=20)
+//   ccml/optim/novograd.py:75-145 per-tensor second moment of ||g||^2 (amsgrad=False, luc=False)
+// Parameters, gradients and first moments are three parallel flat arenas, so the whole optimizer is three launches:
+// (1) per-chunk sum of squares, (2) one-workgroup per-tensor bookkeeping (norms, clip coefficient, second moments),
+// (3) the element-wise update.  Only tensors listed in `work` are touched, which is how "p.grad is None" (other
+// language heads, layers skipped by stochastic depth) is expressed.
+#include "common.h"
+
+__global__ void __launch_bounds__(256)
+sumsq_chunks_kernel(const float* __restrict__ grads, const int64_t* __restrict__ work, float* __restrict__ chunk_sumsq) {
+  __shared__ float red[4];
+  const int64_t off = work[(size_t)blockIdx.x * 3 + 1], len = work[(size_t)blockIdx.x * 3 + 2];
+  const float* g = grads + off;
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < len; i += 256) { float v = g[i]; s = fmaf(v, v, s); }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_sumsq[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// scratch layout: [0, n_work) chunk sums | [n_work, n_work+n_tensors) per-tensor scale | [n_work+n_tensors] total sumsq
+__global__ void __launch_bounds__(256)
+novograd_prepare_kernel(const int64_t* __restrict__ work, int n_work, int n_tensors, float* __restrict__ scratch,
+                        float* __restrict__ exp_avg_sq, float beta2, float eps, float max_norm,
+                        float* __restrict__ total_norm_out) {
+  __shared__ float s_total;
+  __shared__ float red[4];
+  float* chunk = scratch;
+  float* scale = scratch + n_work;
+  // pass 1: per-tensor sums (deterministic: one thread walks a tensor's contiguous chunk run)
+  for (int t = threadIdx.x; t < n_tensors; t += 256) scale[t] = -1.f;    // -1 marks "not in this step"
+  __syncthreads();
+  float mine = 0.f;
+  for (int w = threadIdx.x; w < n_work; w += 256) {
+    int64_t tid_ = work[(size_t)w * 3];
+    if (w == 0 || work[(size_t)(w - 1) * 3] != tid_) {                 // first chunk of a tensor
+      float acc = 0.f;
+      for (int u = w; u < n_work && work[(size_t)u * 3] == tid_; ++u) acc += chunk[u];
+      scale[tid_] = acc;                                                // holds ||g_t||^2 for now
+      mine += acc;
+    }
+  }
+  mine = wave_sum(mine);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = red[0] + red[1] + red[2] + red[3];
+    s_total = tot;
+    if (total_norm_out) *total_norm_out = sqrtf(tot);
+  }
+  __syncthreads();
+  const float total = sqrtf(s_total);
+  const float clip = (max_norm > 0.f) ? fminf(1.f, max_norm / (total + 1e-6f)) : 1.f;
+  for (int t = threadIdx.x; t < n_tensors; t += 256) {
+    float n = scale[t];
+    if (n < 0.f) continue;
+    n *= clip * clip;                                                   // norm of the clipped gradient
+    float v = exp_avg_sq[t];
+    v = (v == 0.f) ? n : beta2 * v + (1.f - beta2) * n;                 // novograd.py:115-118
+    exp_avg_sq[t] = v;
+    scale[t] = clip / (sqrtf(v) + eps);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+novograd_apply_kernel(float* __restrict__ params, float* __restrict__ grads, float* __restrict__ exp_avg,
+                      const int64_t* __restrict__ work, const float* __restrict__ scale, float lr, float beta1,
+                      float weight_decay, float ga) {
+  const int64_t t = work[(size_t)blockIdx.x * 3], off = work[(size_t)blockIdx.x * 3 + 1], len = work[(size_t)blockIdx.x * 3 + 2];
+  const float sc = scale[t];
+  for (int64_t i = threadIdx.x; i < len; i += 256) {
+    float p = params[off + i];
+    float g = grads[off + i] * sc + weight_decay * p;
+    g *= ga;
+    float m = beta1 * exp_avg[off + i] + g;
+    exp_avg[off + i] = m;
+    params[off + i] = p - lr * m;
+  }
+}
+
+extern "C" int lidk_novograd_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* work,
+                                  int n_work, int n_tensors, float lr, float beta1, float beta2, float eps,
+                                  float weight_decay, int grad_averaging, float max_norm, float* scratch,
+                                  float* total_norm_out, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !work || !scratch || n_work <= 0 || n_tensors <= 0) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  sumsq_chunks_kernel<<<n_work, 256, 0, s>>>(grads, work, scratch);
+  novograd_prepare_kernel<<<1, 256, 0, s>>>(work, n_work, n_tensors, scratch, exp_avg_sq, beta2, eps, max_norm, total_norm_out);
+  novograd_apply_kernel<<<n_work, 256, 0, s>>>(params, grads, exp_avg, work, scratch + n_work, lr, beta1, weight_decay,
+                                               grad_averaging ? (1.f - beta1) : 1.f);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ weight refresh (f32 master -> T operands)
+template <typename T>
+__global__ void cast_matrix_kernel(const float* __restrict__ src, T* __restrict__ w, T* __restrict__ wt, int R, int C) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: 8 rows per pass
+  for (int i = ty; i < 32; i += 8) {
+    int r = r0 + i, c = c0 + tx;
+    if (r < R && c < C) {
+      float v = src[(size_t)r * C + c];
+      tile[i][tx] = v;
+      if (w) w[(size_t)r * C + c] = from_f<T>(v);
+    }
+  }
+  if (!wt) return;
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, r = r0 + tx;
+    if (r < R && c < C) wt[(size_t)c * R + r] = from_f<T>(tile[tx][i]);
+  }
+}
+
+extern "C" int lidk_cast_weights(const float* params, void* wT, const int64_t* mats, int n_mats, int dtype, void* stream) {
+  if (!params || !wT || !mats || n_mats < 0) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  for (int i = 0; i < n_mats; ++i) {
+    const int64_t* m = mats + (size_t)i * 6;
+    const int R = (int)m[1], C = (int)m[2];
+    if (R <= 0 || C <= 0) return LIDK_ERR_ARG;
+    dim3 grid(cdiv(C, 32), cdiv(R, 32));
+    if (dtype == LIDK_BF16) {
+      bf16* base = (bf16*)wT;
+      cast_matrix_kernel<bf16><<<grid, 256, 0, s>>>(params + m[0], m[3] >= 0 ? base + m[3] : nullptr,
+                                                    m[4] >= 0 ? base + m[4] : nullptr, R, C);
+    } else if (dtype == LIDK_F32) {
+      float* base = (float*)wT;
+      cast_matrix_kernel<float><<<grid, 256, 0, s>>>(params + m[0], m[3] >= 0 ? base + m[3] : nullptr,
+                                                     m[4] >= 0 ? base + m[4] : nullptr, R, C);
+    } else {
+      return LIDK_ERR_ARG;
+    }
+  }
+  return launch_status();
+}
+
+extern "C" int lidk_version(void) { return 1; }

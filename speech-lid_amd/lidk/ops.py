@@ -1,0 +1,290 @@
+"""Tensor-level wrappers over the C-ABI (one Python function per include/lidk.h entry point).
+
+torch is used only for device memory and the current HIP stream.  Every wrapper refuses CPU tensors: there is no
+fallback path.  Outputs are passed in (the engine preallocates them); a few allocate when ``out`` is None for tests.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import LidkError, check, dtype_code, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise LidkError(f"lidk op got a tensor on {t.device}: the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise LidkError("lidk op needs contiguous tensors")
+    return t.data_ptr()
+
+
+def _pv(t):
+    """Like _p but accepts row-strided 2-D views (unit inner stride)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise LidkError(f"lidk op got a tensor on {t.device}: the HIP path has no CPU fallback")
+    if t.stride(-1) != 1:
+        raise LidkError("lidk op needs unit inner stride")
+    return t.data_ptr()
+
+
+def _code(t):
+    return dtype_code(t.dtype)
+
+
+# ----------------------------------------------------------------------------------------------- features
+_TABLES = {}
+
+
+def fft_tables(device, win_length=400, n_mels=80):
+    """window [512] (hann(win) periodic, centred), twiddle [256][2], melfb [257][n_mels] — host-computed once."""
+    key = (str(device), win_length, n_mels)
+    if key not in _TABLES:
+        win = torch.zeros(512)
+        left = (512 - win_length) // 2
+        win[left:left + win_length] = torch.hann_window(win_length)
+        k = torch.arange(256, dtype=torch.float64) * (2.0 * math.pi / 512.0)
+        tw = torch.stack([torch.cos(k), torch.sin(k)], dim=1).float()
+        _TABLES[key] = (win.to(device), tw.contiguous().to(device), melscale_fbanks(n_mels).contiguous().to(device))
+    return _TABLES[key]
+
+
+def melscale_fbanks(n_mels=80, n_freqs=257, f_min=0.0, f_max=8000.0, sample_rate=16000):
+    """HTK mel filterbank, norm=None — what torchaudio.transforms.MelSpectrogram builds by default for the call at
+    lid/audio_processor.py:91-101 (sample_rate is torchaudio's default 16000 whatever `sr` is: SURVEY Q1)."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.min(down, up), min=0.0)
+
+
+def normalize_wav(wav, out=None):
+    out = torch.empty_like(wav) if out is None else out
+    B, Lw = wav.shape
+    check(lib().lidk_normalize_wav(_p(wav), _p(out), B, Lw, _stream()), "normalize_wav")
+    return out
+
+
+def dither_preemph(wav, coef=0.97, dither=1e-5, seed=0, noise=None, out=None):
+    out = torch.empty_like(wav) if out is None else out
+    B, Lw = wav.shape
+    check(lib().lidk_dither_preemph(_p(wav), _p(out), _p(noise), B, Lw, coef, dither, seed, _stream()), "dither_preemph")
+    return out
+
+
+def logmel(wav, pad=0, hop=160, win_length=400, n_mels=80, spans=None, top_db=80.0, out=None):
+    """wav (B, L) f32 -> (B, F, n_mels) f32 dB with per-utterance top_db floor and optional SpecAugment spans
+    (int32 (B, mask_times, 4))."""
+    B, Lw = wav.shape
+    F_ = 1 + (Lw + 2 * pad) // hop
+    win, tw, fb = fft_tables(wav.device, win_length, n_mels)
+    out = torch.empty(B, F_, n_mels, device=wav.device, dtype=torch.float32) if out is None else out
+    umax = torch.empty(B, device=wav.device, dtype=torch.float32)
+    mt = 0 if spans is None else spans.shape[1]
+    check(lib().lidk_logmel(_p(wav), _p(win), _p(tw), _p(fb), _p(out), _p(umax), B, Lw, pad, hop, n_mels, _p(spans), mt,
+                            top_db, _stream()), "logmel")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- element-wise
+def scale_cast(x, out, scale=1.0):
+    check(lib().lidk_scale_cast(_p(x), _code(x), _p(out), _code(out), x.numel(), scale, _stream()), "scale_cast")
+    return out
+
+
+def dropout(x, out, p, seed=0, keep_in=None, keep_out=None):
+    check(lib().lidk_dropout(_p(x), _code(x), _p(out), _code(out), _p(keep_in), _p(keep_out), x.numel(), p, seed,
+                             _stream()), "dropout")
+    return out
+
+
+def relu_bwd(dy, y, dx):
+    check(lib().lidk_relu_bwd(_p(dy), _p(y), _p(dx), dy.numel(), _code(dy), _stream()), "relu_bwd")
+    return dx
+
+
+def colsum(x, out, partial, scale=1.0):
+    """out (N,) f32 += scale * x.sum(0); x (M, N)."""
+    M, N = x.shape
+    check(lib().lidk_colsum(_pv(x), x.stride(0), _code(x), _p(out), _p(partial), M, N, scale, _stream()), "colsum")
+    return out
+
+
+def transpose(x, out):
+    R, Cc = x.shape
+    check(lib().lidk_transpose(_pv(x), x.stride(0), _pv(out), out.stride(0), R, Cc, _code(x), _stream()), "transpose")
+    return out
+
+
+def reduce_partials_f64(partial, nparts, ncols, out):
+    check(lib().lidk_reduce_partials_f64(_p(partial), nparts, ncols, _p(out), _stream()), "reduce_partials_f64")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x, gamma, beta, yT=None, y32=None, mean=None, rstd=None, eps=1e-5, dtype=None):
+    M, Cc = x.shape
+    code = _code(yT) if yT is not None else (dtype_code(dtype) if dtype is not None else L.F32)
+    check(lib().lidk_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(yT), _p(y32), _p(mean), _p(rstd), M, Cc, eps, code,
+                                   _stream()), "layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, partial, dres=None, dx=None, dxT=None, dxT_scale=1.0, dgamma=None,
+                  dbeta=None, dtype=None):
+    M, Cc = x.shape
+    code = _code(dxT) if dxT is not None else (dtype_code(dtype) if dtype is not None else _code(dy))
+    check(lib().lidk_layernorm_bwd(_p(dy), _code(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dxT),
+                                   dxT_scale, _p(dgamma), _p(dbeta), _p(partial), M, Cc, code, _stream()), "layernorm_bwd")
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+def gemm_nt(A, B, out, bias=None, act=L.ACT_NONE, alpha=1.0, res=None, out2=None, aux=None, splitk=1, M=None, N=None,
+            K=None):
+    """out[M,N] = epilogue(A[M,K] @ B[N,K]^T).  A, B share the activation dtype; out is that dtype or f32."""
+    M = A.shape[0] if M is None else M
+    K = A.shape[1] if K is None else K
+    N = B.shape[0] if N is None else N
+    g = L.GemmArgs()
+    g.A, g.B = _pv(A), _pv(B)
+    g.M, g.N, g.K, g.lda, g.ldb = M, N, K, A.stride(0), B.stride(0)
+    g.bias, g.act, g.alpha = _p(bias), act, alpha
+    g.res, g.ldres = _pv(res), (res.stride(0) if res is not None else 0)
+    g.out, g.ldo, g.out_f32 = _pv(out), out.stride(0), int(out.dtype == torch.float32)
+    g.out2, g.ldo2 = _pv(out2), (out2.stride(0) if out2 is not None else 0)
+    g.aux, g.ldaux = _pv(aux), (aux.stride(0) if aux is not None else 0)
+    g.splitk = splitk
+    if A.dtype != B.dtype:
+        raise LidkError("gemm_nt: A and B must share a dtype")
+    check(lib().lidk_gemm_nt(C.byref(g), _code(A), _stream()), "gemm_nt")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def attn_fwd(qkv, rel_emb, out, probs, B, T, heads, dh):
+    max_pos = (rel_emb.shape[0] - 1) // 2
+    check(lib().lidk_attn_fwd(_p(qkv), _p(rel_emb), _p(out), _p(probs), B, T, heads, dh, max_pos, _code(qkv), _stream()),
+          "attn_fwd")
+
+
+def attn_bwd(qkv, rel_emb, probs, dout, dqkv, drel_emb, dscores, B, T, heads, dh):
+    max_pos = (rel_emb.shape[0] - 1) // 2
+    check(lib().lidk_attn_bwd(_p(qkv), _p(rel_emb), _p(probs), _p(dout), _p(dqkv), _p(drel_emb), _p(dscores), B, T, heads,
+                              dh, max_pos, _code(qkv), _stream()), "attn_bwd")
+
+
+# ----------------------------------------------------------------------------------------------- conv module
+def glu_fwd(y, g):
+    M, C2 = y.shape
+    check(lib().lidk_glu_fwd(_p(y), _p(g), M, C2 // 2, _code(y), _stream()), "glu_fwd")
+
+
+def glu_bwd(y, dg, dy):
+    M, C2 = y.shape
+    check(lib().lidk_glu_bwd(_p(y), _p(dg), _p(dy), M, C2 // 2, _code(y), _stream()), "glu_bwd")
+
+
+def dwconv_stat_parts(B, T):
+    return lib().lidk_dwconv_stat_parts(B, T)
+
+
+def dwconv_fwd(g, w, bias, c, stat_partial, B, T, pad_left):
+    Cc, K = w.shape
+    check(lib().lidk_dwconv_fwd(_p(g), _p(w), _p(bias), _p(c), _p(stat_partial), B, T, Cc, K, pad_left, _code(g),
+                                _stream()), "dwconv_fwd")
+
+
+def dwconv_bwd_input(dc, w, dg, B, T, pad_left):
+    Cc, K = w.shape
+    check(lib().lidk_dwconv_bwd_input(_p(dc), _p(w), _p(dg), B, T, Cc, K, pad_left, _code(dc), _stream()), "dwconv_bwd_input")
+
+
+def dwconv_bwd_weight(dc, g, dw, db, partial, B, T, pad_left):
+    Cc, K = dw.shape
+    check(lib().lidk_dwconv_bwd_weight(_p(dc), _p(g), _p(dw), _p(db), _p(partial), B, T, Cc, K, pad_left, _code(dc),
+                                       _stream()), "dwconv_bwd_weight")
+
+
+def bn_train_stats(sums, count, mean, rstd, running_mean, running_var, nbt, momentum=0.1, eps=1e-5):
+    Cc = mean.shape[0]
+    check(lib().lidk_bn_train_stats(_p(sums), float(count), _p(mean), _p(rstd), _p(running_mean), _p(running_var), _p(nbt),
+                                    momentum, eps, Cc, _stream()), "bn_train_stats")
+
+
+def bn_eval_stats(running_mean, running_var, mean, rstd, eps=1e-5):
+    check(lib().lidk_bn_eval_stats(_p(running_mean), _p(running_var), _p(mean), _p(rstd), eps, mean.shape[0], _stream()),
+          "bn_eval_stats")
+
+
+def bn_swish_fwd(c, mean, rstd, gamma, beta, s):
+    M, Cc = c.shape
+    check(lib().lidk_bn_swish_fwd(_p(c), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(s), M, Cc, _code(c), _stream()),
+          "bn_swish_fwd")
+
+
+def bn_swish_bwd_reduce(ds, c, mean, rstd, gamma, beta, partial):
+    M, Cc = c.shape
+    check(lib().lidk_bn_swish_bwd_reduce(_p(ds), _p(c), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(partial), M, Cc,
+                                         _code(c), _stream()), "bn_swish_bwd_reduce")
+
+
+def bn_swish_bwd_apply(ds, c, mean, rstd, gamma, beta, sums, sums_local, count, dc, dgamma, dbeta):
+    M, Cc = c.shape
+    check(lib().lidk_bn_swish_bwd_apply(_p(ds), _p(c), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), _p(sums_local),
+                                        float(count), _p(dc), _p(dgamma), _p(dbeta), M, Cc, _code(c), _stream()),
+          "bn_swish_bwd_apply")
+
+
+def im2col_k3s2(mel, out, T):
+    B, F_, Cc = mel.shape
+    check(lib().lidk_im2col_k3s2(_p(mel), _p(out), B, F_, Cc, T, _code(out), _stream()), "im2col_k3s2")
+
+
+# ----------------------------------------------------------------------------------------------- loss
+def ctc_workspace_bytes(B, T, V1, Lmax):
+    return lib().lidk_ctc_workspace_bytes(B, T, V1, Lmax)
+
+
+def ctc_loss(logits, targets, in_len, tg_len, loss, dlogits, workspace, blank, grad_scale=1.0, zero_infinity=True):
+    B, T, V1 = logits.shape
+    Lmax = targets.shape[1]
+    check(lib().lidk_ctc_loss(_p(logits), _p(targets), _p(in_len), _p(tg_len), _p(loss), _p(dlogits), _p(workspace), B, T,
+                              V1, Lmax, blank, grad_scale, int(zero_infinity), _stream()), "ctc_loss")
+
+
+def lid_score(logits, scores_col, stride, blank):
+    """scores_col: 1-element-offset view into a (B, n_lang) f32 matrix column; stride = n_lang."""
+    B, T, V1 = logits.shape
+    if not scores_col.is_cuda:
+        raise LidkError("lid_score: CPU tensor")
+    check(lib().lidk_lid_score(_p(logits), scores_col.data_ptr(), stride, B, T, V1, blank, _stream()), "lid_score")
+
+
+# ----------------------------------------------------------------------------------------------- optimizer
+def novograd_step(params, grads, exp_avg, exp_avg_sq, work, n_tensors, lr, betas, eps, weight_decay, grad_averaging,
+                  max_norm, scratch, total_norm):
+    check(lib().lidk_novograd_step(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), _p(work), work.shape[0], n_tensors,
+                                   lr, betas[0], betas[1], eps, weight_decay, int(grad_averaging), max_norm, _p(scratch),
+                                   _p(total_norm), _stream()), "novograd_step")
+
+
+def cast_weights(params, wT, mats_host):
+    """mats_host: CPU int64 tensor (n, 6) — the only host pointer in the ABI."""
+    if mats_host.is_cuda or mats_host.dtype != torch.int64 or not mats_host.is_contiguous():
+        raise LidkError("cast_weights: mats must be a contiguous CPU int64 tensor")
+    check(lib().lidk_cast_weights(_p(params), _p(wT), mats_host.data_ptr(), mats_host.shape[0], _code(wT), _stream()),
+          "cast_weights")

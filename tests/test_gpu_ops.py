@@ -1,0 +1,456 @@
+"""Per-kernel parity tests (GPU): every C-ABI op against a torch-CPU / oracle computation of the same math.
+
+f32 mode must agree to ~1e-5 (it is the algorithm check); bf16 mode is compared against the same reference
+evaluated on bf16-rounded inputs, with tolerances sized by bf16's 2^-8 relative rounding.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import lidk
+from lidk import ops
+from lidk import _lib as L
+from oracle import conformer as oc
+from oracle import features as of
+from oracle import optim as oo
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DT = [torch.float32, torch.bfloat16]
+
+
+def g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+def dev(t, dtype=None):
+    t = t.to(DEV)
+    return t.to(dtype).contiguous() if dtype is not None else t.contiguous()
+
+
+def rt(t, dtype):
+    """round-trip through the activation dtype on CPU (reference sees exactly what the kernel sees)"""
+    return t.to(dtype).float()
+
+
+def tol(dtype, f32, bf16):
+    return f32 if dtype == torch.float32 else bf16
+
+
+def check(name, got, ref, atol, rtol=0.0):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    err = (got - ref).abs()
+    lim = atol + rtol * ref.abs()
+    worst = float((err - lim).max())
+    print(f"[{name}] max_abs_err={float(err.max()):.3e} ref_max={float(ref.abs().max()):.3e}")
+    assert worst <= 0, f"{name}: max abs err {float(err.max()):.3e} exceeds atol={atol} rtol={rtol}"
+
+
+# ------------------------------------------------------------------------------------------------ element-wise
+@pytest.mark.parametrize("dt", DT)
+def test_scale_cast_dropout_relu(dt):
+    x = torch.randn(1003, generator=g(1))
+    out = torch.empty(1003, device=DEV, dtype=dt)
+    ops.scale_cast(dev(x), out, 0.5)
+    check("scale_cast", out, rt(0.5 * x, dt), 1e-6 if dt == torch.float32 else 0, 0)
+    xd = dev(x, dt)
+    y = torch.empty_like(xd)
+    keep = torch.empty(1003, device=DEV, dtype=torch.uint8)
+    ops.dropout(xd, y, 0.25, seed=123, keep_out=keep)
+    k = keep.cpu().bool()
+    assert 0.65 < k.float().mean() < 0.85
+    check("dropout", y, rt(rt(x, dt) * k / 0.75, dt), 1e-6, 1e-2 if dt == torch.bfloat16 else 1e-6)
+    y2 = torch.empty_like(xd)
+    ops.dropout(xd, y2, 0.25, keep_in=keep)
+    assert torch.equal(y, y2)
+    y3 = torch.empty_like(xd)
+    ops.dropout(xd, y3, 0.25, seed=123)
+    assert torch.equal(y, y3)                      # stateless generator: same (seed, index) -> same mask
+    dy = torch.randn(1003, generator=g(2))
+    dx = torch.empty_like(xd)
+    ops.relu_bwd(dev(dy, dt), xd, dx)
+    check("relu_bwd", dx, rt(dy, dt) * (rt(x, dt) > 0), 0)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_colsum_transpose(dt):
+    x = torch.randn(777, 130, generator=g(3))
+    out = torch.full((130,), 2.0, device=DEV)
+    partial = torch.empty(L.LN_PARTIAL_BLOCKS * 130, device=DEV)
+    ops.colsum(dev(x, dt), out, partial, 0.5)
+    check("colsum", out, 2.0 + 0.5 * rt(x, dt).double().sum(0).float(), 2e-4)
+    xt = torch.empty(130, 777, device=DEV, dtype=dt)
+    ops.transpose(dev(x, dt), xt)
+    assert torch.equal(xt.cpu(), x.to(dt).t().contiguous())
+    p = torch.randn(37, 10, generator=g(4))
+    o64 = torch.empty(10, device=DEV, dtype=torch.float64)
+    ops.reduce_partials_f64(dev(p), 37, 10, o64)
+    check("reduce_partials_f64", o64, p.double().sum(0), 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,C", [(204, 64), (1000, 256), (37, 144)])
+def test_layernorm_fwd_bwd(dt, M, C):
+    x = (2.0 * torch.randn(M, C, generator=g(5)) + 0.5).requires_grad_()
+    gamma = (1 + 0.2 * torch.randn(C, generator=g(6))).requires_grad_()
+    beta = (0.1 * torch.randn(C, generator=g(7))).requires_grad_()
+    y = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    dy = torch.randn(M, C, generator=g(8))
+    dres = torch.randn(M, C, generator=g(9))
+    y.backward(rt(dy, dt))
+    xd, gd, bd = dev(x.detach()), dev(gamma.detach()), dev(beta.detach())
+    yT = torch.empty(M, C, device=DEV, dtype=dt)
+    y32 = torch.empty(M, C, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.layernorm_fwd(xd, gd, bd, yT=yT, y32=y32, mean=mean, rstd=rstd)
+    check("ln_fwd_f32", y32, y, 2e-5)
+    check("ln_fwd_T", yT, y, tol(dt, 2e-5, 0), tol(dt, 0, 8e-3))
+    check("ln_mean", mean, x.detach().mean(1), 1e-5)
+    dx = torch.empty(M, C, device=DEV)
+    dxT = torch.empty(M, C, device=DEV, dtype=dt)
+    dgam = torch.full((C,), 1.0, device=DEV)
+    dbet = torch.full((C,), -1.0, device=DEV)
+    partial = torch.empty(L.LN_PARTIAL_BLOCKS * 2 * C, device=DEV)
+    ops.layernorm_bwd(dev(dy, dt), xd, mean, rstd, gd, partial, dres=dev(dres), dx=dx, dxT=dxT, dxT_scale=0.5,
+                      dgamma=dgam, dbeta=dbet)
+    check("ln_bwd_dx", dx, x.grad + dres, 5e-5, 1e-5)
+    check("ln_bwd_dxT", dxT, 0.5 * (x.grad + dres), tol(dt, 5e-5, 1e-3), tol(dt, 1e-5, 8e-3))
+    check("ln_bwd_dgamma", dgam, 1.0 + gamma.grad, 2e-3, 1e-4)
+    check("ln_bwd_dbeta", dbet, -1.0 + beta.grad, 2e-3, 1e-4)
+    # f32 dy path (encoder output gradient enters the last post_norm as f32)
+    dx2 = torch.empty(M, C, device=DEV)
+    ops.layernorm_bwd(dev(rt(dy, dt)), xd, mean, rstd, gd, partial, dx=dx2, dtype=dt)
+    check("ln_bwd_dx_f32dy", dx2, x.grad, 5e-5, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _gemm_ref(A, B, dt):
+    return rt(A, dt).double() @ rt(B, dt).double().t()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(300, 41, 256), (130, 70, 240), (64, 64, 64), (1000, 256, 1024), (4100, 1536, 256),
+                                   (204, 768, 64), (33, 80, 80)])
+def test_gemm_plain_and_tails(dt, M, N, K):
+    A = torch.randn(M, K, generator=g(10)) * (1 + torch.arange(K) / K)            # asymmetric data
+    B = torch.randn(N, K, generator=g(11)) + 0.1 * torch.arange(N)[:, None] / N
+    ref = _gemm_ref(A, B, dt).float()
+    out = torch.full((M, N), 7.0, device=DEV, dtype=dt)
+    ops.gemm_nt(dev(A, dt), dev(B, dt), out)
+    scale = float(ref.abs().max())
+    check(f"gemm_{M}x{N}x{K}", out, ref, tol(dt, 2e-4 * scale, 6e-3 * scale))
+    o32 = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(dev(A, dt), dev(B, dt), o32)
+    check(f"gemm_f32out_{M}x{N}x{K}", o32, ref, 2e-4 * scale)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_epilogues(dt):
+    M, N, K = 333, 200, 128
+    A = torch.randn(M, K, generator=g(12)) * 0.3
+    B = torch.randn(N, K, generator=g(13)) * 0.3
+    bias = torch.randn(N, generator=g(14))
+    res = torch.randn(M, N, generator=g(15))
+    aux = torch.randn(M, N, generator=g(16))
+    acc = _gemm_ref(A, B, dt).float()
+    Ad, Bd = dev(A, dt), dev(B, dt)
+    # bias + swish, pre-activation saved
+    out = torch.empty(M, N, device=DEV, dtype=dt)
+    pre = torch.empty(M, N, device=DEV, dtype=dt)
+    ops.gemm_nt(Ad, Bd, out, bias=dev(bias), act=L.ACT_SWISH, out2=pre)
+    a = acc + bias
+    check("gemm_swish_pre", pre, a, tol(dt, 2e-4, 4e-2))
+    check("gemm_swish", out, a * torch.sigmoid(a), tol(dt, 2e-4, 4e-2))
+    # relu
+    ops.gemm_nt(Ad, Bd, out, bias=dev(bias), act=L.ACT_RELU)
+    check("gemm_relu", out, torch.relu(a), tol(dt, 2e-4, 4e-2))
+    # alpha + f32 residual, f32 out
+    o32 = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(Ad, Bd, o32, bias=dev(bias), alpha=0.5, res=dev(res))
+    check("gemm_alpha_res", o32, res + 0.5 * a, 2e-4 if dt == torch.float32 else 2e-4)
+    # swish-grad multiplier
+    s = torch.sigmoid(rt(aux, dt))
+    ops.gemm_nt(Ad, Bd, out, act=L.ACT_SWISH_GRAD, aux=dev(aux, dt))
+    check("gemm_swish_grad", out, acc * s * (1 + rt(aux, dt) * (1 - s)), tol(dt, 2e-4, 4e-2))
+    # split-K atomic accumulation onto an existing f32 gradient
+    M2, N2, K2 = 256, 96, 4104
+    A2 = torch.randn(M2, K2, generator=g(17)) * 0.1
+    B2 = torch.randn(N2, K2, generator=g(18)) * 0.1
+    base = torch.randn(M2, N2, generator=g(19))
+    o = dev(base.clone())
+    ops.gemm_nt(dev(A2, dt), dev(B2, dt), o, splitk=8)
+    check("gemm_splitk", o, base + _gemm_ref(A2, B2, dt).float(), 5e-4)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, emb, B, T, H, dh):
+    inner = H * dh
+    q, k, v = qkv.split(inner, dim=-1)
+    q, k, v = (t.reshape(B, T, H, dh).transpose(1, 2) for t in (q, k, v))
+    scale = dh ** -0.5
+    dots = q @ k.transpose(-1, -2) * scale + oc.rel_pos_scores(q, emb, scale)
+    p = dots.softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(B * T, inner), p
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,T,H,dh,maxpos", [(2, 51, 4, 16, 512), (2, 151, 4, 64, 512), (1, 70, 8, 32, 512),
+                                             (2, 51, 8, 8, 512), (2, 60, 2, 16, 20)])
+def test_attention_fwd_bwd(dt, B, T, H, dh, maxpos):
+    inner = H * dh
+    qkv = (0.7 * torch.randn(B * T, 3 * inner, generator=g(20)))
+    emb = (0.5 * torch.randn(2 * maxpos + 1, dh, generator=g(21)))
+    qkv_r = rt(qkv, dt).requires_grad_()
+    emb_r = (rt(emb, dt) if dt == torch.bfloat16 else emb.clone()).requires_grad_()   # kernel rounds E to T in LDS
+    out_ref, p_ref = _attn_ref(qkv_r, emb_r, B, T, H, dh)
+    dout = torch.randn(B * T, inner, generator=g(22))
+    out_ref.backward(rt(dout, dt))
+    qd, ed = dev(qkv, dt), dev(emb)
+    out = torch.empty(B * T, inner, device=DEV, dtype=dt)
+    probs = torch.empty(B, H, T, T, device=DEV, dtype=dt)
+    ops.attn_fwd(qd, ed, out, probs, B, T, H, dh)
+    check("attn_probs", probs, p_ref, tol(dt, 2e-6, 4e-3))
+    check("attn_out", out, out_ref, tol(dt, 1e-5, 1.5e-2))
+    dqkv = torch.zeros(B * T, 3 * inner, device=DEV, dtype=dt)
+    demb = torch.zeros_like(ed)
+    dsc = torch.empty(B, H, T, T, device=DEV)
+    ops.attn_bwd(qd, ed, probs, dev(dout, dt), dqkv, demb, dsc, B, T, H, dh)
+    gs = float(qkv_r.grad.abs().max())
+    check("attn_dqkv", dqkv, qkv_r.grad, tol(dt, 2e-5 * max(1, gs), 3e-2 * max(1, gs)))
+    check("attn_demb", demb, emb_r.grad, tol(dt, 1e-4, 6e-2) * max(1.0, float(emb_r.grad.abs().max())))
+
+
+# ------------------------------------------------------------------------------------------------ conv module
+@pytest.mark.parametrize("dt", DT)
+def test_glu(dt):
+    M, C = 203, 128
+    y = torch.randn(M, 2 * C, generator=g(30))
+    yr = rt(y, dt).requires_grad_()
+    gl = yr[:, :C] * torch.sigmoid(yr[:, C:])
+    dg = torch.randn(M, C, generator=g(31))
+    gl.backward(rt(dg, dt))
+    yd = dev(y, dt)
+    go = torch.empty(M, C, device=DEV, dtype=dt)
+    ops.glu_fwd(yd, go)
+    check("glu_fwd", go, gl, tol(dt, 1e-6, 2e-2))
+    dy = torch.empty(M, 2 * C, device=DEV, dtype=dt)
+    ops.glu_bwd(yd, dev(dg, dt), dy)
+    check("glu_bwd", dy, yr.grad, tol(dt, 1e-6, 3e-2))
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,T,C,K", [(3, 51, 128, 31), (2, 151, 512, 31), (2, 40, 96, 7), (1, 33, 64, 4)])
+def test_dwconv_fwd_bwd_and_stats(dt, B, T, C, K):
+    pad = (K // 2, K // 2 - (K + 1) % 2)
+    x = torch.randn(B, T, C, generator=g(32))
+    w = (0.3 * torch.randn(C, K, generator=g(33))).requires_grad_()
+    b = (0.1 * torch.randn(C, generator=g(34))).requires_grad_()
+    xr = rt(x, dt).requires_grad_()
+    y = F.conv1d(F.pad(xr.transpose(1, 2), pad), w[:, None, :], b, groups=C).transpose(1, 2)   # (B,T,C)
+    dy = torch.randn(B, T, C, generator=g(35))
+    y.backward(rt(dy, dt))
+    xd, wd, bd = dev(x, dt), dev(w.detach()), dev(b.detach())
+    c = torch.empty(B, T, C, device=DEV, dtype=dt)
+    nparts = ops.dwconv_stat_parts(B, T)
+    stat = torch.empty(nparts, 2, C, device=DEV)
+    ops.dwconv_fwd(xd, wd, bd, c, stat, B, T, pad[0])
+    check("dwconv_fwd", c, y, tol(dt, 2e-5, 3e-2))
+    sums = torch.empty(2 * C, device=DEV, dtype=torch.float64)
+    ops.reduce_partials_f64(stat, nparts, 2 * C, sums)
+    yf = y.detach().reshape(-1, C).double()
+    check("dwconv_stat_sum", sums[:C], yf.sum(0), 2e-3)
+    check("dwconv_stat_sumsq", sums[C:], (yf * yf).sum(0), 2e-3, 1e-5)
+    dg = torch.empty(B, T, C, device=DEV, dtype=dt)
+    ops.dwconv_bwd_input(dev(dy, dt), wd, dg, B, T, pad[0])
+    check("dwconv_dgrad", dg, xr.grad, tol(dt, 2e-5, 3e-2))
+    dw = torch.zeros(C, K, device=DEV)
+    db = torch.zeros(C, device=DEV)
+    partial = torch.empty(B * C * (K + 1), device=DEV)
+    ops.dwconv_bwd_weight(dev(dy, dt), xd, dw, db, partial, B, T, pad[0])
+    check("dwconv_wgrad", dw, w.grad, 2e-4, 1e-4)
+    check("dwconv_bgrad", db, b.grad, 2e-4, 1e-4)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_batchnorm_swish_train_and_eval(dt):
+    M, C = 408, 128
+    c = 1.5 * torch.randn(M, C, generator=g(36)) + 0.3
+    gamma = (1 + 0.2 * torch.randn(C, generator=g(37))).requires_grad_()
+    beta = (0.1 * torch.randn(C, generator=g(38))).requires_grad_()
+    rm, rv = 0.1 * torch.randn(C, generator=g(39)), 0.5 + torch.rand(C, generator=g(40))
+    cr = rt(c, dt).requires_grad_()
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = F.batch_norm(cr, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    s = z * torch.sigmoid(z)
+    ds = torch.randn(M, C, generator=g(41))
+    s.backward(rt(ds, dt))
+    cd = dev(c, dt)
+    sums = torch.stack([cr.detach().double().sum(0), (cr.detach().double() ** 2).sum(0)]).reshape(-1).to(DEV)
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    rmd, rvd = dev(rm), dev(rv)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    ops.bn_train_stats(sums, M, mean, rstd, rmd, rvd, nbt)
+    check("bn_running_mean", rmd, rm_ref, 1e-6)
+    check("bn_running_var", rvd, rv_ref, 1e-5)
+    assert int(nbt) == 1
+    so = torch.empty(M, C, device=DEV, dtype=dt)
+    gd, bd = dev(gamma.detach()), dev(beta.detach())
+    ops.bn_swish_fwd(cd, mean, rstd, gd, bd, so)
+    check("bn_swish_fwd", so, s, tol(dt, 2e-5, 3e-2))
+    partial = torch.empty(L.LN_PARTIAL_BLOCKS * 2 * C, device=DEV)
+    ops.bn_swish_bwd_reduce(dev(ds, dt), cd, mean, rstd, gd, bd, partial)
+    bs = torch.empty(2 * C, device=DEV, dtype=torch.float64)
+    ops.reduce_partials_f64(partial, L.LN_PARTIAL_BLOCKS, 2 * C, bs)
+    dc = torch.empty(M, C, device=DEV, dtype=dt)
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.bn_swish_bwd_apply(dev(ds, dt), cd, mean, rstd, gd, bd, bs, bs, M, dc, dgam, dbet)
+    check("bn_bwd_dc", dc, cr.grad, tol(dt, 2e-5, 2e-2))
+    check("bn_bwd_dgamma", dgam, gamma.grad, 1e-3, 1e-4)
+    check("bn_bwd_dbeta", dbet, beta.grad, 1e-3, 1e-4)
+    # eval-mode statistics
+    ops.bn_eval_stats(dev(rm), dev(rv), mean, rstd)
+    ops.bn_swish_fwd(cd, mean, rstd, gd, bd, so)
+    ze = F.batch_norm(rt(c, dt), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 1e-5)
+    check("bn_swish_eval", so, ze * torch.sigmoid(ze), tol(dt, 2e-5, 3e-2))
+
+
+# ------------------------------------------------------------------------------------------------ front-end
+def test_normalize_dither_preemph():
+    w = 3.0 + 2.0 * torch.randn(3, 16000, generator=g(50))
+    out = ops.normalize_wav(dev(w))
+    check("normalize_wav", out, of.normalize_wav(w), 2e-5)
+    noise = torch.rand(3, 16000, generator=g(51))
+    out = ops.dither_preemph(dev(w), noise=dev(noise))
+    check("dither_preemph", out, of.dither_preemph(w, noise), 2e-6)
+    out2 = ops.dither_preemph(dev(w), seed=5)
+    check("dither_preemph_gen", out2, of.dither_preemph(w), 2.1e-5)        # differs only by the 1e-5*U dither
+
+
+@pytest.mark.parametrize("L_,pad,B", [(16000, 0, 4), (48000, 16, 3), (4000, 0, 2)])
+def test_logmel_matches_oracle(L_, pad, B):
+    w = of.normalize_wav(torch.randn(B, L_, generator=g(52)) * torch.linspace(0.2, 1.0, L_))
+    w[0] = torch.sin(2 * math.pi * 1000.0 * torch.arange(L_) / 16000.0)         # tonal utterance: deep floor
+    ref = of.wav2mel(w, pad=pad)                                                 # (B, 80, F)
+    out = ops.logmel(dev(w), pad=pad)
+    assert out.shape == (B, ref.shape[-1], 80)
+    check("logmel_db", out, ref.transpose(1, 2), 2e-3)
+    spans = torch.tensor([[[3, 9, 10, 22], [30, 31, 0, 5]]] * B, dtype=torch.int32)
+    out = ops.logmel(dev(w), pad=pad, spans=dev(spans))
+    ref_aug = torch.stack([of.apply_specaug(ref[i], [tuple(s) for s in spans[i].tolist()]) for i in range(B)])
+    check("logmel_specaug", out, ref_aug.transpose(1, 2), 2e-3)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_im2col(dt):
+    B, F_, C = 3, 101, 80
+    T = (F_ + 2 - 3) // 2 + 1
+    mel = torch.randn(B, F_, C, generator=g(53))
+    out = torch.empty(B * T, 3 * C, device=DEV, dtype=dt)
+    ops.im2col_k3s2(dev(mel), out, T)
+    padded = F.pad(mel, (0, 0, 1, 1))
+    ref = torch.stack([padded[:, 2 * t:2 * t + 3].reshape(B, 3 * C) for t in range(T)], 1).reshape(B * T, 3 * C)
+    check("im2col", out, rt(ref, dt), 0)
+    # and the GEMM against the permuted conv weight reproduces Conv1d(k3, s2, p1)
+    w = 0.1 * torch.randn(C, C, 3, generator=g(54))
+    bias = torch.randn(C, generator=g(55))
+    conv = F.conv1d(rt(mel, dt).transpose(1, 2), rt(w, dt), bias, stride=2, padding=1).transpose(1, 2).reshape(B * T, C)
+    w2 = w.permute(0, 2, 1).reshape(C, 3 * C)
+    y = torch.empty(B * T, C, device=DEV, dtype=dt)
+    ops.gemm_nt(out, dev(w2, dt), y, bias=dev(bias), act=L.ACT_RELU)
+    check("subsample_conv", y, torch.relu(conv), tol(dt, 1e-4, 5e-2))
+
+
+# ------------------------------------------------------------------------------------------------ loss
+def _ctc_case(B, T, V, Lmax, seed, in_len, tg_len, force_repeat=True):
+    logits = 2.0 * torch.randn(B, T, V + 1, generator=g(seed))
+    targets = torch.randint(0, V, (B, Lmax), generator=g(seed + 1))
+    if force_repeat:
+        targets[0, 1] = targets[0, 0]
+        targets[0, 3] = targets[0, 2]
+    return logits, targets, torch.tensor(in_len), torch.tensor(tg_len)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=4, T=51, V=40, Lmax=12, in_len=[51, 45, 51, 40], tg_len=[12, 9, 12, 6]),
+    dict(B=3, T=151, V=40, Lmax=20, in_len=[151, 151, 100], tg_len=[20, 20, 20]),
+    dict(B=3, T=20, V=5, Lmax=12, in_len=[20, 8, 20], tg_len=[12, 12, 0]),        # utt 1 infeasible -> zero_infinity
+    dict(B=2, T=300, V=4441, Lmax=60, in_len=[300, 280], tg_len=[60, 33]),        # large vocabulary (the reference's "cn")
+])
+def test_ctc_loss_and_grad(case):
+    B, T, V, Lmax = case["B"], case["T"], case["V"], case["Lmax"]
+    logits, targets, in_len, tg_len = _ctc_case(B, T, V, Lmax, 60, case["in_len"], case["tg_len"])
+    lr = logits.clone().requires_grad_()
+    per = F.ctc_loss(torch.log_softmax(lr, -1).transpose(0, 1), targets, in_len, tg_len, blank=V, reduction="none",
+                     zero_infinity=True)
+    per.mean().backward()
+    loss = torch.empty(B, device=DEV)
+    dl = torch.full((B, T, V + 1), 3.0, device=DEV)
+    ws = torch.empty(ops.ctc_workspace_bytes(B, T, V + 1, Lmax) // 4, device=DEV)
+    ops.ctc_loss(dev(logits), dev(targets), dev(in_len), dev(tg_len), loss, dl, ws, V, grad_scale=1.0 / B)
+    check("ctc_loss", loss, per, 2e-4, 2e-5)
+    check("ctc_grad", dl, lr.grad, 2e-6, 1e-4)
+
+
+def test_lid_score():
+    cfg = oc.ModelCfg(lang2vocab={"a": 30, "b": 40, "c": 50}, lang2index={"a": 0, "b": 1, "c": 2})
+    logits = {k: 3.0 * torch.randn(5, 51, v + 1, generator=g(70 + v)) for k, v in cfg.lang2vocab.items()}
+    ref = oc.lang_scores(logits, cfg)
+    scores = torch.zeros(5, 3, device=DEV)
+    for k, v in cfg.lang2vocab.items():
+        ops.lid_score(dev(logits[k]), scores[:, cfg.lang2index[k]:], 3, v)
+    check("lid_score", scores, ref, 2e-5)
+    assert torch.equal(scores.argmax(-1).cpu(), ref.argmax(-1))
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_novograd_clip_and_cast():
+    shapes = [(64, 48), (300,), (10, 7, 3), (9000,), (16, 16)]
+    sizes = [int(np.prod(s)) for s in shapes]
+    offs, o = [], 0
+    for n in sizes:
+        offs.append(o)
+        o += (n + 7) // 8 * 8
+    total = o
+    gen = g(80)
+    params = torch.zeros(total)
+    for off, n in zip(offs, sizes):
+        params[off:off + n] = torch.randn(n, generator=gen)
+    pd, gd = dev(params), torch.zeros(total, device=DEV)
+    md = torch.zeros(total, device=DEV)
+    vd = torch.zeros(len(shapes), device=DEV)
+    scratch = torch.empty(4096, device=DEV)
+    tn = torch.empty(1, device=DEV)
+    ref_p = [params[off:off + n].clone() for off, n in zip(offs, sizes)]
+    states = [oo.NovogradState() for _ in shapes]
+    for step, active in enumerate([[0, 1, 2, 3, 4], [0, 2, 3], [0, 1, 2, 3, 4]]):
+        grads = [None] * len(shapes)
+        gflat = torch.zeros(total)
+        for t in active:
+            grads[t] = (30.0 if step == 0 else 0.5) * torch.randn(sizes[t], generator=gen)   # step 0 exceeds max_norm=20
+            gflat[offs[t]:offs[t] + sizes[t]] = grads[t]
+        gd.copy_(gflat)
+        work = []
+        for t in active:
+            for s in range(0, sizes[t], L.OPT_CHUNK):
+                work.append([t, offs[t] + s, min(L.OPT_CHUNK, sizes[t] - s)])
+        ops.novograd_step(pd, gd, md, vd, dev(torch.tensor(work, dtype=torch.int64)), len(shapes), 0.01, (0.95, 0.98),
+                          1e-8, 1e-3, False, 20.0, scratch, tn)
+        act_g = [grads[t] for t in active]
+        total_norm = oo.clip_grad_norm(act_g, 20.0)
+        oo.novograd_step(ref_p, grads, states, 0.01, weight_decay=1e-3)
+        check(f"total_norm_{step}", tn, total_norm.reshape(1), 1e-3, 1e-5)
+        got = pd.cpu()
+        for t, (off, n) in enumerate(zip(offs, sizes)):
+            check(f"novograd_p{t}_step{step}", got[off:off + n], ref_p[t], 2e-6, 1e-5)
+    # cast_weights: W and W^T in the T arena
+    for dt in DT:
+        wT = torch.zeros(2 * 64 * 48 + 16, device=DEV, dtype=dt)
+        mats = torch.tensor([[offs[0], 64, 48, 0, 64 * 48 + 8, 0]], dtype=torch.int64)
+        ops.cast_weights(pd, wT, mats)
+        W = pd[offs[0]:offs[0] + 64 * 48].reshape(64, 48).cpu()
+        assert torch.equal(wT[:64 * 48].reshape(64, 48).cpu(), W.to(dt))
+        assert torch.equal(wT[64 * 48 + 8:64 * 48 + 8 + 64 * 48].reshape(48, 64).cpu(), W.t().contiguous().to(dt))
