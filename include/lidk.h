@@ -51,6 +51,9 @@ int lidk_logmel(const float* wav, const float* window, const float* twiddle, con
 /* ------------------------------------------------------------------ generic element-wise helpers */
 /* y = scale * x with dtype conversion (x_dtype/y_dtype in {LIDK_F32, LIDK_BF16}). */
 int lidk_scale_cast(const void* x, int x_dtype, void* y, int y_dtype, long n, float scale, void* stream);
+/* Strided 2-D variant: y[m][n] = scale*x[m][n], n < N; columns N..ldy of y are not written (zero padding stays). */
+int lidk_scale_cast_2d(const void* x, int ldx, int x_dtype, void* y, int ldy, int y_dtype, int M, int N, float scale,
+                       void* stream);
 /* nn.Dropout (lid/conformer.py:491,590; lid/ConformerLangModel.py:349): y = x*keep/(1-p).  keep_in (uint8, optional)
  * supplies the mask (backward pass / parity tests); otherwise it is generated from (seed, index) and, if keep_out is
  * non-NULL, written there. */
@@ -166,7 +169,7 @@ int lidk_novograd_step(float* params, float* grads, float* exp_avg, float* exp_a
                        int grad_averaging, float max_norm, float* scratch, float* total_norm_out, void* stream);
 /* Refresh the T-typed GEMM operands from the f32 master parameters: for each of n_mats entries
  * mats [n][6] int64 = (src offset in `params`, rows, cols, dst offset of W [rows][cols] in wT or -1,
- * dst offset of W^T [cols][rows] in wT or -1, reserved). */
+ * dst offset of W^T in wT or -1, leading dimension of W^T (>= rows; 0 means rows; pad columns are not written)). */
 int lidk_cast_weights(const float* params, void* wT, const int64_t* mats_host, int n_mats, int dtype, void* stream);
 
 #ifdef __cplusplus

@@ -35,6 +35,34 @@ extern "C" int lidk_scale_cast(const void* x, int xd, void* y, int yd, long n, f
   return LIDK_ERR_ARG;
 }
 
+// strided 2-D variant: y[m][n] = scale * x[m][n] for n < N (pad columns of y are left untouched)
+template <typename TI, typename TO>
+__global__ void scale_cast_2d_kernel(const TI* __restrict__ x, int ldx, TO* __restrict__ y, int ldy, int M, int N, float scale) {
+  long n_el = (long)M * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_el; i += (long)gridDim.x * blockDim.x) {
+    long m = i / N; int n = (int)(i - m * N);
+    y[m * ldy + n] = from_f<TO>(to_f(x[m * ldx + n]) * scale);
+  }
+}
+template <typename TI, typename TO>
+static int scale_cast_2d_launch(const void* x, int ldx, void* y, int ldy, int M, int N, float scale, hipStream_t s) {
+  long n_el = (long)M * N;
+  int blocks = (int)((n_el + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  scale_cast_2d_kernel<TI, TO><<<blocks, 256, 0, s>>>((const TI*)x, ldx, (TO*)y, ldy, M, N, scale);
+  return launch_status();
+}
+extern "C" int lidk_scale_cast_2d(const void* x, int ldx, int xd, void* y, int ldy, int yd, int M, int N, float scale,
+                                  void* stream) {
+  if (!x || !y || M <= 0 || N <= 0 || ldx < N || ldy < N) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  if (xd == LIDK_F32 && yd == LIDK_F32) return scale_cast_2d_launch<float, float>(x, ldx, y, ldy, M, N, scale, s);
+  if (xd == LIDK_F32 && yd == LIDK_BF16) return scale_cast_2d_launch<float, bf16>(x, ldx, y, ldy, M, N, scale, s);
+  if (xd == LIDK_BF16 && yd == LIDK_F32) return scale_cast_2d_launch<bf16, float>(x, ldx, y, ldy, M, N, scale, s);
+  if (xd == LIDK_BF16 && yd == LIDK_BF16) return scale_cast_2d_launch<bf16, bf16>(x, ldx, y, ldy, M, N, scale, s);
+  return LIDK_ERR_ARG;
+}
+
 // ------------------------------------------------------------------------------------ dropout
 // Counter-based generator: splitmix64 of (seed, element index) -> 24-bit uniform.  Stateless, so the same
 // (seed, index) gives the same decision on every rank and in the backward pass.

@@ -95,7 +95,7 @@ extern "C" int lidk_novograd_step(float* params, float* grads, float* exp_avg, f
 
 // ------------------------------------------------------------------------------------ weight refresh (f32 master -> T operands)
 template <typename T>
-__global__ void cast_matrix_kernel(const float* __restrict__ src, T* __restrict__ w, T* __restrict__ wt, int R, int C) {
+__global__ void cast_matrix_kernel(const float* __restrict__ src, T* __restrict__ w, T* __restrict__ wt, int R, int C, int ldt) {
   __shared__ float tile[32][33];
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: 8 rows per pass
@@ -111,7 +111,7 @@ __global__ void cast_matrix_kernel(const float* __restrict__ src, T* __restrict_
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     int c = c0 + i, r = r0 + tx;
-    if (r < R && c < C) wt[(size_t)c * R + r] = from_f<T>(tile[tx][i]);
+    if (r < R && c < C) wt[(size_t)c * ldt + r] = from_f<T>(tile[tx][i]);
   }
 }
 
@@ -121,16 +121,17 @@ extern "C" int lidk_cast_weights(const float* params, void* wT, const int64_t* m
   for (int i = 0; i < n_mats; ++i) {
     const int64_t* m = mats + (size_t)i * 6;
     const int R = (int)m[1], C = (int)m[2];
-    if (R <= 0 || C <= 0) return LIDK_ERR_ARG;
+    const int ldt = m[5] > 0 ? (int)m[5] : R;
+    if (R <= 0 || C <= 0 || ldt < R) return LIDK_ERR_ARG;
     dim3 grid(cdiv(C, 32), cdiv(R, 32));
     if (dtype == LIDK_BF16) {
       bf16* base = (bf16*)wT;
       cast_matrix_kernel<bf16><<<grid, 256, 0, s>>>(params + m[0], m[3] >= 0 ? base + m[3] : nullptr,
-                                                    m[4] >= 0 ? base + m[4] : nullptr, R, C);
+                                                    m[4] >= 0 ? base + m[4] : nullptr, R, C, ldt);
     } else if (dtype == LIDK_F32) {
       float* base = (float*)wT;
       cast_matrix_kernel<float><<<grid, 256, 0, s>>>(params + m[0], m[3] >= 0 ? base + m[3] : nullptr,
-                                                     m[4] >= 0 ? base + m[4] : nullptr, R, C);
+                                                     m[4] >= 0 ? base + m[4] : nullptr, R, C, ldt);
     } else {
       return LIDK_ERR_ARG;
     }

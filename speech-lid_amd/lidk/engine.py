@@ -1,0 +1,550 @@
+"""Host-side orchestration of the HIP kernels for the Conformer-LID model (forward + hand-written backward).
+
+One ``Engine`` owns, in HBM:
+  * ``flat``  f32 master parameters, ``grad`` f32 gradients (parallel arenas, layout.py), BatchNorm buffers;
+  * ``wT``    the GEMM operands in the activation dtype T (bf16 or f32): every weight W [N,K] and its transpose;
+  * per-(B,T) workspaces: saved activations of every block (T) and the f32 residual stream.
+torch provides memory and the current stream only; all arithmetic is lidk kernels.  There is no autograd inside:
+``backward`` replays the block chain in reverse with explicit dgrad / wgrad GEMMs.
+
+Reference semantics followed: lid/conformer.py:252-259 (block), :445-466 (encoder, stochastic depth),
+lid/ConformerLangModel.py:272-294,352-356 (heads).
+"""
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from ._lib import LidkError
+from .layout import ALIGN, ConformerCfg, Spec, init_values, model_specs
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+class _BlockParams:
+    """Views of one ConformerBlock's parameters: f32 master / gradient views and T-typed GEMM operands."""
+
+    def __init__(self, eng: "Engine", p: str, heads: int, dh: int):
+        self.p, self.heads, self.dh = p, heads, dh
+        v, g, w = eng.pview, eng.gview, eng.wview
+        self.names = [s.name for s in eng.specs if s.name.startswith(p + ".")]
+        for tag, n in (("ff1", ".ff1.fn"), ("ff2", ".ff2.fn")):
+            setattr(self, tag, dict(
+                ln_w=v(p + n + ".norm.weight"), ln_b=v(p + n + ".norm.bias"),
+                dln_w=g(p + n + ".norm.weight"), dln_b=g(p + n + ".norm.bias"),
+                w1=w(p + n + ".fn.net.0.weight"), b1=v(p + n + ".fn.net.0.bias"),
+                dw1=g(p + n + ".fn.net.0.weight"), db1=g(p + n + ".fn.net.0.bias"),
+                w2=w(p + n + ".fn.net.3.weight"), b2=v(p + n + ".fn.net.3.bias"),
+                dw2=g(p + n + ".fn.net.3.weight"), db2=g(p + n + ".fn.net.3.bias")))
+        a = p + ".attn"
+        self.attn = dict(ln_w=v(a + ".norm.weight"), ln_b=v(a + ".norm.bias"),
+                         dln_w=g(a + ".norm.weight"), dln_b=g(a + ".norm.bias"),
+                         wqkv=eng.wview_qkv(a + ".fn"), dwqkv=eng.gview_qkv(a + ".fn"),
+                         wo=w(a + ".fn.to_out.weight"), bo=v(a + ".fn.to_out.bias"),
+                         dwo=g(a + ".fn.to_out.weight"), dbo=g(a + ".fn.to_out.bias"),
+                         emb=v(a + ".fn.rel_pos_emb.weight"), demb=g(a + ".fn.rel_pos_emb.weight"))
+        c = p + ".conv.net"
+        self.conv = dict(ln_w=v(c + ".0.weight"), ln_b=v(c + ".0.bias"), dln_w=g(c + ".0.weight"), dln_b=g(c + ".0.bias"),
+                         w1=w(c + ".2.weight"), b1=v(c + ".2.bias"), dw1=g(c + ".2.weight"), db1=g(c + ".2.bias"),
+                         dw=v(c + ".4.conv.weight"), dwb=v(c + ".4.conv.bias"),
+                         ddw=g(c + ".4.conv.weight"), ddwb=g(c + ".4.conv.bias"),
+                         bn_w=v(c + ".5.weight"), bn_b=v(c + ".5.bias"), dbn_w=g(c + ".5.weight"), dbn_b=g(c + ".5.bias"),
+                         rm=eng.buffers[c + ".5.running_mean"], rv=eng.buffers[c + ".5.running_var"],
+                         nbt=eng.buffers[c + ".5.num_batches_tracked"],
+                         w2=w(c + ".7.weight"), b2=v(c + ".7.bias"), dw2=g(c + ".7.weight"), db2=g(c + ".7.bias"))
+        self.post = dict(w=v(p + ".post_norm.weight"), b=v(p + ".post_norm.bias"),
+                         dw=g(p + ".post_norm.weight"), db=g(p + ".post_norm.bias"))
+
+
+class _BlockBuf:
+    """Saved activations of one block for one (B, T)."""
+
+    def __init__(self, eng: "Engine", B: int, T: int, heads: int, dh: int, ff: int, ci: int):
+        M, d, dev, dt = B * T, eng.cfg.d, eng.device, eng.act_dtype
+        e = lambda *s: torch.empty(*s, device=dev, dtype=dt)
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        inner = heads * dh
+        self.mean = [f(M) for _ in range(5)]
+        self.rstd = [f(M) for _ in range(5)]
+        self.h1, self.a1, self.u1, self.x1 = e(M, d), e(M, ff), e(M, ff), f(M, d)
+        self.h2, self.qkv, self.probs, self.o, self.x2 = e(M, d), e(M, 3 * inner), e(B, heads, T, T), e(M, inner), f(M, d)
+        self.h3, self.y, self.g, self.c, self.s, self.x3 = e(M, d), e(M, 2 * ci), e(M, ci), e(M, ci), e(M, ci), f(M, d)
+        self.bn_mean, self.bn_rstd = f(ci), f(ci)
+        self.h4, self.a4, self.u4, self.x4 = e(M, d), e(M, ff), e(M, ff), f(M, d)
+        self.out = f(M, d)
+
+
+class _Work:
+    """Everything sized by (B, F): front-end buffers, per-block buffers, backward scratch."""
+
+    def __init__(self, eng: "Engine", B: int, F_: int):
+        cfg = eng.cfg
+        self.B, self.F = B, F_
+        self.T = T = (F_ + 2 - 3) // 2 + 1
+        self.M = M = B * T
+        self.Mp = Mp = _ceil(M, 8)
+        d, dev, dt = cfg.d, eng.device, eng.act_dtype
+        e = lambda *s: torch.empty(*s, device=dev, dtype=dt)
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=dt)
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        ff, ci = d * cfg.ff_mult, d * cfg.conv_expansion_factor
+        self.col = e(M, 3 * cfg.n_mels)
+        ff_e, ci_e = ff, ci
+        self.r = e(M, cfg.n_mels)
+        self.x0 = f(M, d)
+        self.x0d = f(M, d)
+        self.pos_keep = torch.empty(M * d, device=dev, dtype=torch.uint8)
+        self.enc = [_BlockBuf(eng, B, T, cfg.heads, cfg.dim_head, ff_e, ci_e) for _ in range(cfg.n_blocks)]
+        ff, ci = max(ff_e, 4 * d), max(ci_e, 2 * d)          # scratch must also fit the head block (ff 4d, conv 2d, k 31)
+        self.head = _BlockBuf(eng, B, T, cfg.last_heads, cfg.last_dim_head, d * 4, d * 2)
+        self.head_h = e(M, d)
+        self.head_keep = torch.empty(M * d, device=dev, dtype=torch.uint8)
+        self.v1p = _ceil(max(cfg.lang2vocab.values()) + 1, 8)
+        self.dlT = z(M, self.v1p)
+        # backward scratch (shared by all blocks)
+        cmax = max(ff, 2 * ci, 3 * cfg.heads * cfg.dim_head, 3 * cfg.last_heads * cfg.last_dim_head, 4 * d, 3 * cfg.n_mels,
+                   self.v1p)
+        self.cmax = cmax
+        self.tA, self.tB = z(cmax, Mp), z(cmax, Mp)          # transposed operands; pad columns stay zero
+        self.dbig = e(M, cmax)                                # da / dy_pw1 / dqkv
+        self.dmid = e(M, max(ci, cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head, d))   # ds / do
+        self.dmid2 = e(M, ci)
+        self.dmid3 = e(M, ci)
+        self.dh = e(M, d)
+        self.dyT = e(M, d)
+        self.dxa, self.dxb = f(M, d), f(M, d)
+        hmax = max(cfg.heads, cfg.last_heads)
+        self.dsc = f(B, hmax, T, T)
+        self.partial = f(L.LN_PARTIAL_BLOCKS * 2 * cmax)
+        self.stat_parts = eng.k.dwconv_stat_parts(B, T)
+        self.stat_partial = f(self.stat_parts * 2 * ci)
+        self.dw_partial = f(B * ci * (max(cfg.conv_kernel_size, 31) + 1))
+        self.sums = torch.empty(2 * ci, device=dev, dtype=torch.float64)
+        self.sums_local = torch.empty(2 * ci, device=dev, dtype=torch.float64)
+        self.dconv3 = f(cfg.n_mels, 3 * cfg.n_mels)
+        self.logits: Dict[str, torch.Tensor] = {}
+
+
+class Engine:
+    def __init__(self, cfg: ConformerCfg, act_dtype=torch.bfloat16, backend=None):
+        self.cfg = cfg
+        self.act_dtype = act_dtype
+        # kernel backend: the real lidk.ops (HIP; refuses CPU tensors).  tests/ may inject a torch-CPU fake to check
+        # the orchestration on a GPU-less machine; nothing in the product constructs an Engine with another backend.
+        self.k = backend if backend is not None else ops
+        self.device = torch.device("cpu")
+        self.specs, self.buffer_specs, self.stages, self.n_flat = model_specs(cfg)
+        self.by_name: Dict[str, Spec] = {s.name: s for s in self.specs}
+        self.flat = torch.zeros(self.n_flat)
+        self.grad: Optional[torch.Tensor] = None
+        self.buffers: Dict[str, torch.Tensor] = {}
+        for name, shape, dt in self.buffer_specs:
+            self.buffers[name] = torch.ones(shape) if name.endswith("running_var") else torch.zeros(shape, dtype=dt)
+        self._built = False
+        self.reset_parameters()
+        self._work: Dict[tuple, _Work] = {}
+        # data-parallel hooks (set by the Trainer): all-reduce of f64 BatchNorm sums, and "gradients of stage ready"
+        self.stat_allreduce: Optional[Callable[[torch.Tensor], None]] = None
+        self.on_stage_grads_ready: Optional[Callable[[str], None]] = None
+        self.world_size = 1
+        self.seed = 0
+        self.step_count = 0
+
+    # ------------------------------------------------------------------ parameters
+    def reset_parameters(self):
+        vals = init_values(self.cfg)
+        for s in self.specs:
+            self.flat[s.offset:s.offset + s.numel] = vals[s.name].reshape(-1).to(self.flat.device)
+        for name, t in self.buffers.items():
+            if name.endswith("running_var"):
+                t.fill_(1)
+            else:
+                t.zero_()
+        if self._built:
+            self.refresh_weights()
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == "cpu" and not self._built and self.k is ops:
+            return self                      # still on the host before the first move to a GPU: nothing to build
+        self.device = device
+        self.flat = self.flat.to(device)
+        self.grad = torch.zeros_like(self.flat)
+        self.buffers = {k: v.to(device) for k, v in self.buffers.items()}
+        self._build_operands()
+        return self
+
+    def load_state(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """Copy a reference-named state dict (parameters + BatchNorm buffers) into the arenas."""
+        missing = [n for n in list(self.by_name) + list(self.buffers) if n not in sd]
+        unexpected = [n for n in sd if n not in self.by_name and n not in self.buffers]
+        if strict and (missing or unexpected):
+            raise KeyError(f"state dict mismatch: missing {missing[:5]} unexpected {unexpected[:5]}")
+        with torch.no_grad():
+            for n, t in sd.items():
+                if n in self.by_name:
+                    s = self.by_name[n]
+                    if tuple(t.shape) != tuple(s.shape):
+                        raise ValueError(f"{n}: shape {tuple(t.shape)} != {tuple(s.shape)}")
+                    self.flat[s.offset:s.offset + s.numel].copy_(t.reshape(-1).to(self.flat.dtype))
+                elif n in self.buffers:
+                    self.buffers[n].copy_(t.to(self.buffers[n].dtype))
+        if self._built:
+            self.refresh_weights()
+
+    def state(self) -> Dict[str, torch.Tensor]:
+        out = {s.name: self.pview(s.name) for s in self.specs}
+        out.update(self.buffers)
+        return out
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def pview(self, name):
+        s = self.by_name[name]
+        return self.flat[s.offset:s.offset + s.numel].view(s.shape)
+
+    def gview(self, name):
+        s = self.by_name[name]
+        return self.grad[s.offset:s.offset + s.numel].view(s.shape)
+
+    def wview(self, name):
+        """(W [N,K], W^T [K,ldt]) views in the T arena."""
+        return self._wviews[name]
+
+    def wview_qkv(self, prefix):
+        return self._wviews[prefix + ".to_q.weight+to_kv"]
+
+    def gview_qkv(self, prefix):
+        q, kv = self.by_name[prefix + ".to_q.weight"], self.by_name[prefix + ".to_kv.weight"]
+        assert kv.offset == q.offset + q.numel, "to_q/to_kv must be adjacent in the arena"
+        n = q.shape[0] + kv.shape[0]
+        return self.grad[q.offset:q.offset + n * q.shape[1]].view(n, q.shape[1])
+
+    def _build_operands(self):
+        """Lay out the T-typed copies: per GEMM weight W [N,K] and W^T [K, ceil8(N)] (zero padded)."""
+        mats, views, off = [], {}, 0
+
+        def add(key, src_off, n, k):
+            nonlocal off
+            ldt = _ceil(n, 8)
+            w_off, off = off, off + _ceil(n * k, ALIGN)
+            t_off, off = off, off + _ceil(k * ldt, ALIGN)
+            mats.append([src_off, n, k, w_off, t_off, ldt])
+            views[key] = (w_off, t_off, n, k, ldt)
+
+        skip = set()
+        for s in self.specs:
+            if s.kind != "w" or s.name in skip:
+                continue
+            if s.name.endswith(".to_q.weight"):
+                kv = self.by_name[s.name.replace("to_q", "to_kv")]
+                assert kv.offset == s.offset + s.numel
+                add(s.name[:-len(".to_q.weight")] + ".to_q.weight+to_kv", s.offset, s.shape[0] + kv.shape[0], s.shape[1])
+                skip.add(kv.name)
+                continue
+            add(s.name, s.offset, s.shape[0], s.shape[1])
+        c3 = self.by_name["model.featurizer.sub_sampling.sub_sampling.0.weight"]
+        self._c3_off, off = off, off + _ceil(c3.shape[0] * 3 * c3.shape[1], ALIGN)
+        self.wT = torch.zeros(off, device=self.device, dtype=self.act_dtype)
+        self.mats = torch.tensor(mats, dtype=torch.int64)
+        self._wviews = {}
+        for key, (w_off, t_off, n, k, ldt) in views.items():
+            self._wviews[key] = (self.wT[w_off:w_off + n * k].view(n, k), self.wT[t_off:t_off + k * ldt].view(k, ldt))
+        self.w_conv3 = self.wT[self._c3_off:self._c3_off + c3.shape[0] * 3 * c3.shape[1]].view(c3.shape[0], 3 * c3.shape[1])
+        fz = "model.featurizer"
+        self.enc_params = [_BlockParams(self, f"{fz}.encoders.{i}", self.cfg.heads, self.cfg.dim_head)
+                           for i in range(self.cfg.n_blocks)]
+        self.head_params = {l: _BlockParams(self, f"model.last_projects.{l}.block", self.cfg.last_heads, self.cfg.last_dim_head)
+                            for l in self.cfg.lang2vocab}
+        self._built = True
+        self._work.clear()
+        self.refresh_weights()
+
+    def refresh_weights(self):
+        """f32 master -> T operands (after an optimizer step, load_state_dict or reset)."""
+        self.k.cast_weights(self.flat, self.wT, self.mats)
+        c3 = self.pview("model.featurizer.sub_sampling.sub_sampling.0.weight")       # [Co][Ci][3] -> [Co][k*Ci+ci]
+        self.w_conv3.copy_(c3.permute(0, 2, 1).reshape(c3.shape[0], -1))             # 19 K elements: layout glue, not math
+
+    def work(self, B, F_):
+        key = (B, F_)
+        if key not in self._work:
+            if len(self._work) >= 4:
+                self._work.pop(next(iter(self._work)))
+            self._work[key] = _Work(self, B, F_)
+        return self._work[key]
+
+    # ------------------------------------------------------------------ forward pieces
+    def _front_fwd(self, w: _Work, mel, training, seed):
+        cfg = self.cfg
+        fz = "model.featurizer.sub_sampling"
+        self.k.im2col_k3s2(mel, w.col, w.T)
+        self.k.gemm_nt(w.col, self.w_conv3, w.r, bias=self.pview(fz + ".sub_sampling.0.bias"), act=L.ACT_RELU)
+        self.k.gemm_nt(w.r, self.wview(fz + ".linear.weight")[0], w.x0, bias=self.pview(fz + ".linear.bias"),
+                    alpha=math.sqrt(cfg.d))
+        if training and cfg.pos_dropout > 0:
+            self.k.dropout(w.x0, w.x0d, cfg.pos_dropout, seed=seed, keep_in=self._forced_masks.get("pos"),
+                        keep_out=w.pos_keep)
+            return w.x0d
+        return w.x0
+
+    def _ff_fwd(self, x, P, h, a, u, xo, mean, rstd):
+        self.k.layernorm_fwd(x, P["ln_w"], P["ln_b"], yT=h, mean=mean, rstd=rstd)
+        self.k.gemm_nt(h, P["w1"][0], u, bias=P["b1"], act=L.ACT_SWISH, out2=a)
+        self.k.gemm_nt(u, P["w2"][0], xo, bias=P["b2"], alpha=0.5, res=x)
+
+    def _block_fwd(self, x, bp: _BlockParams, bb: _BlockBuf, w: _Work, training: bool):
+        B, T, M = w.B, w.T, w.M
+        self._ff_fwd(x, bp.ff1, bb.h1, bb.a1, bb.u1, bb.x1, bb.mean[0], bb.rstd[0])
+        A = bp.attn
+        self.k.layernorm_fwd(bb.x1, A["ln_w"], A["ln_b"], yT=bb.h2, mean=bb.mean[1], rstd=bb.rstd[1])
+        self.k.gemm_nt(bb.h2, A["wqkv"][0], bb.qkv)
+        self.k.attn_fwd(bb.qkv, A["emb"], bb.o, bb.probs, B, T, bp.heads, bp.dh)
+        self.k.gemm_nt(bb.o, A["wo"][0], bb.x2, bias=A["bo"], res=bb.x1)
+        C = bp.conv
+        ci, K = C["dw"].shape[0], C["dw"].shape[2]
+        self.k.layernorm_fwd(bb.x2, C["ln_w"], C["ln_b"], yT=bb.h3, mean=bb.mean[2], rstd=bb.rstd[2])
+        self.k.gemm_nt(bb.h3, C["w1"][0], bb.y, bias=C["b1"])
+        self.k.glu_fwd(bb.y, bb.g)
+        dw2d = C["dw"].view(ci, K)
+        pad_left = K // 2
+        if training:
+            self.k.dwconv_fwd(bb.g, dw2d, C["dwb"], bb.c, w.stat_partial, B, T, pad_left)
+            self.k.reduce_partials_f64(w.stat_partial, w.stat_parts, 2 * ci, w.sums[:2 * ci])
+            if self.stat_allreduce is not None:
+                self.stat_allreduce(w.sums[:2 * ci])
+            self.k.bn_train_stats(w.sums[:2 * ci], M * self.world_size, bb.bn_mean, bb.bn_rstd, C["rm"], C["rv"], C["nbt"])
+        else:
+            self.k.dwconv_fwd(bb.g, dw2d, C["dwb"], bb.c, None, B, T, pad_left)
+            self.k.bn_eval_stats(C["rm"], C["rv"], bb.bn_mean, bb.bn_rstd)
+        self.k.bn_swish_fwd(bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], bb.s)
+        self.k.gemm_nt(bb.s, C["w2"][0], bb.x3, bias=C["b2"], res=bb.x2)
+        self._ff_fwd(bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.x4, bb.mean[3], bb.rstd[3])
+        return bb.x4
+
+    def _head_fwd(self, w: _Work, feat, lang, training, seed, logits):
+        cfg = self.cfg
+        bp, bb = self.head_params[lang], w.head
+        x4 = self._block_fwd(feat, bp, bb, w, training)
+        p = f"model.last_projects.{lang}.linear"
+        if training and cfg.dropout > 0:
+            self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
+                              dtype=self.act_dtype)
+            self.k.dropout(bb.out, w.head_h, cfg.dropout, seed=seed + 7919, keep_in=self._forced_masks.get("head"),
+                        keep_out=w.head_keep)
+        else:
+            self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], yT=w.head_h, mean=bb.mean[4], rstd=bb.rstd[4])
+        self.k.gemm_nt(w.head_h, self.wview(p + ".weight")[0], logits, bias=self.pview(p + ".bias"))
+
+    _forced_masks: Dict[str, torch.Tensor] = {}
+
+    def forward(self, mel: torch.Tensor, lang: Optional[str], training: bool, keep_layers: Optional[List[bool]] = None,
+                masks: Optional[Dict[str, torch.Tensor]] = None):
+        """mel (B, F, n_mels) f32 on the GPU -> {lang: logits (B, T, V+1) f32}.  In training mode the activations needed
+        by ``backward`` stay in the (B, F) workspace until the next forward of the same shape."""
+        if not self._built:
+            raise LidkError("Engine.forward before Engine.to('cuda')")
+        if mel.dtype != torch.float32:
+            raise LidkError(f"Engine.forward needs float32 features, got {mel.dtype}")
+        if self.k is ops and not mel.is_cuda:
+            raise LidkError(f"Engine.forward got a tensor on {mel.device}: the HIP path has no CPU fallback")
+        mel = mel.contiguous()
+        B, F_, nm = mel.shape
+        if nm != self.cfg.n_mels:
+            raise LidkError(f"expected {self.cfg.n_mels} mel bins, got {nm}")
+        w = self.work(B, F_)
+        self._forced_masks = masks or {}
+        self.step_count += 1
+        seed = (self.seed * 1000003 + self.step_count) & 0x7FFFFFFFFFFF
+        x = self._front_fwd(w, mel, training, seed)
+        keep = keep_layers if (training and keep_layers is not None) else [True] * self.cfg.n_blocks
+        for i in range(self.cfg.n_blocks):
+            if not keep[i]:
+                continue
+            bp, bb = self.enc_params[i], w.enc[i]
+            x4 = self._block_fwd(x, bp, bb, w, training)
+            self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
+                              dtype=self.act_dtype)
+            x = bb.out
+        out = {}
+        langs = [lang] if lang is not None else list(self.cfg.lang2vocab)
+        for l in langs:
+            v1 = self.cfg.lang2vocab[l] + 1
+            key = (l, B)
+            if key not in w.logits:
+                w.logits[key] = torch.empty(w.M, v1, device=self.device, dtype=torch.float32)
+            self._head_fwd(w, x, l, training, seed, w.logits[key])
+            out[l] = w.logits[key].view(B, w.T, v1)
+        self._ctx = dict(w=w, feat=x, keep=keep, lang=lang, training=training, front_in=mel)
+        self._forced_masks = {}
+        return out
+
+    # ------------------------------------------------------------------ backward pieces
+    def _splitk(self, n, k, Mp):
+        tiles = -(-n // 64) * -(-k // 64)
+        return max(1, min(-(-768 // tiles), Mp // 128 if Mp >= 128 else 1))
+
+    def _wgrad(self, w: _Work, dyT, xT, dW, n, k):
+        """dW [n,k] (f32) += dyT[M,n]^T @ xT[M,k] via two transposes and a split-K NT GEMM."""
+        tA, tB = w.tA[:n], w.tB[:k]
+        self.k.transpose(dyT, tA)
+        self.k.transpose(xT, tB)
+        self.k.gemm_nt(tA, tB, dW, splitk=self._splitk(n, k, w.Mp), M=n, N=k, K=w.Mp)
+
+    def _ff_bwd(self, w: _Work, dx_res, dyT, x_in, P, h, a, u, mean, rstd, dx_out, dxT_out, dxT_scale):
+        """dyT = 0.5*dx_res (T).  Produces dx_out = dx_res + LN'(dh) and optional T copy for the next stage."""
+        M, d, ff = w.M, self.cfg.d, a.shape[1]
+        self._wgrad(w, dyT, u, P["dw2"], d, ff)
+        self.k.colsum(dyT, P["db2"], w.partial)
+        da = w.dbig[:, :ff] if w.dbig.shape[1] == ff else w.dbig.view(-1)[:M * ff].view(M, ff)
+        self.k.gemm_nt(dyT, P["w2"][1], da, act=L.ACT_SWISH_GRAD, aux=a, N=ff, K=d)
+        self._wgrad(w, da, h, P["dw1"], ff, d)
+        self.k.colsum(da, P["db1"], w.partial)
+        self.k.gemm_nt(da, P["w1"][1], w.dh, N=d, K=ff)
+        self.k.layernorm_bwd(w.dh, x_in, mean, rstd, P["ln_w"], w.partial, dres=dx_res, dx=dx_out, dxT=dxT_out,
+                          dxT_scale=dxT_scale, dgamma=P["dln_w"], dbeta=P["dln_b"], dtype=self.act_dtype)
+
+    def _block_bwd(self, w: _Work, x_in, bp: _BlockParams, bb: _BlockBuf, dx4, dyT_half, dx_in_out, want_T=None):
+        """dx4: f32 gradient at x4 (after post_norm backward); dyT_half = 0.5*dx4 in T.  Writes the gradient w.r.t. the
+        block input into dx_in_out (f32)."""
+        B, T, M, d = w.B, w.T, w.M, self.cfg.d
+        a, b = (w.dxa, w.dxb) if dx4 is w.dxb else (w.dxb, w.dxa)     # two f32 ping-pong buffers
+        # ---- ff2: y = x3 + 0.5*ff(x3)
+        self._ff_bwd(w, dx4, dyT_half, bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.mean[3], bb.rstd[3], a, w.dyT, 1.0)
+        dx3 = a
+        # ---- conv module: y = x2 + conv(x2)
+        C = bp.conv
+        ci, K = C["dw"].shape[0], C["dw"].shape[2]
+        pad_left = K // 2
+        self._wgrad(w, w.dyT, bb.s, C["dw2"].view(d, ci), d, ci)
+        self.k.colsum(w.dyT, C["db2"], w.partial)
+        ds = w.dmid.view(-1)[:M * ci].view(M, ci)
+        self.k.gemm_nt(w.dyT, C["w2"][1], ds, N=ci, K=d)
+        self.k.bn_swish_bwd_reduce(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial)
+        self.k.reduce_partials_f64(w.partial, L.LN_PARTIAL_BLOCKS, 2 * ci, w.sums_local[:2 * ci])
+        sums = w.sums_local
+        if self.stat_allreduce is not None:
+            w.sums[:2 * ci].copy_(w.sums_local[:2 * ci])
+            self.stat_allreduce(w.sums[:2 * ci])
+            sums = w.sums
+        dc = w.dmid2
+        self.k.bn_swish_bwd_apply(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], sums[:2 * ci], w.sums_local[:2 * ci],
+                               M * self.world_size, dc, C["dbn_w"], C["dbn_b"])
+        self.k.dwconv_bwd_weight(dc, bb.g, C["ddw"].view(ci, K), C["ddwb"], w.dw_partial, B, T, pad_left)
+        dg = w.dmid3
+        self.k.dwconv_bwd_input(dc, C["dw"].view(ci, K), dg, B, T, pad_left)
+        dy1 = w.dbig.view(-1)[:M * 2 * ci].view(M, 2 * ci)
+        self.k.glu_bwd(bb.y, dg, dy1)
+        self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d)
+        self.k.colsum(dy1, C["db1"], w.partial)
+        self.k.gemm_nt(dy1, C["w1"][1], w.dh, N=d, K=2 * ci)
+        self.k.layernorm_bwd(w.dh, bb.x2, bb.mean[2], bb.rstd[2], C["ln_w"], w.partial, dres=dx3, dx=b, dxT=w.dyT,
+                          dxT_scale=1.0, dgamma=C["dln_w"], dbeta=C["dln_b"], dtype=self.act_dtype)
+        dx2 = b
+        # ---- attention: y = x1 + attn(x1)
+        A = bp.attn
+        inner = bp.heads * bp.dh
+        self._wgrad(w, w.dyT, bb.o, A["dwo"], d, inner)
+        self.k.colsum(w.dyT, A["dbo"], w.partial)
+        do = w.dmid.view(-1)[:M * inner].view(M, inner)
+        self.k.gemm_nt(w.dyT, A["wo"][1], do, N=inner, K=d)
+        dqkv = w.dbig.view(-1)[:M * 3 * inner].view(M, 3 * inner)
+        self.k.attn_bwd(bb.qkv, A["emb"], bb.probs, do, dqkv, A["demb"], w.dsc, B, T, bp.heads, bp.dh)
+        self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
+        self.k.gemm_nt(dqkv, A["wqkv"][1], w.dh, N=d, K=3 * inner)
+        self.k.layernorm_bwd(w.dh, bb.x1, bb.mean[1], bb.rstd[1], A["ln_w"], w.partial, dres=dx2, dx=a, dxT=w.dyT,
+                          dxT_scale=0.5, dgamma=A["dln_w"], dbeta=A["dln_b"], dtype=self.act_dtype)
+        dx1 = a
+        # ---- ff1
+        self._ff_bwd(w, dx1, w.dyT, x_in, bp.ff1, bb.h1, bb.a1, bb.u1, bb.mean[0], bb.rstd[0], dx_in_out, None, 1.0)
+
+    def backward(self, dlogits: torch.Tensor):
+        """dlogits (B, T, V+1) f32 for the language of the last training forward.  Accumulates into ``grad``."""
+        ctx = self._ctx
+        if not ctx["training"] or ctx["lang"] is None:
+            raise LidkError("Engine.backward needs a preceding training-mode forward with a single language")
+        cfg, w, lang = self.cfg, ctx["w"], ctx["lang"]
+        M, d = w.M, cfg.d
+        v1 = cfg.lang2vocab[lang] + 1
+        v1p = _ceil(v1, 8)
+        dl = dlogits.contiguous().view(M, v1)
+        p = f"model.last_projects.{lang}.linear"
+        dlT = w.dlT.view(-1)[:M * v1p].view(M, v1p)
+        if v1p != v1:
+            dlT.zero_()
+        self.k.scale_cast_2d(dl, dlT, M, v1)
+        # vocabulary projection
+        self._wgrad(w, dlT[:, :v1], w.head_h, self.gview(p + ".weight"), v1, d)
+        self.k.colsum(dl, self.gview(p + ".bias"), w.partial)
+        self.k.gemm_nt(dlT, self.wview(p + ".weight")[1][:, :v1p], w.dh, N=d, K=v1p)
+        bp, bb = self.head_params[lang], w.head
+        dy_ln = w.dh
+        if cfg.dropout > 0:
+            self.k.dropout(w.dh, w.dyT, cfg.dropout, keep_in=w.head_keep)
+            dy_ln = w.dyT
+            # post_norm backward consumes dy_ln; it must not alias its dxT output
+            self.k.scale_cast(dy_ln, w.dh, 1.0)
+            dy_ln = w.dh
+        self.k.layernorm_bwd(dy_ln, bb.x4, bb.mean[4], bb.rstd[4], bp.post["w"], w.partial, dx=w.dxa, dxT=w.dyT,
+                          dxT_scale=0.5, dgamma=bp.post["dw"], dbeta=bp.post["db"], dtype=self.act_dtype)
+        dfeat = torch.empty_like(w.dxa) if not hasattr(w, "dfeat") else w.dfeat
+        w.dfeat = dfeat
+        self._block_bwd(w, ctx["feat"], bp, bb, w.dxa, w.dyT, dfeat)
+        if self.on_stage_grads_ready:
+            self.on_stage_grads_ready(f"head.{lang}")
+        # encoder blocks in reverse
+        dy = dfeat                                   # f32 gradient at the block output (after post_norm)
+        kept = [i for i in range(cfg.n_blocks) if ctx["keep"][i]]
+        for idx in reversed(range(len(kept))):
+            i = kept[idx]
+            bp, bb = self.enc_params[i], w.enc[i]
+            x_in = w.enc[kept[idx - 1]].out if idx > 0 else (w.x0d if (cfg.pos_dropout > 0) else w.x0)
+            self.k.layernorm_bwd(dy, bb.x4, bb.mean[4], bb.rstd[4], bp.post["w"], w.partial, dx=w.dxa, dxT=w.dyT,
+                              dxT_scale=0.5, dgamma=bp.post["dw"], dbeta=bp.post["db"], dtype=self.act_dtype)
+            self._block_bwd(w, x_in, bp, bb, w.dxa, w.dyT, dfeat)
+            dy = dfeat
+            if self.on_stage_grads_ready:
+                self.on_stage_grads_ready(f"enc.{i}")
+        # front end: x0 = sqrt(d) * (r @ Wl^T + b) [dropout]; r = relu(col @ Wc^T + bc)
+        fz = "model.featurizer.sub_sampling"
+        if cfg.pos_dropout > 0:
+            self.k.dropout(dy, w.dxa, cfg.pos_dropout, keep_in=w.pos_keep)
+            dy = w.dxa
+        self.k.scale_cast(dy, w.dyT, math.sqrt(d))
+        nm = cfg.n_mels
+        self._wgrad(w, w.dyT, w.r, self.gview(fz + ".linear.weight"), d, nm)
+        self.k.colsum(w.dyT, self.gview(fz + ".linear.bias"), w.partial)
+        dr = w.dmid.view(-1)[:M * nm].view(M, nm)
+        self.k.gemm_nt(w.dyT, self.wview(fz + ".linear.weight")[1], dr, N=nm, K=d)
+        self.k.relu_bwd(dr, w.r, dr)
+        w.dconv3.zero_()
+        self._wgrad(w, dr, w.col, w.dconv3, nm, 3 * nm)
+        self.gview(fz + ".sub_sampling.0.weight").add_(w.dconv3.view(nm, 3, nm).permute(0, 2, 1))   # layout glue
+        self.k.colsum(dr, self.gview(fz + ".sub_sampling.0.bias"), w.partial)
+        if self.on_stage_grads_ready:
+            self.on_stage_grads_ready("front")
+
+    # ------------------------------------------------------------------ bookkeeping for the optimizer / DDP
+    def active_tensor_ids(self, lang: str, keep: List[bool]) -> List[int]:
+        """Tensors that receive a gradient in a step (everything else has 'grad None')."""
+        ids = []
+        a, b = self.stages["front"]
+        ids += [t for t in range(a, b) if not self.specs[t].name.startswith("model.featurizer.linear.")]
+        for i in range(self.cfg.n_blocks):
+            if keep[i]:
+                a, b = self.stages[f"enc.{i}"]
+                ids += list(range(a, b))
+        a, b = self.stages[f"head.{lang}"]
+        ids += list(range(a, b))
+        return ids
+
+    def stage_range(self, stage: str):
+        a, b = self.stages[stage]
+        lo = self.specs[a].offset
+        hi = self.specs[b - 1].offset + _ceil(self.specs[b - 1].numel, ALIGN)
+        return lo, hi

@@ -107,6 +107,13 @@ def scale_cast(x, out, scale=1.0):
     return out
 
 
+def scale_cast_2d(x, out, M, N, scale=1.0):
+    """out[:M, :N] = scale * x[:M, :N] for row-strided 2-D tensors (pad columns of out untouched)."""
+    check(lib().lidk_scale_cast_2d(_pv(x), x.stride(0), _code(x), _pv(out), out.stride(0), _code(out), M, N, scale,
+                                   _stream()), "scale_cast_2d")
+    return out
+
+
 def dropout(x, out, p, seed=0, keep_in=None, keep_out=None):
     check(lib().lidk_dropout(_p(x), _code(x), _p(out), _code(out), _p(keep_in), _p(keep_out), x.numel(), p, seed,
                              _stream()), "dropout")

