@@ -1,0 +1,422 @@
+"""ccml.Trainer — epoch / step driver behind the reference's API (ccml/trainer.py:19-787 in kouyt5/speech-lid).
+
+Same constructor keywords (the YAML ``trainer:`` block), same ``fit`` / ``test`` signatures, same public attributes and
+callback hooks; the implementation is new and MI355X-first:
+
+* models backed by a lidk ``Engine`` (attribute ``lidk_engine``) train data-parallel WITHOUT torch DDP: the engine reports
+  "gradients of stage X are complete" while backward is still running and the trainer all-reduces that contiguous slice of
+  the flat gradient arena on a side HIP stream (RCCL over xGMI), so communication overlaps the rest of backward; BatchNorm
+  batch statistics are exchanged as two small f64 all-reduces per conv module (SyncBatchNorm semantics, reference
+  trainer.py:428); gradient clipping is folded into the fused optimizer launch.
+* any other ``nn.Module`` follows the generic path (torch DDP when ``ddp=True``), so the framework still drives arbitrary
+  CCMLModules.
+
+Deliberate deviations from the reference, all behavioural no-ops at the shipped settings (accumulate_grad=1):
+  Q9  gradient sync happens on the micro-batch that steps the optimizer (the reference syncs on the first one);
+  Q8  CPU data-parallel (gloo) is allowed (the reference raises) - used by the CPU test-suite;
+  host syncs: running-loss floats are materialised every ``log_interval`` steps instead of twice per step.
+"""
+import contextlib
+import logging
+import os
+import time
+from typing import Any, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader, Dataset, Sampler
+from torch.utils.data.distributed import DistributedSampler
+from tqdm import tqdm
+
+from ccml.loggers.base_logger import BaseLogger
+from ccml.loggers.logger import Logger
+from ccml.utils.profile import _time_cost_recoder, register_cost_statistic
+
+
+class Trainer:
+    def __init__(self, total_epoch: int = 0, world_size: int = 1, local_rank: int = -1, accumulate_grad: int = 1,
+                 eval_interval: int = 1, train_data_factor: float = 1.0, ddp: bool = False, backend: str = "gloo",
+                 init_method: str = "env://", master_addr: str = "localhost", master_port: str = "11488",
+                 use_amp: bool = False, gpu_id: Optional[int] = None, checkpoint_path: str = None,
+                 callbacks: List[Any] = (), resume_train_states: bool = True, loggers: Optional[List[BaseLogger]] = (),
+                 log_interval: int = 1, use_swa: bool = False, swa_config: Tuple[float, float] = (0.1, 0.1),
+                 max_grad_norm: float = 20.0, sync_bn: bool = True) -> None:
+        self.total_epoch, self.eval_interval, self.accumulate_grad = total_epoch, eval_interval, max(1, accumulate_grad)
+        self.world_size, self.local_rank = world_size, local_rank
+        self.use_amp, self.gpu_id, self.train_data_factor, self.ddp = use_amp, gpu_id, train_data_factor, ddp
+        self.resume_train_states, self.checkpoint_path = resume_train_states, checkpoint_path
+        self.use_swa, self.swa_config = use_swa, swa_config
+        self.max_grad_norm, self.sync_bn, self.log_interval = max_grad_norm, sync_bn, max(1, log_interval)
+        if gpu_id is not None and not torch.cuda.is_available():
+            raise RuntimeError(f"gpu_id={gpu_id} but no GPU is visible")
+        self.device = torch.device(f"cuda:{gpu_id}") if gpu_id is not None else torch.device("cpu")
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        if ddp:
+            self._init_process_group(backend, init_method, master_addr, str(master_port))
+            self.local_rank, self.world_size = dist.get_rank(), dist.get_world_size()
+
+        self.train_dataset = self.val_dataset = self.test_dataset = None
+        self.train_dataloader = self.val_dataloader = self.test_dataloader = None
+        self.train_sampler = self.val_sampler = self.test_sampler = None
+        self.train_batch_sampler = self.val_batch_sampler = self.test_batch_sampler = None
+        self.ccml_module = None
+        self.training = False
+        self.tbar = None
+        self.sche_interval = self.sche_monitor = None
+        self.total_steps = 0
+        self.current_epoch = self.current_step = 0
+        self.optimizer = self.lr_scheduler = self.scheduler_param = None
+        self.model = self.swa_model = None
+        self.engine = None                       # lidk Engine of the model, when it has one
+        self.callbacks = list(callbacks)
+        self.dataloader_params = {}
+        self.scalar = torch.amp.GradScaler("cuda", enabled=False)   # bf16 needs no loss scaling; kept for the ckpt key (Q11)
+        self._comm_stream = None
+        self._sync_grads = True
+        self.logger = Logger(rank=self.local_rank, interval=self.log_interval)
+        self.logger.attach_trainer(self)
+        for lg in loggers or ():
+            self.logger.add_logger(lg)
+        for cb in self.callbacks:
+            cb.add_trainer(self)
+
+    # ------------------------------------------------------------------ distributed plumbing
+    def _init_process_group(self, backend, init_method, master_addr, master_port):
+        if dist.is_initialized():
+            return
+        if backend == "nccl" and not torch.cuda.is_available():      # 'nccl' is RCCL on ROCm; without a GPU fall back to gloo
+            logging.warning("no GPU visible: using the gloo backend for data parallelism")
+            backend = "gloo"
+        if init_method == "env://":
+            os.environ.setdefault("MASTER_ADDR", master_addr)
+            os.environ.setdefault("MASTER_PORT", master_port)
+        elif init_method == "tcp://":
+            init_method = f"tcp://{master_addr}:{master_port}"
+        dist.init_process_group(backend=backend, init_method=init_method, world_size=self.world_size, rank=self.local_rank)
+
+    def init_ddp(self, backend="nccl", rank=0, world_size=1, init_method="env://"):
+        dist.init_process_group(backend=backend, world_size=world_size, rank=rank, init_method=init_method)
+
+    def _all_reduce_mean(self, t: torch.Tensor):
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(t)
+            t.div_(self.world_size)
+
+    def _attach_native_dp(self, engine):
+        """Wire the engine's data-parallel hooks: SyncBN sums + per-stage gradient all-reduce."""
+        engine.world_size = self.world_size if self.sync_bn else 1
+        if self.sync_bn:
+            engine.stat_allreduce = lambda t: dist.all_reduce(t)
+        use_side_stream = self.device.type == "cuda"
+        if use_side_stream:
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+
+        def on_ready(stage: str):
+            if not self._sync_grads:
+                return
+            lo, hi = engine.stage_range(stage)
+            buf = engine.grad[lo:hi]
+            if use_side_stream:
+                self._comm_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._comm_stream):
+                    self._all_reduce_mean(buf)
+            else:
+                self._all_reduce_mean(buf)
+
+        engine.on_stage_grads_ready = on_ready
+        dist.broadcast(engine.flat, src=0)                 # DDP ctor semantics: rank 0's parameters and buffers win
+        for b in engine.buffers.values():
+            dist.broadcast(b, src=0)
+        engine.refresh_weights()
+
+    def _wait_comm(self):
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    # ------------------------------------------------------------------ model / data set-up
+    def init_model(self, model: torch.nn.Module = None, ddp: bool = False, gpu: Optional[int] = None, use_swa: bool = False,
+                   swa_w: float = 0.1):
+        if hasattr(model, "set_compute_dtype"):
+            model.set_compute_dtype(torch.bfloat16 if self.use_amp else torch.float32)
+        model = model.to(self.device)
+        self.engine = getattr(model, "lidk_engine", None)
+        swa_model = None
+        if use_swa:
+            swa_model = torch.optim.swa_utils.AveragedModel(
+                model, avg_fn=lambda avg, cur, n: swa_w * avg + (1 - swa_w) * cur)
+        if ddp:
+            if self.engine is not None:
+                self._attach_native_dp(self.engine)
+            else:
+                if self.sync_bn and self.device.type == "cuda":
+                    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+                model = torch.nn.parallel.DistributedDataParallel(
+                    model, device_ids=[self.device.index] if self.device.type == "cuda" else None)
+        return model, swa_model
+
+    def init_dataloader(self, ddp: bool = False, train_batch_size: int = 4, val_batch_size: int = 4, pin_memory: bool = True,
+                        num_workers: int = 0, prefetch_factor: int = 2, train_sampler: Sampler = None,
+                        val_sampler: Sampler = None, test_sampler: Sampler = None, train_batch_sampler: Sampler = None,
+                        val_batch_sampler: Sampler = None, test_batch_sampler: Sampler = None, test_batch_size: int = None,
+                        **_unused):
+        self.train_sampler, self.val_sampler, self.test_sampler = train_sampler, val_sampler, test_sampler
+        self.train_batch_sampler, self.val_batch_sampler = train_batch_sampler, val_batch_sampler
+        self.test_batch_sampler = test_batch_sampler
+        pin = pin_memory and self.device.type == "cuda"
+        extra = dict(num_workers=num_workers, pin_memory=pin)
+        if num_workers > 0:
+            extra["prefetch_factor"] = prefetch_factor
+
+        def build(ds, batch_sampler, sampler, bs, shuffle, drop_last):
+            cf = getattr(ds, "collate_fn", None)
+            if batch_sampler is not None:
+                return DataLoader(ds, batch_sampler=batch_sampler, collate_fn=cf, **extra)
+            return DataLoader(ds, batch_size=bs, sampler=sampler, shuffle=shuffle and sampler is None, drop_last=drop_last,
+                              collate_fn=cf, **extra)
+
+        if self.training:
+            if ddp and train_batch_sampler is None:
+                self.train_sampler = DistributedSampler(self.train_dataset)
+                self.val_sampler = DistributedSampler(self.val_dataset)
+            self.train_dataloader = build(self.train_dataset, train_batch_sampler, self.train_sampler, train_batch_size, True, True)
+            self.val_dataloader = build(self.val_dataset, val_batch_sampler, self.val_sampler, val_batch_size, False, False)
+        if self.test_dataset is not None:
+            self.test_dataloader = build(self.test_dataset, test_batch_sampler, self.test_sampler,
+                                         test_batch_size or val_batch_size, False, False)
+
+    def trainer_prepare(self):
+        if self.ccml_module is None:
+            raise Exception("no CCMLModule given to the trainer")
+        self.model, self.swa_model = self.init_model(self.ccml_module.get_model(), self.ddp, self.gpu_id, self.use_swa,
+                                                     self.swa_config[0])
+        self.training = self.train_dataset is not None and self.val_dataset is not None
+        self.init_dataloader(ddp=self.ddp, **self.dataloader_params)
+        if not self.training:
+            self.resume_train_states = False
+            if self.checkpoint_path is not None:
+                self.model, _, _, _, _, _ = self.resume_from_checkpoint(self.checkpoint_path, False, self.gpu_id, self.model)
+            return
+        self.total_steps = (len(self.train_dataloader) / self.accumulate_grad) * self.total_epoch
+        self.optimizer, self.lr_scheduler, self.scheduler_param = self.ccml_module.config_optim()
+        if self.scheduler_param is not None:
+            self.sche_interval = self.scheduler_param["interval"]
+            self.sche_monitor = self.scheduler_param["monitor"]
+        if self.checkpoint_path is not None:
+            if not os.path.exists(self.checkpoint_path):
+                raise Exception(f"resume failed, checkpoint {self.checkpoint_path} not found")
+            (self.model, self.current_epoch, self.optimizer, self.scalar, self.lr_scheduler,
+             self.logger) = self.resume_from_checkpoint(self.checkpoint_path, self.resume_train_states, self.gpu_id, self.model,
+                                                        self.optimizer, self.scalar, self.lr_scheduler, self.logger)
+        self.current_step = self.current_epoch * int(len(self.train_dataloader) / self.accumulate_grad)
+        self.logger.watch_model(model=self.model)
+
+    # ------------------------------------------------------------------ module pass-throughs (reference names)
+    def train_loop(self, batch=None):
+        return self.ccml_module.train_loop(batch)
+
+    def before_train_loop(self, value):
+        return self.ccml_module.before_train_loop(value)
+
+    def train_loop_end(self, outputs):
+        return self.ccml_module.train_loop_end(outputs)
+
+    def eval_loop(self, batch=None):
+        return self.ccml_module.val_loop(batch)
+
+    def eval_loop_end(self, outputs):
+        return self.ccml_module.val_loop_end(outputs)
+
+    def test_loop(self, batch=None):
+        return self.ccml_module.test_loop(batch)
+
+    def test_loop_end(self, outputs):
+        return self.ccml_module.test_loop_end(outputs)
+
+    # ------------------------------------------------------------------ the data-parallel step
+    def _zero_grad(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.engine is not None:
+            self.engine.zero_grad()
+
+    def _optimizer_step(self):
+        self._wait_comm()
+        if getattr(self.optimizer, "fused_clip", False):
+            self.optimizer.step(max_norm=self.max_grad_norm)           # clip + Novograd + weight refresh, fused
+        else:
+            params = [p for g in self.optimizer.param_groups for p in g["params"]]
+            torch.nn.utils.clip_grad_norm_(params, max_norm=self.max_grad_norm)
+            self.optimizer.step()
+            if self.engine is not None:
+                self.engine.refresh_weights()
+        self._zero_grad()
+
+    def _scheduler_step(self, interval: str, metric=None):
+        if self.lr_scheduler is None or self.sche_interval != interval:
+            return
+        if self.sche_monitor is not None:
+            self.lr_scheduler.step(metric)
+        else:
+            self.lr_scheduler.step()
+
+    def train_step(self, i: int, batch, n_batches: int):
+        """One micro-batch: forward, backward, and (on a stepping micro-batch) clip + optimizer + schedule."""
+        acc = self.accumulate_grad
+        stepping = (i % acc == acc - 1) or (i == n_batches - 1)
+        self._sync_grads = stepping or not self.ddp
+        ctx = contextlib.nullcontext()
+        if self.ddp and not stepping and isinstance(self.model, torch.nn.parallel.DistributedDataParallel):
+            ctx = self.model.no_sync()
+        t0 = time.time()
+        with ctx:
+            batch = self.batch_to_device(batch)
+            out = self.train_loop(batch)
+            loss = out["loss"] / acc
+            loss.backward()
+        _time_cost_recoder.recoder("forward", time.time() - t0)
+        if stepping:
+            t1 = time.time()
+            self._optimizer_step()
+            monitor = out.get(self.sche_monitor) if self.sche_monitor else None
+            self._scheduler_step("step", monitor)
+            self.current_step += 1
+            _time_cost_recoder.recoder("loss.step", time.time() - t1)
+        return out, loss.detach(), stepping
+
+    def fit(self, ccml_module=None, train_dataset: Dataset = None, val_dataset: Dataset = None, test_dataset: Dataset = None,
+            dataloader_params: dict = None):
+        self.ccml_module = ccml_module
+        self.train_dataset = train_dataset if train_dataset is not None else self.train_dataset
+        self.val_dataset = val_dataset if val_dataset is not None else self.val_dataset
+        self.test_dataset = test_dataset if test_dataset is not None else self.test_dataset
+        self.dataloader_params = dict(dataloader_params if dataloader_params is not None else ccml_module.dataloader_param)
+        ccml_module.point_trainer(self)
+        self.trainer_prepare()
+        self._zero_grad()
+        for epoch in range(self.current_epoch, self.total_epoch):
+            self.current_epoch = epoch
+            for s in (self.train_sampler, self.val_sampler, self.train_batch_sampler, self.val_batch_sampler):
+                if s is not None and hasattr(s, "set_epoch"):
+                    s.set_epoch(epoch)
+            self.model.train()
+            results, n = [], len(self.train_dataloader)
+            run_sum = torch.zeros((), device=self.device)
+            acc_sum, acc_cnt = torch.zeros((), device=self.device), 0
+            value = {"avg_accumulate_loss": 0.0, "moving_avg_loss": 0.0}
+            self.exec_callbacks("before_train_epoch", {})
+            self.before_train_loop({})
+            with tqdm(enumerate(self.train_dataloader), total=n, desc="train", disable=self.local_rank > 0) as tbar:
+                self.tbar = tbar
+                last = time.time()
+                for i, batch in tbar:
+                    if i > self.train_data_factor * n:
+                        break
+                    _time_cost_recoder.recoder("get_batch", time.time() - last)
+                    out, loss, stepped = self.train_step(i, batch, n)
+                    results.append(self.detach_dict(out))
+                    run_sum += loss
+                    acc_sum += loss
+                    acc_cnt += 1
+                    if stepped:
+                        if self.current_step % self.log_interval == 0:          # the only host sync of the step
+                            value = {"avg_accumulate_loss": float(acc_sum) / acc_cnt, "moving_avg_loss": float(run_sum) / (i + 1)}
+                        self.exec_callbacks("after_train_loop", value)
+                        acc_sum.zero_()
+                        acc_cnt = 0
+                    last = time.time()
+            if self.use_swa and epoch > self.swa_config[1] * self.total_epoch:
+                self.swa_model.update_parameters(self.model)
+            self.exec_callbacks("after_train_epoch", {})
+            self.train_loop_end(results)
+            if epoch % self.eval_interval != self.eval_interval - 1:
+                continue
+            self._evaluate(epoch)
+        if self.use_swa and self.train_dataloader is not None:
+            self.model.train()
+            with torch.no_grad():
+                for i, batch in enumerate(self.train_dataloader):
+                    if i > self.train_data_factor * len(self.train_dataloader):
+                        break
+                    self.eval_loop(self.batch_to_device(batch))
+            self.exec_callbacks("after_eval_epoch", {"swa": True})
+
+    def _evaluate(self, epoch: int):
+        self.model.eval()
+        results, total, i = [], 0.0, -1
+        n = len(self.val_dataloader)
+        with tqdm(enumerate(self.val_dataloader), total=n, desc="eval", disable=self.local_rank > 0) as tbar:
+            self.tbar = tbar
+            for i, batch in tbar:
+                if i > self.train_data_factor * n:
+                    break
+                with torch.no_grad():
+                    out = self.eval_loop(self.batch_to_device(batch))
+                results.append(self.detach_dict(out))
+                total += float(out["val_loss"].detach())
+        avg = total / max(i + 1, 1)
+        self.exec_callbacks("after_eval_loop", {"moving_avg_loss": avg, "all_val_results": results})
+        self._scheduler_step("epoch", avg)
+        self.eval_loop_end(results)
+        self.exec_callbacks("after_eval_epoch", {"avg_val_loss": avg, "all_val_results": results, "epoch": epoch})
+
+    def test(self, ccml_module, dataset: Dataset, dataloader_params: dict):
+        self.test_dataset, self.ccml_module = dataset, ccml_module
+        self.dataloader_params = dict(dataloader_params or {})
+        ccml_module.point_trainer(self)
+        self.trainer_prepare()
+        self.ccml_module.get_model().eval()
+        results = []
+        with tqdm(enumerate(self.test_dataloader), total=len(self.test_dataloader), desc="test") as tbar:
+            self.tbar = tbar
+            for _, batch in tbar:
+                with torch.no_grad():
+                    results.append(self.detach_dict(self.test_loop(self.batch_to_device(batch))))
+        self.ccml_module.test_loop_end(results)
+        self.exec_callbacks("test_loop_end", {"avg_test_loss": 0.0, "all_test_results": results})
+
+    # ------------------------------------------------------------------ checkpoints
+    def resume_from_checkpoint(self, checkpoint_path: str = None, resume_train_states: bool = True, gpu_id: Optional[int] = None,
+                               model: torch.nn.Module = None, optimizer=None, scalar=None, lr_scheduler=None,
+                               logger: Logger = None):
+        state = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        target = model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state["model"].items()}
+        target.load_state_dict(sd)
+        if not resume_train_states:
+            return model, 0, optimizer, scalar, lr_scheduler, logger
+        optimizer.load_state_dict(state["optimizer"])
+        if scalar is not None and state.get("scalar"):
+            scalar.load_state_dict(state["scalar"])
+        if lr_scheduler is not None and "lr_scheduler" in state:
+            lr_scheduler.load_state_dict(state["lr_scheduler"])
+        if logger is not None:
+            logger.load_state_dict(state.get("logger"))
+        return model, state["epoch"], optimizer, scalar, lr_scheduler, logger
+
+    # ------------------------------------------------------------------ helpers
+    def exec_callbacks(self, stage: str = None, value: Any = None):
+        for cb in self.callbacks:
+            fn = getattr(cb, stage, None)
+            if fn is None:
+                logging.warning("callback %r has no hook %s", cb, stage)
+            else:
+                fn(value)
+
+    def detach_dict(self, data: dict):
+        return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
+
+    @register_cost_statistic(need_return=True)
+    def batch_to_device(self, batch: List[Any]):
+        def move(x):
+            return x.to(self.device, non_blocking=True) if isinstance(x, torch.Tensor) else x
+        batch = list(batch)
+        for i, item in enumerate(batch):
+            if isinstance(item, torch.Tensor):
+                batch[i] = move(item)
+            elif isinstance(item, list):
+                batch[i] = [move(x) for x in item]
+            elif hasattr(item, "to") and not isinstance(item, str):        # e.g. lid.audio_processor.WaveBatch
+                batch[i] = item.to(self.device, non_blocking=True)
+        return batch

@@ -1,0 +1,129 @@
+"""Feature path of the LID pipeline on the GPU — the reference's lid/audio_processor.py surface
+(``normalize_wav``, ``wav_augment`` dither + pre-emphasis, ``wav2mel``, ``spectrogram_augment``) backed by lidk kernels.
+
+In the reference these run per utterance on CPU DataLoader workers (torchaudio).  Here a batch travels to the GPU as raw
+waveforms (``WaveBatch``) and one fused launch sequence produces the ``(B, F, n_mels)`` dB features the model consumes:
+reflect-padded STFT (LDS FFT-512) -> |X|^2 -> mel -> dB -> per-utterance top_db floor -> SpecAugment masks.  SpecAugment
+spans are drawn on the host with torch's generator in torchaudio's draw order, so runs are reproducible from the seed.
+
+Out of scope (CPU-only libsox effects): speed / pitch perturbation, reverb, awgn, the kaldi fbank variant.
+"""
+from typing import List, Optional
+
+import torch
+
+from lidk import ops as _ops
+from lidk._lib import LidkError
+
+
+def frame_geometry(sr: int = 16000, win_length: float = 0.025, hop_length: float = 0.01):
+    return int(sr * win_length), int(sr * hop_length)
+
+
+def num_frames(n_samples: int, pad: int = 0, hop: int = 160) -> int:
+    return 1 + (n_samples + 2 * pad) // hop
+
+
+def normalize_wav(wav: torch.Tensor) -> torch.Tensor:
+    """(x - mean) / (std_unbiased + 1e-6) per utterance; wav (B, L) or (1, L) on the GPU."""
+    return _ops.normalize_wav(wav.contiguous())
+
+
+def wav_augment(wav: torch.Tensor, sr: int, speed_shift: bool = False, pitch_shift: bool = False, reverb: bool = False,
+                seed: int = 0):
+    """Dither (1e-5 * U[0,1)) + pre-emphasis 0.97.  The sox effects of the reference are not available."""
+    if speed_shift or pitch_shift or reverb:
+        raise NotImplementedError("sox speed/pitch/reverb are CPU-only libsox effects outside the lidk hot path")
+    return _ops.dither_preemph(wav.contiguous(), coef=0.97, dither=1e-5, seed=seed), sr
+
+
+def wav2mel(x: torch.Tensor, use_kaildi: bool = False, win_length: float = 0.025, hop_length: float = 0.01,
+            n_mels: int = 80, n_fft: int = 512, pad: int = 0, sr: int = 16000) -> torch.Tensor:
+    """x (1, L) [or (B, L)] f32 on the GPU -> (1, n_mels, F) [or (B, n_mels, F)] dB, as the reference's wav2mel."""
+    if use_kaildi:
+        raise NotImplementedError("kaldi fbank is never enabled by the lid confs (SURVEY 2 #1)")
+    if n_fft != 512:
+        raise NotImplementedError("the lidk STFT kernel is a 512-point FFT")
+    win, hop = frame_geometry(sr, win_length, hop_length)
+    return _ops.logmel(x.contiguous(), pad=pad, hop=hop, win_length=win, n_mels=n_mels).transpose(1, 2)
+
+
+def draw_mask_span(size: int, mask_param: float, gen: Optional[torch.Generator] = None):
+    """torchaudio.functional.mask_along_axis: value = U*param, min = U*(size-value); [floor(min), floor(min)+floor(value))."""
+    value = torch.rand(1, generator=gen) * mask_param
+    min_value = torch.rand(1, generator=gen) * (size - value)
+    start = int(min_value.long())
+    return start, start + int(value.long())
+
+
+def draw_specaug_spans(n_frames: int, n_mels: int = 80, t_mask: float = 0.05, f_mask: float = 27, mask_times: int = 0,
+                       gen: Optional[torch.Generator] = None) -> List[tuple]:
+    """Per repetition: TimeMasking(int(F * t_mask)) then FrequencyMasking(f_mask) (lid/audio_processor.py:225-227)."""
+    spans = []
+    for _ in range(mask_times):
+        t0, t1 = draw_mask_span(n_frames, int(n_frames * t_mask), gen)
+        f0, f1 = draw_mask_span(n_mels, f_mask, gen)
+        spans.append((t0, t1, f0, f1))
+    return spans
+
+
+def spectrogram_augment(spec: torch.Tensor, sr: int = 16000, n_mels: int = 80, hop_length: float = 0.01,
+                        t_mask: float = 0.05, f_mask: float = 27, mask_times: int = 0, t_stretch: bool = False):
+    """spec (1, n_mels, F) -> masked copy (mask value 0.0 dB).  Stand-alone form for callers that hold a finished
+    spectrogram; in training the masks are fused into the log-mel launch through ``WaveBatch.spans``."""
+    if t_stretch:
+        raise NotImplementedError("TimeStretch is never enabled by the lid confs (SURVEY 2 #2)")
+    out = spec.clone()
+    for t0, t1, f0, f1 in draw_specaug_spans(spec.size(-1), spec.size(-2), t_mask, f_mask, mask_times):
+        out[..., :, t0:t1] = 0.0
+        out[..., f0:f1, :] = 0.0
+    return out
+
+
+class WaveBatch:
+    """A batch of equal-length raw utterances plus everything the GPU feature path needs.
+
+    It stands where the reference's collate puts the mel tensor (``batch[0]``): ``Trainer.batch_to_device`` moves it with
+    ``.to(device)`` and the model calls ``to_mel()``.  Utterances shorter than ``wav.shape[1]`` are zero padded and
+    ``n_samples`` holds their true lengths (their trailing frames are then those of the padded signal, as a zero-padded
+    mel from the reference's collate would be close to, but not equal to: variable-length batches are BASELINE config 5,
+    a "next" row)."""
+
+    def __init__(self, wav: torch.Tensor, spans: Optional[torch.Tensor] = None, pad: int = 0, n_mels: int = 80, sr: int = 16000,
+                 normalize: bool = True, preemph: bool = False, dither_seed: int = 0):
+        self.wav, self.spans = wav, spans
+        self.pad, self.n_mels, self.sr = pad, n_mels, sr
+        self.normalize, self.preemph, self.dither_seed = normalize, preemph, dither_seed
+
+    @property
+    def shape(self):
+        B, L = self.wav.shape
+        return (B, num_frames(L, self.pad), self.n_mels)
+
+    @property
+    def device(self):
+        return self.wav.device
+
+    def to(self, device, non_blocking: bool = False):
+        self.wav = self.wav.to(device, non_blocking=non_blocking)
+        if self.spans is not None:
+            self.spans = self.spans.to(device, non_blocking=non_blocking)
+        return self
+
+    def pin_memory(self):
+        self.wav = self.wav.pin_memory()
+        if self.spans is not None:
+            self.spans = self.spans.pin_memory()
+        return self
+
+    def to_mel(self) -> torch.Tensor:
+        """-> (B, F, n_mels) f32 dB on the GPU (the model input)."""
+        if getattr(_ops, "IS_HIP_BACKEND", False) and not self.wav.is_cuda:
+            raise LidkError("WaveBatch.to_mel: the feature path runs on the GPU only (no CPU fallback)")
+        x = self.wav.contiguous()
+        if self.normalize:
+            x = _ops.normalize_wav(x)
+        if self.preemph:
+            x = _ops.dither_preemph(x, coef=0.97, dither=1e-5, seed=self.dither_seed)
+        spans = self.spans.contiguous() if self.spans is not None else None
+        return _ops.logmel(x, pad=self.pad, n_mels=self.n_mels, spans=spans)

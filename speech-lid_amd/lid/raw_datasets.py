@@ -1,0 +1,278 @@
+"""Datasets, collate and samplers for the LID pipeline — the reference's lid/raw_datasets.py surface
+(``RawDataset``, ``MergedDataset``, ``RandomSamplerWithBase``, ``MutiBatchSampler``) plus a synthetic source.
+
+Difference that matters: ``collate_fn`` does NOT compute features on CPU workers.  With ``type: mel`` it returns a
+``WaveBatch`` (raw waveforms + host-drawn SpecAugment spans) in the slot where the reference puts the mel tensor; the
+log-mel / SpecAugment kernels run on the GPU when the model consumes it.  The six-tuple layout is unchanged:
+``(wavs, texts (B,Lmax) int64, wav_percents (B,), text_percents (B,), audio_paths list[str], langs (B,) int64)``.
+"""
+import csv
+import logging
+import math
+import os
+import random
+import wave
+from typing import Any, Dict, Iterator, List, Optional
+
+import numpy as np
+import torch
+from torch.nn.utils.rnn import pad_sequence
+from torch.utils.data import Dataset, Sampler
+
+from lid.audio_processor import WaveBatch, draw_specaug_spans, num_frames
+
+
+# ------------------------------------------------------------------------------------------------ audio I/O (host side)
+def read_audio(audio_path: str, normalize: bool = True):
+    """-> (wav (1, L) f32 on the host, sample_rate).  Reads .npy arrays and PCM .wav files (stdlib ``wave``); compressed
+    formats need torchaudio/soundfile, which this image lacks.  Normalisation happens on the GPU (WaveBatch.normalize)."""
+    if audio_path.endswith(".npy"):
+        wav, sr = torch.from_numpy(np.load(audio_path).astype(np.float32)).reshape(1, -1), 16000
+    else:
+        with wave.open(audio_path, "rb") as f:
+            sr, n, width, ch = f.getframerate(), f.getnframes(), f.getsampwidth(), f.getnchannels()
+            raw = f.readframes(n)
+        if width != 2:
+            raise ValueError(f"{audio_path}: only 16-bit PCM wav is supported")
+        wav = torch.from_numpy(np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0).reshape(-1, ch).mean(1)[None]
+    return wav, sr
+
+
+def audio_duration(path: str) -> float:
+    if path.endswith(".npy"):
+        return np.load(path, mmap_mode="r").shape[-1] / 16000.0
+    with wave.open(path, "rb") as f:
+        return f.getnframes() / f.getframerate()
+
+
+class RawDataset(Dataset):
+    """One language's manifest: common-voice TSV (``clips/`` beside it) or xf ``.label`` (``wav/train/`` beside it)."""
+
+    def __init__(self, manifest_path: str, max_duration=16.7, train=False, source: str = "common_voice") -> None:
+        self.train = train
+        rows = self._read_cv(manifest_path) if source == "common_voice" else self._read_xf(manifest_path)
+        self.datasets = [r for r in rows if max_duration <= 0 or r["duration"] <= max_duration]
+        logging.info("%s: %d utterances kept of %d", manifest_path, len(self.datasets), len(rows))
+
+    @staticmethod
+    def _read_cv(manifest_path):
+        base = os.path.join(os.path.dirname(manifest_path), "clips")
+        out = []
+        with open(manifest_path, encoding="utf-8") as f:
+            for row in csv.DictReader(f, delimiter="\t"):
+                path = os.path.join(base, row["path"])
+                out.append({"path": path, "locale": row["locale"], "sentence": row["sentence"], "duration": audio_duration(path)})
+        return out
+
+    @staticmethod
+    def _read_xf(manifest_path):
+        lang = os.path.basename(os.path.dirname(manifest_path))
+        base = os.path.join(os.path.dirname(manifest_path), "wav", "train")
+        out = []
+        with open(manifest_path) as f:
+            for line in f:
+                name, text = line.rstrip("\n").split("\t")[:2]
+                path = os.path.join(base, name)
+                out.append({"path": path, "locale": lang, "sentence": text.strip(), "duration": audio_duration(path)})
+        return out
+
+    def __getitem__(self, index):
+        return self.datasets[index]
+
+    def __len__(self):
+        return len(self.datasets)
+
+    def lang(self):
+        return self.datasets[0]["locale"]
+
+    def export_vocab(self):
+        return sorted({c for item in self.datasets for c in item["sentence"]})
+
+
+# ------------------------------------------------------------------------------------------------ samplers
+class RandomSamplerWithBase(Sampler[int]):
+    """Random permutation of one language's items, offset into the merged index space."""
+
+    def __init__(self, data_source, generator=None) -> None:
+        self.data_source, self.generator, self.base_value = data_source, generator, 0
+
+    @property
+    def num_samples(self) -> int:
+        return len(self.data_source)
+
+    def set_base_value(self, value: int):
+        self.base_value = value
+
+    def __iter__(self) -> Iterator[int]:
+        g = self.generator
+        if g is None:
+            g = torch.Generator()
+            g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+        yield from (i + self.base_value for i in torch.randperm(len(self.data_source), generator=g).tolist())
+
+    def __len__(self) -> int:
+        return self.num_samples
+
+
+class MutiBatchSampler(Sampler[List[int]]):
+    """Single-language batches, languages picked in proportion to their remaining size (reference:
+    lid/raw_datasets.py:374-440; a batch never mixes languages because one head is trained per step).
+
+    Data parallel: with ``world_size > 1`` every rank runs the SAME seeded draw of a global batch of
+    ``batch_size * world_size`` indices from one language and keeps its contiguous ``batch_size`` slice, so all ranks train
+    the same head on disjoint utterances.  ``set_epoch`` reseeds the draw."""
+
+    def __init__(self, samplers: List[Sampler[int]], batch_size: int, drop_last: bool, rank: int = 0, world_size: int = 1,
+                 seed: Optional[int] = None) -> None:
+        self.samplers, self.batch_size, self.drop_last = samplers, batch_size, drop_last
+        self.rank, self.world_size, self.seed, self.epoch = rank, world_size, seed, 0
+        self.weight = [len(s) for s in samplers]
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def __iter__(self) -> Iterator[List[int]]:
+        gb = self.batch_size * self.world_size
+        rng = random.Random((self.seed, self.epoch).__hash__()) if (self.seed is not None or self.world_size > 1) else random
+        if self.world_size > 1 or self.seed is not None:
+            for k, s in enumerate(self.samplers):                           # identical permutations on every rank
+                s.generator = torch.Generator().manual_seed(((self.seed or 0) * 1000003 + self.epoch * 1009 + k) % (2 ** 31))
+        iters = [iter(s) for s in self.samplers]
+        remain = [len(s) for s in self.samplers]
+        while sum(remain) > 0:
+            area = rng.randint(0, sum(remain) - 1)
+            idx = 0
+            while area >= remain[idx]:
+                area -= remain[idx]
+                idx += 1
+            take = min(gb, remain[idx])
+            batch = [next(iters[idx]) for _ in range(take)]
+            remain[idx] -= take
+            if take == gb:
+                yield batch[self.rank * self.batch_size:(self.rank + 1) * self.batch_size]
+            elif not self.drop_last:
+                per = math.ceil(take / self.world_size)
+                mine = batch[self.rank * per:(self.rank + 1) * per]
+                yield mine if mine else batch[:1]
+
+    def __len__(self) -> int:
+        gb = self.batch_size * self.world_size
+        if self.drop_last:
+            return sum(len(s) // gb for s in self.samplers)
+        return sum((len(s) + gb - 1) // gb for s in self.samplers)
+
+
+# ------------------------------------------------------------------------------------------------ datasets
+class _FeatureCfg:
+    def __init__(self, type="wav", speed_shift=True, pitch_shift=True, reverb=True, use_kaildi=False, win_length=0.025,
+                 hop_length=0.01, n_mels=80, n_fft=512, pad=0, sr=16000, t_mask=0.05, f_mask=27, mask_times=2, t_stretch=False,
+                 **_ignored):
+        self.type, self.pad, self.sr, self.n_mels = type, pad, sr, n_mels
+        self.t_mask, self.f_mask, self.mask_times = t_mask, f_mask, mask_times
+        if speed_shift or pitch_shift or reverb:
+            logging.warning("speed/pitch/reverb perturbation are libsox CPU effects outside the lidk path: disabled")
+
+
+class _CollateMixin:
+    def collate_fn(self, batch):
+        """batch: list of (wav (L,) or (1,L), encoded text, path, lang)."""
+        fc = self.feat
+        wavs = [b[0].reshape(-1) for b in batch]
+        lens = [w.shape[0] for w in wavs]
+        texts = pad_sequence([b[1] for b in batch]).transpose(1, 0)
+        langs = torch.LongTensor([self.lang2index_dict[b[3]] for b in batch])
+        text_pct = torch.FloatTensor([b[1].shape[-1] / (texts.shape[1] + 1e-9) for b in batch])
+        if fc.type != "mel":
+            wav_pct = torch.FloatTensor([n / max(lens) for n in lens])
+            return wavs, texts, wav_pct, text_pct, [b[2] for b in batch], langs
+        wav = pad_sequence(wavs, batch_first=True)
+        frames = [num_frames(n, fc.pad) for n in lens]
+        wav_pct = torch.FloatTensor([f / max(frames) for f in frames])
+        spans = None
+        if self.train and fc.mask_times > 0:
+            spans = torch.tensor([draw_specaug_spans(f, fc.n_mels, fc.t_mask, fc.f_mask, fc.mask_times) for f in frames],
+                                 dtype=torch.int32)
+        wb = WaveBatch(wav, spans, pad=fc.pad, n_mels=fc.n_mels, sr=fc.sr, normalize=True, preemph=self.train,
+                       dither_seed=random.getrandbits(31) if self.train else 0)
+        wb.lang_id = int(langs[0])
+        return wb, texts, wav_pct, text_pct, [b[2] for b in batch], langs
+
+
+class MergedDataset(_CollateMixin, Dataset):
+    """File-based multi-language dataset (reference: lid/raw_datasets.py:187-365)."""
+
+    def __init__(self, train: bool = False, manifest_files: List[str] = None, lang2index_dict: dict = None,
+                 lang2tokenizer: Dict = None, max_duration: float = 16.7, source: str = "common_voice", **feature) -> None:
+        self.train, self.lang2index_dict, self.lang2tokenizer = train, lang2index_dict, lang2tokenizer
+        self.feat = _FeatureCfg(**feature)
+        self.type = self.feat.type
+        self.datasets, self.samplers = [], []
+        for manifest in manifest_files:
+            ds = RawDataset(manifest_path=manifest, train=train, max_duration=max_duration, source=source)
+            sampler = RandomSamplerWithBase(data_source=ds)
+            sampler.set_base_value(len(self.datasets))
+            self.samplers.append(sampler)
+            self.datasets.extend(ds.datasets)
+
+    def __len__(self):
+        return len(self.datasets)
+
+    def __getitem__(self, index):
+        item = self.datasets[index]
+        wav, _ = read_audio(item["path"], normalize=False)
+        text = self.lang2tokenizer[item["locale"]].encoder(item["sentence"]) if self.lang2tokenizer else torch.LongTensor([0])
+        return wav, text, item["path"], item["locale"]
+
+    def export_dict(self):
+        return {s.data_source.lang(): s.data_source.export_vocab() for s in self.samplers}
+
+
+class _SynthLang:
+    def __init__(self, lang, n):
+        self._lang, self._n = lang, n
+
+    def __len__(self):
+        return self._n
+
+    def lang(self):
+        return self._lang
+
+
+class SyntheticMergedDataset(_CollateMixin, Dataset):
+    """Synthetic LID data: language k is white noise through a 2-pole resonator at f_k = 300 + 500 k Hz
+    (radius 0.97), so each language has a distinct spectral signature; transcripts are ``text_len`` uniform tokens.
+    Item i is a pure function of (seed, i): every rank and every epoch sees the same corpus."""
+
+    def __init__(self, train: bool, langs: Dict[str, int], lang2vocab: Dict[str, int], items_per_lang: int = 64,
+                 seconds: float = 3.0, text_len: int = 20, seed: int = 1234, lang2tokenizer: Dict = None, **feature):
+        self.train, self.lang2index_dict, self.lang2vocab = train, dict(langs), dict(lang2vocab)
+        self.feat = _FeatureCfg(**{"speed_shift": False, "pitch_shift": False, "reverb": False, **feature})
+        self.type = self.feat.type
+        self.n_samples, self.text_len, self.seed = int(seconds * self.feat.sr), text_len, seed
+        self.lang2tokenizer = lang2tokenizer
+        self.datasets, self.samplers = [], []
+        for lang in langs:
+            s = RandomSamplerWithBase(_SynthLang(lang, items_per_lang))
+            s.set_base_value(len(self.datasets))
+            self.samplers.append(s)
+            self.datasets += [{"locale": lang, "path": f"synthetic://{lang}/{i}"} for i in range(items_per_lang)]
+
+    def __len__(self):
+        return len(self.datasets)
+
+    def waveform(self, index: int) -> torch.Tensor:
+        from scipy.signal import lfilter
+        lang = self.datasets[index]["locale"]
+        k = self.lang2index_dict[lang]
+        g = torch.Generator().manual_seed((self.seed * 7919 + index) % (2 ** 31))
+        x = 0.1 * torch.randn(self.n_samples, generator=g)
+        f0, r = 300.0 + 500.0 * k, 0.97
+        w = 2 * math.pi * f0 / self.feat.sr
+        y = lfilter([1.0], [1.0, -2 * r * math.cos(w), r * r], x.numpy().astype(np.float64))
+        return torch.from_numpy(y.astype(np.float32))
+
+    def __getitem__(self, index):
+        item = self.datasets[index]
+        g = torch.Generator().manual_seed((self.seed * 104729 + index + 4321) % (2 ** 31))
+        text = torch.randint(0, self.lang2vocab[item["locale"]], (self.text_len,), generator=g)
+        return self.waveform(index), text, item["path"], item["locale"]

@@ -136,6 +136,7 @@ class Engine:
         # kernel backend: the real lidk.ops (HIP; refuses CPU tensors).  tests/ may inject a torch-CPU fake to check
         # the orchestration on a GPU-less machine; nothing in the product constructs an Engine with another backend.
         self.k = backend if backend is not None else ops
+        self._hip = bool(getattr(self.k, "IS_HIP_BACKEND", False))
         self.device = torch.device("cpu")
         self.specs, self.buffer_specs, self.stages, self.n_flat = model_specs(cfg)
         self.by_name: Dict[str, Spec] = {s.name: s for s in self.specs}
@@ -169,7 +170,7 @@ class Engine:
 
     def to(self, device):
         device = torch.device(device)
-        if device.type == "cpu" and not self._built and self.k is ops:
+        if device.type == "cpu" and not self._built and self._hip:
             return self                      # still on the host before the first move to a GPU: nothing to build
         self.device = device
         self.flat = self.flat.to(device)
@@ -351,7 +352,7 @@ class Engine:
             raise LidkError("Engine.forward before Engine.to('cuda')")
         if mel.dtype != torch.float32:
             raise LidkError(f"Engine.forward needs float32 features, got {mel.dtype}")
-        if self.k is ops and not mel.is_cuda:
+        if self._hip and not mel.is_cuda:
             raise LidkError(f"Engine.forward got a tensor on {mel.device}: the HIP path has no CPU fallback")
         mel = mel.contiguous()
         B, F_, nm = mel.shape

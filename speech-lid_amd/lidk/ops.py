@@ -12,6 +12,9 @@ from . import _lib as L
 from ._lib import LidkError, check, dtype_code, lib
 
 
+IS_HIP_BACKEND = True      # marks the real kernel backend (the engine refuses CPU tensors when this is set)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 

@@ -137,9 +137,10 @@ def attn_fwd(qkv, rel_emb, out, probs, B, T, heads, dh):
     probs.copy_(p.to(probs.dtype))
 
 
+@torch.enable_grad()
 def attn_bwd(qkv, rel_emb, probs, dout, dqkv, drel_emb, dscores, B, T, heads, dh):
-    q = _f(qkv).clone().requires_grad_()
-    e = rel_emb.clone().requires_grad_()
+    q = _f(qkv).detach().clone().requires_grad_()
+    e = rel_emb.detach().clone().requires_grad_()
     o, _ = _attn(q, e, B, T, heads, dh)
     o.backward(_f(dout))
     dqkv.copy_(q.grad.to(dqkv.dtype))
@@ -180,12 +181,14 @@ def dwconv_fwd(g, w, bias, c, stat_partial, B, T, pad_left):
         stat_partial[C:2 * C] = (y * y).sum(0)
 
 
+@torch.enable_grad()
 def dwconv_bwd_input(dc, w, dg, B, T, pad_left):
     x = torch.zeros(B * T, w.shape[0], requires_grad=True)
     _dw(x, w, None, B, T, pad_left).backward(_f(dc).view(B * T, -1))
     dg.view(B * T, -1).copy_(x.grad.to(dg.dtype))
 
 
+@torch.enable_grad()
 def dwconv_bwd_weight(dc, g, dw, db, partial, B, T, pad_left):
     w = torch.zeros_like(dw).requires_grad_()
     b = torch.zeros(dw.shape[0], requires_grad=True)
@@ -267,8 +270,9 @@ def ctc_workspace_bytes(B, T, V1, Lmax):
     return 4
 
 
+@torch.enable_grad()
 def ctc_loss(logits, targets, in_len, tg_len, loss, dlogits, workspace, blank, grad_scale=1.0, zero_infinity=True):
-    lg = logits.clone().requires_grad_()
+    lg = logits.detach().clone().requires_grad_()
     per = F.ctc_loss(torch.log_softmax(lg, -1).transpose(0, 1), targets, in_len, tg_len, blank=blank, reduction="none",
                      zero_infinity=zero_infinity)
     loss.copy_(per.detach())
@@ -302,3 +306,24 @@ def novograd_step(params, grads, exp_avg, exp_avg_sq, work, n_tensors, lr, betas
             g = g * (1 - betas[0])
         exp_avg[a:b] = betas[0] * exp_avg[a:b] + g
         params[a:b] -= lr * exp_avg[a:b]
+
+
+# ------------------------------------------------------------------------------------------------ feature path (via the oracle)
+def normalize_wav(wav, out=None):
+    from oracle import features as of
+    return of.normalize_wav(wav)
+
+
+def dither_preemph(wav, coef=0.97, dither=1e-5, seed=0, noise=None, out=None):
+    from oracle import features as of
+    if noise is None and dither:
+        noise = torch.rand(wav.shape, generator=torch.Generator().manual_seed(int(seed) % (2 ** 31)))
+    return of.dither_preemphasis(wav, noise if dither else None, coef)
+
+
+def logmel(wav, pad=0, hop=160, win_length=400, n_mels=80, spans=None, top_db=80.0, out=None):
+    from oracle import features as of
+    mel = of.wav2mel(wav, n_mels=n_mels, pad=pad)                       # (B, n_mels, F)
+    if spans is not None:
+        mel = torch.stack([of.apply_specaug(mel[i], [tuple(s) for s in spans[i].tolist()]) for i in range(mel.shape[0])])
+    return mel.transpose(1, 2).contiguous()

@@ -1,0 +1,158 @@
+"""End-to-end parity on the GPU: HIP engine vs vectors captured from the reference (tests/golden/) and vs the oracle.
+
+f32 mode is the algorithm check (tolerance 2e-4 on logits of magnitude ~1-3, gradients to 1e-3 relative); bf16 mode is the
+production mode: logits within 6e-2 absolute (bf16 has 8 significant bits and the path is ~40 GEMMs deep), loss within
+2 %, per-tensor gradient direction cosine >= 0.99.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz
+from lidk import ops
+from lidk.engine import Engine
+from lidk.layout import ConformerCfg
+from oracle import conformer as oc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_cfg(**kw):
+    base = dict(lang2vocab={"a": 30, "b": 40, "c": 50}, lang2index={"a": 0, "b": 1, "c": 2}, n_blocks=2, encoder_dim=64,
+                dim_head=16, heads=4, last_dim_head=8, dropout=0.1, hidden_dim=32)
+    base.update(kw)
+    return ConformerCfg(**base)
+
+
+def make_engine(cfg, weights, dt):
+    eng = Engine(cfg, act_dtype=dt)
+    eng.to(DEV)
+    eng.load_state({k: v.to(DEV) for k, v in weights.items()})
+    return eng
+
+
+def gpu_ctc(out, g, blank=40):
+    B, T, V1 = out.shape
+    texts = torch.from_numpy(g["texts"]).to(DEV)
+    in_len = (T * torch.from_numpy(g["wav_pct"]).to(DEV)).long()
+    tg_len = (texts.shape[-1] * torch.from_numpy(g["text_pct"]).to(DEV)).long()
+    loss = torch.empty(B, device=DEV)
+    dl = torch.empty(B, T, V1, device=DEV)
+    ws = torch.empty(ops.ctc_workspace_bytes(B, T, V1, texts.shape[1]) // 4 + 1, device=DEV)
+    ops.ctc_loss(out.contiguous(), texts, in_len, tg_len, loss, dl, ws, blank, grad_scale=1.0 / B)
+    return float(loss.mean()), dl
+
+
+TOL = {torch.float32: dict(logit=2e-4, loss=1e-4, grel=2e-3, cos=0.99999), torch.bfloat16: dict(logit=6e-2, loss=2e-2, grel=None, cos=0.99)}
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_eval_forward_and_lid_scores(cfg1_weights, cfg1_cfg, dt):
+    g = load_npz("cfg1_eval.npz")
+    eng = make_engine(make_cfg(), cfg1_weights, dt)
+    mel = torch.from_numpy(g["mel"]).to(DEV)
+    out = eng.forward(mel, None, training=False)
+    worst = 0.0
+    for lang in "abc":
+        err = float((out[lang].cpu() - torch.from_numpy(g[f"logits_{lang}"])).abs().max())
+        worst = max(worst, err)
+    print(f"[eval logits {dt}] max_abs_err={worst:.3e}")
+    assert worst <= TOL[dt]["logit"]
+    scores = torch.zeros(4, 3, device=DEV)
+    for lang, v in cfg1_cfg.lang2vocab.items():
+        ops.lid_score(out[lang].contiguous(), scores[:, cfg1_cfg.lang2index[lang]:], 3, v)
+    ref = torch.from_numpy(g["lid_asr"])
+    print(f"[lid_asr {dt}] max_abs_err={float((scores.cpu() - ref).abs().max()):.3e} margin={float((ref.sort(-1).values[:, -1] - ref.sort(-1).values[:, -2]).min()):.3e}")
+    assert float((scores.cpu() - ref).abs().max()) <= (1e-5 if dt == torch.float32 else 5e-3)
+    if dt == torch.float32:
+        assert torch.equal(scores.argmax(-1).cpu(), ref.argmax(-1))          # argmax language labels exact
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_train_step_A_loss_and_all_gradients(cfg1_weights, dt):
+    g = load_npz("cfg1_trainA.npz")
+    mel = torch.from_numpy(load_npz("cfg1_eval.npz")["mel"]).to(DEV)
+    eng = make_engine(make_cfg(dropout=0.0, pos_dropout=0.0), cfg1_weights, dt)
+    eng.zero_grad()
+    out = eng.forward(mel, "b", training=True, keep_layers=[True, True])
+    err = float((out["b"].cpu() - torch.from_numpy(g["logits_b"])).abs().max())
+    print(f"[trainA logits {dt}] max_abs_err={err:.3e}")
+    assert err <= TOL[dt]["logit"]
+    loss, dl = gpu_ctc(out["b"], g)
+    print(f"[trainA loss {dt}] got={loss:.6f} ref={float(g['loss']):.6f}")
+    assert abs(loss - float(g["loss"])) <= TOL[dt]["loss"] * abs(float(g["loss"]))
+    eng.backward(dl)
+    torch.cuda.synchronize()
+    worst_cos, worst_rel, bad = 1.0, 0.0, []
+    for k in g:
+        if not k.startswith("grad::"):
+            continue
+        name, ref = k[6:], torch.from_numpy(g[k]).reshape(-1).double()
+        got = eng.gview(name).cpu().reshape(-1).double()
+        nr = float(ref.norm())
+        if nr < 1e-4:                                  # exact-zero gradients in exact arithmetic (bias before BatchNorm):
+            print(f"[zero-grad {name} {dt}] |got|={float(got.norm()):.3e}")      # what is left is rounding noise of dc
+            assert float(got.norm()) < (1e-3 if dt == torch.float32 else 0.25), name
+            continue
+        cos = float((got @ ref) / (got.norm() * ref.norm() + 1e-30))
+        rel = float((got - ref).norm() / nr)
+        worst_cos, worst_rel = min(worst_cos, cos), max(worst_rel, rel)
+        if cos < TOL[dt]["cos"] or (TOL[dt]["grel"] and rel > TOL[dt]["grel"]):
+            bad.append((name, cos, rel))
+    print(f"[trainA grads {dt}] worst_cos={worst_cos:.6f} worst_rel_l2={worst_rel:.3e}")
+    assert not bad, bad[:8]
+    ref_names = {k[6:] for k in g if k.startswith("grad::")}
+    for s in eng.specs:
+        if s.name not in ref_names:
+            assert float(eng.gview(s.name).abs().max()) == 0.0, s.name
+    if dt == torch.float32:
+        for k in g:
+            if k.startswith("bn::"):
+                np.testing.assert_allclose(eng.buffers[k[4:]].cpu().numpy(), g[k], atol=2e-5, rtol=2e-5, err_msg=k)
+
+
+def test_train_step_B_masks_and_skipped_layer_f32(cfg1_weights):
+    g = load_npz("cfg1_trainB.npz")
+    gA = load_npz("cfg1_trainA.npz")
+    mel = torch.from_numpy(load_npz("cfg1_eval.npz")["mel"]).to(DEV)
+    eng = make_engine(make_cfg(), cfg1_weights, torch.float32)
+    eng.zero_grad()
+    masks = {"pos": torch.from_numpy(g["pos_mask"]).reshape(-1).to(torch.uint8).to(DEV),
+             "head": torch.from_numpy(g["head_mask"]).reshape(-1).to(torch.uint8).to(DEV)}
+    out = eng.forward(mel, "b", training=True, keep_layers=list(g["keep"]), masks=masks)
+    assert float((out["b"].cpu() - torch.from_numpy(g["logits_b"])).abs().max()) <= 2e-4
+    loss, dl = gpu_ctc(out["b"], gA)
+    assert abs(loss - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    eng.backward(dl)
+    for n, ref in zip(g["grad_names"], g["grad_norms"]):
+        np.testing.assert_allclose(float(eng.gview(str(n)).norm()), ref, rtol=2e-3, atol=2e-5, err_msg=str(n))
+    assert float(eng.grad[slice(*eng.stage_range("enc.1"))].abs().max()) == 0.0
+
+
+def test_own_dropout_masks_are_consistent_between_fwd_and_bwd():
+    """With the kernel's own counter-based masks: export them, feed them to the oracle, compare logits and one gradient."""
+    torch.manual_seed(3)
+    cfg = make_cfg()
+    eng = Engine(cfg, act_dtype=torch.float32)
+    eng.to(DEV)
+    sd = {k: v.cpu().clone() for k, v in eng.state().items()}
+    mel = (20 * torch.randn(3, 61, 80) - 30)
+    eng.zero_grad()
+    out = eng.forward(mel.to(DEV), "a", training=True, keep_layers=[True, True])
+    w = eng.work(3, 61)
+    pos = w.pos_keep.cpu().view(3, w.T, 64).bool()
+    head = w.head_keep.cpu().view(3, w.T, 64).bool()
+    assert 0.85 < pos.float().mean() < 0.95 and 0.85 < head.float().mean() < 0.95
+    ocfg = oc.ModelCfg(lang2vocab=cfg.lang2vocab, lang2index=cfg.lang2index, n_blocks=2, encoder_dim=64, dim_head=16,
+                       heads=4, last_dim_head=8, dropout=0.1)
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in sd.items()}
+    ref, _ = oc.forward(mel, sdr, ocfg, "a", oc.RunOpts(training=True, keep_layers=[True, True], pos_keep_mask=pos,
+                                                        head_keep_mask=head))
+    assert float((out["a"].cpu() - ref["a"].detach()).abs().max()) <= 3e-4
+    dl = torch.randn(3, w.T, 31) * 0.01
+    ref["a"].backward(dl)
+    eng.backward(dl.to(DEV))
+    n = "model.featurizer.sub_sampling.linear.weight"
+    got, want = eng.gview(n).cpu(), sdr[n].grad
+    assert float((got - want).norm() / want.norm()) < 2e-3
