@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Conformer-LID training throughput in audio-seconds/sec (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the whole hot path over one batch of synthetic input already resident in HBM:
+raw 3 s @ 16 kHz waveforms -> normalize + dither/pre-emphasis -> log-mel + SpecAugment (HIP) -> 12-layer d256 Conformer +
+one 14-language CTC head, forward and backward (HIP, bf16 MFMA GEMMs) -> [N>1: gradient all-reduce over RCCL, SyncBN
+statistics] -> global-norm clip(20) + Novograd + bf16 weight refresh (HIP) -> TriStage LR step.  Batch 64 per GPU (weak
+scaling), BASELINE.json configs[1]; nothing is skipped or cached between steps.  Stochastic depth is OFF in the headline
+number (every layer runs every step, matching the 21.67 GFLOP/utterance accounting of SURVEY 8d); pass
+--stochastic-depth to time the reference default (p=0.7, ~16 % fewer executed blocks on average).
+
+Prints ONE JSON line (rank 0) with the contract's fields plus:
+  roofline     : the MFMA GEMM kernel (gemm_nt_bf16_kernel, both tile shapes): algorithmic 2*M*N*K FLOPs of every launch of
+                 one training step / their summed durations, each launch bracketed by HIP events on its own stream
+  cpu_baseline : the CPU oracle (oracle/, torch fp32) running the same step on this host's cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "speech-lid_amd")]
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+SECONDS = 3.0
+BATCH = 64
+N_LANGS = 14
+
+
+def build(args, rank, world, device):
+    from ccml import seed_everything
+    from ccml.trainer import Trainer
+    from lid import hydra_lite
+    import lid.main as launcher
+    seed_everything(0)
+    ov = [f"trainer.gpu_id={device.index}", "trainer.use_amp=true", f"trainer.ddp={'true' if world > 1 else 'false'}",
+          f"trainer.world_size={world}", f"trainer.local_rank={rank}", "trainer.backend=nccl", "trainer.total_epoch=1000",
+          f"data.sampler_common.train_batch_size={args.batch}", f"data.synthetic.items_per_lang={max(args.batch * world, 8)}",
+          "data.synthetic.val_items_per_lang=2", "data.synthetic.test_items_per_lang=2", "module.interval=1000000",
+          "trainer.log_interval=1000000", f"model.n_blocks={args.blocks}"]
+    cfg = hydra_lite.load_config(os.path.join(ROOT, "speech-lid_amd", "lid", "conf"), "synthetic_cfg2", ov)
+    module, sets, params = launcher.build(cfg, rank, world)
+    module.model.use_stochastic_depth = bool(args.stochastic_depth)
+    trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
+    trainer.ccml_module = module
+    trainer.train_dataset, trainer.val_dataset, trainer.test_dataset = sets["train"], sets["val"], sets["test"]
+    trainer.dataloader_params = params
+    module.point_trainer(trainer)
+    trainer.trainer_prepare()
+    trainer._zero_grad()
+    return cfg, module, trainer, sets["train"]
+
+
+def resident_batches(ds, rank, world, device, batch):
+    """One batch per language, built once and moved to HBM (each rank gets different utterances of the same language)."""
+    out = []
+    per_lang = len(ds) // N_LANGS
+    for k in range(N_LANGS):
+        base = k * per_lang
+        idx = [base + (rank * batch + j) % per_lang for j in range(batch)]
+        b = list(ds.collate_fn([ds[i] for i in idx]))
+        b[0] = b[0].to(device)
+        for j in (1, 2, 3, 5):
+            b[j] = b[j].to(device)
+        out.append(b)
+    return out
+
+
+def cpu_baseline(module, ds, steps, batch, threads):
+    """The oracle (torch-CPU fp32 restatement, pinned to the reference) running the same training step on host cores."""
+    import random
+    from oracle import conformer as oc
+    from oracle import features as of
+    from oracle import optim as oo
+    torch.set_num_threads(threads)
+    cfg = module.model.cfg
+    ocfg = oc.ModelCfg(lang2vocab=cfg.lang2vocab, lang2index=cfg.lang2index, n_blocks=cfg.n_blocks, encoder_dim=cfg.d,
+                       dim_head=cfg.dim_head, heads=cfg.heads, last_dim_head=cfg.last_dim_head, dropout=cfg.dropout)
+    sd = {k: v.detach().cpu().clone() for k, v in module.model.state_dict().items()}
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running_" not in k]
+    states = {k: oo.NovogradState() for k in names}
+    per_lang = len(ds) // N_LANGS
+    times = []
+    for step in range(steps + 1):
+        k = step % N_LANGS
+        lang = list(cfg.lang2vocab)[k]
+        items = [ds[k * per_lang + j % per_lang] for j in range(batch)]
+        t0 = time.time()
+        wav = of.normalize_wav(torch.stack([it[0] for it in items]))
+        wav = of.dither_preemphasis(wav, torch.rand_like(wav))
+        mel = of.wav2mel(wav, pad=16)
+        mel = torch.stack([of.apply_specaug(m, of.draw_specaug_spans(m.shape[-1], 80, 0.05, 12, 1)) for m in mel])
+        feats = mel.transpose(1, 2).contiguous()
+        p = {n: sd[n].requires_grad_(True) for n in names}
+        full = {**sd, **p}
+        opts = oc.RunOpts(training=True, keep_layers=[True] * cfg.n_blocks)
+        out, _ = oc.forward(feats, full, ocfg, lang, opts)
+        texts = torch.stack([it[1] for it in items])
+        loss = oc.ctc_loss(out[lang], texts, torch.ones(batch), torch.ones(batch), blank=cfg.lang2vocab[lang])
+        loss.backward()
+        with torch.no_grad():
+            act = [n for n in names if sd[n].grad is not None]
+            oo.clip_grad_norm([sd[n].grad for n in act], 20.0)
+            oo.novograd_step([sd[n] for n in act], [sd[n].grad for n in act], [states[n] for n in act], lr=1e-3,
+                             weight_decay=1e-5)
+            for n in names:
+                sd[n].grad = None
+                sd[n].requires_grad_(False)
+            sd.update(opts.bn_buffers)
+        if step > 0:
+            times.append(time.time() - t0)
+    t = sum(times) / len(times)
+    return {"value": round(batch * SECONDS / t, 2), "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
+            "sample": f"{steps} steps of batch {batch} (3 s utterances) after 1 warm-up step, {t:.2f} s/step, fp32 torch-CPU oracle"}
+
+
+def gemm_roofline(trainer, batches, step_fn):
+    """Bracket every GEMM launch of one training step with HIP events on the launch stream; FLOPs are 2*M*N*K."""
+    eng = trainer.engine
+    k = eng.k
+    orig = k.gemm_nt
+    rec = []
+
+    def timed(A, B, out, *a, M=None, N=None, K=None, **kw):
+        m = A.shape[0] if M is None else M
+        kk = A.shape[1] if K is None else K
+        n = B.shape[0] if N is None else N
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(A, B, out, *a, M=M, N=N, K=K, **kw)
+        e1.record()
+        rec.append((e0, e1, 2.0 * m * n * kk))
+        return r
+
+    k.gemm_nt = timed
+    try:
+        step_fn(0, batches[0])
+        torch.cuda.synchronize()
+    finally:
+        k.gemm_nt = orig
+    ms = sum(a.elapsed_time(b) for a, b, _ in rec)
+    flops = sum(f for _, _, f in rec)
+    return {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_nt_bf16_kernel", "launches_per_step": len(rec), "gemm_ms_per_step": round(ms, 3),
+            "gemm_gflop_per_step": round(flops / 1e9, 1), "avg_launch_us": round(ms * 1e3 / len(rec), 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--blocks", type=int, default=12)
+    ap.add_argument("--stochastic-depth", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the lidk path has no CPU fallback")
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    cfg, module, trainer, ds = build(args, rank, world, device)
+    batches = resident_batches(ds, rank, world, device, args.batch)
+    n_total = args.warmup + args.steps + 8
+
+    def step_fn(i, batch):
+        trainer.train_step(i, batch, n_total)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step_fn(i, batches[i % N_LANGS])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step_fn(args.warmup + i, batches[(args.warmup + i) % N_LANGS])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    roof = gemm_roofline(trainer, batches, step_fn) if rank == 0 else None
+    if world > 1:
+        dist.barrier()
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = min(os.cpu_count() or 1, 16)
+        cpu = cpu_baseline(module, ds, args.cpu_steps, args.cpu_batch, threads)
+    if rank == 0:
+        audio_s = world * args.batch * SECONDS * args.steps
+        line = {"metric": "audio-seconds/sec LID training, Conformer d256", "value": round(audio_s / elapsed, 1),
+                "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"ConformerLangModel {args.blocks}-layer d256, 14-lang CTC heads, log-mel 80-bin, "
+                                       f"3 s@16 kHz, batch={args.batch}/GPU, Novograd+clip, features on GPU",
+                           "global_batch": world * args.batch, "utterance_seconds": SECONDS,
+                           "parallelism": f"dp{world}", "stochastic_depth": bool(args.stochastic_depth)},
+                "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

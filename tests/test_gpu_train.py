@@ -1,0 +1,63 @@
+"""GPU tests of the training path through the drop-in boundary: smoke entry, Trainer.fit on BASELINE config 1, bench.py."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_graft_entry_smoke_matches_oracle():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.smoke()
+
+
+def test_trainer_fit_config1_bf16(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    from ccml import seed_everything
+    from ccml.callbacks.ckpt_callback import CkptCallback
+    from ccml.trainer import Trainer
+    from lid import hydra_lite
+    import lid.main as launcher
+    seed_everything(0)
+    cfg = hydra_lite.load_config(os.path.join(PKG, "lid", "conf"), "synthetic_cfg1",
+                                 ["trainer.total_epoch=4", "trainer.gpu_id=0", "data.synthetic.items_per_lang=16",
+                                  "module.interval=4", "trainer.log_interval=4", "module.optimizer_param.lr=0.02"])
+    module, sets, params = launcher.build(cfg)
+    epoch_loss = []
+    orig = module.train_loop_end
+
+    def spy(outputs):
+        epoch_loss.append(float(torch.stack([o["loss"].float() for o in outputs]).mean()))
+        return orig(outputs)
+
+    module.train_loop_end = spy
+    trainer = Trainer(callbacks=[CkptCallback(file_name_metric=["epoch", "val_loss"], save_topk=1)], loggers=[],
+                      **dict(cfg["trainer"]))
+    trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=params)
+    print("epoch mean train loss:", epoch_loss, "val:", module.last_val)
+    assert all(np.isfinite(epoch_loss)) and epoch_loss[-1] < epoch_loss[0]
+    assert module.model.lidk_engine.act_dtype == torch.bfloat16
+    assert np.isfinite(module.last_val["val_loss"]) and 0.0 <= module.last_val["cavg"] <= 1.0
+    assert os.path.exists("ckpt/last.pt")
+    sd = torch.load("ckpt/last.pt", weights_only=False)["model"]
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
+
+
+def test_bench_contract_small():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--blocks", "2", "--steps", "3", "--warmup", "1",
+                          "--cpu-steps", "1", "--cpu-batch", "2", "--batch", "8"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["value"] > 0 and line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
