@@ -102,12 +102,20 @@ int lidk_gemm_nt(const lidk_gemm_args* args, int dtype, void* stream);
 /* ------------------------------------------------------------------ Attention core with Shaw relative positions (lid/conformer.py:117-148)
  * qkv [B*T][3*heads*dh] (T): q | k | v column blocks, head h at columns h*dh.. within each.  rel_emb [2*max_pos+1][dh] f32.
  * scores = (q.k^T + q.rel_emb[clamp(i-j)+max_pos]) * dh^-0.5 ; probs = softmax_j ; out = probs.v -> [B*T][heads*dh] (T).
- * probs [B][heads][T][T] (T) is saved for backward. */
-int lidk_attn_fwd(const void* qkv, const float* rel_emb, void* out, void* probs, int B, int T, int heads, int dh,
-                  int max_pos, int dtype, void* stream);
+ * probs [B][heads][T][ldp] (T) is saved for backward. */
+int lidk_attn_fwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, void* out, void* probs, int ldp, int B, int T,
+                  int heads, int dh, int max_pos, int dtype, void* stream);
 /* dqkv [B*T][3*heads*dh] (T) written; drel_emb += (atomic f32).  dscores: scratch [B][heads][T][T] f32. */
-int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* probs, const void* dout, void* dqkv,
-                  float* drel_emb, float* dscores, int B, int T, int heads, int dh, int max_pos, int dtype, void* stream);
+int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, const void* probs, int ldp, const void* dout,
+                  void* dqkv, float* drel_emb, float* dscores, int B, int T, int heads, int dh, int max_pos, int dtype,
+                  void* stream);
+/* Row stride (elements) the probs buffer must have for (T, dh, dtype): T rounded up to 32 when the MFMA kernels apply
+ * (bf16, dh in {32,64}, T <= 256), else T.  probs is [B][heads][T][ldp]; rel_emb_T is the T-typed copy of rel_emb
+ * (required by the MFMA kernels, may be NULL otherwise). */
+int lidk_attn_ldp(int T, int dh, int dtype);
+/* Device self-test of the ds_read_b64_tr_b16 lane mapping the transposed-operand kernels assume:
+ * in [8][64] int16 -> out [64 lanes][2 halves][4] int16 as read by the documented addressing. */
+int lidk_selftest_tr16(const void* in_8x64_i16, void* out_64x8_i16, void* stream);
 
 /* ------------------------------------------------------------------ Conv module pieces (lid/conformer.py:47-65,174-205) */
 /* GLU over channels: y [M][2C] -> g [M][C] = y[:, :C] * sigmoid(y[:, C:]) */
@@ -167,10 +175,12 @@ int lidk_lid_score(const float* logits, float* scores, int score_stride, int B, 
 int lidk_novograd_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* work, int n_work,
                        int n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
                        int grad_averaging, float max_norm, float* scratch, float* total_norm_out, void* stream);
-/* Refresh the T-typed GEMM operands from the f32 master parameters: for each of n_mats entries
- * mats [n][6] int64 = (src offset in `params`, rows, cols, dst offset of W [rows][cols] in wT or -1,
- * dst offset of W^T in wT or -1, leading dimension of W^T (>= rows; 0 means rows; pad columns are not written)). */
-int lidk_cast_weights(const float* params, void* wT, const int64_t* mats_host, int n_mats, int dtype, void* stream);
+/* Refresh the T-typed GEMM operands from the f32 master parameters in ONE launch.  mats [n_mats][8] int64 (DEVICE) =
+ * (src offset in `params`, rows R, cols C, dst offset of W [R][C] in wT or -1, dst offset of W^T [C][ldt] in wT or -1,
+ * ldt >= R (pad columns are not written), index of the matrix's first 32x32 tile, tiles per tile-row = ceil(C/32));
+ * rows sorted by first-tile index; total_tiles = sum over matrices of ceil(R/32)*ceil(C/32). */
+int lidk_cast_weights(const float* params, void* wT, const int64_t* mats, int n_mats, long total_tiles, int dtype,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -49,7 +49,7 @@ __device__ __forceinline__ void att_stage_kve(const T* __restrict__ qkv, const f
 template <typename T>
 __global__ void __launch_bounds__(256)
 attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ emb, T* __restrict__ out, T* __restrict__ probs,
-                AttGeom g, float scale) {
+                AttGeom g, int ldp, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T_ = g.T, dh = g.dh, DHP = dh + AttPad<T>::v, NE = T_ + ATT_ROWS - 1;
   T* Ks = reinterpret_cast<T*>(smem);
@@ -80,7 +80,7 @@ attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ emb, T* __r
     for (int j = lane; j < T_; j += 64) { float p = __expf(ps[j] - mx); ps[j] = p; sum += p; }
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
-    T* prow = probs + ((size_t)(b * g.H + h) * T_ + i) * T_;
+    T* prow = probs + ((size_t)(b * g.H + h) * T_ + i) * ldp;
     for (int j = lane; j < T_; j += 64) { float p = ps[j] * inv; ps[j] = p; prow[j] = from_f<T>(p); }
     __builtin_amdgcn_wave_barrier();
     float o = 0.f;
@@ -98,7 +98,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 attn_bwd_rows_kernel(const T* __restrict__ qkv, const float* __restrict__ emb, const T* __restrict__ probs,
                      const T* __restrict__ dout, T* __restrict__ dqkv, float* __restrict__ dscores, AttGeom g,
-                     float scale) {
+                     int ldp, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T_ = g.T, dh = g.dh, DHP = dh + AttPad<T>::v, NE = T_ + ATT_ROWS - 1;
   T* Ks = reinterpret_cast<T*>(smem);
@@ -119,16 +119,17 @@ attn_bwd_rows_kernel(const T* __restrict__ qkv, const float* __restrict__ emb, c
     for (int d = lane; d < dh; d += 64) dos[d] = to_f(dorow[d]);
     __builtin_amdgcn_wave_barrier();
     const size_t prow = ((size_t)(b * g.H + h) * T_ + i) * T_;
+    const size_t pprow = ((size_t)(b * g.H + h) * T_ + i) * ldp;
     float delta = 0.f;
     for (int j = lane; j < T_; j += 64) {
       float dp = dot_qv<T>(dos, Vs + j * DHP, dh);
-      float p = to_f(probs[prow + j]);
+      float p = to_f(probs[pprow + j]);
       ps[j] = dp;
       delta = fmaf(p, dp, delta);
     }
     delta = wave_sum(delta);
     for (int j = lane; j < T_; j += 64) {
-      float p = to_f(probs[prow + j]);
+      float p = to_f(probs[pprow + j]);
       float ds = p * (ps[j] - delta);
       ps[j] = ds;
       dscores[prow + j] = ds;
@@ -150,7 +151,7 @@ template <typename T, int DH>
 __global__ void __launch_bounds__(256)
 attn_bwd_cols_kernel(const T* __restrict__ qkv, const T* __restrict__ probs, const T* __restrict__ dout,
                      const float* __restrict__ dscores, T* __restrict__ dqkv, float* __restrict__ demb, AttGeom g,
-                     float scale) {
+                     int ldp, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T_ = g.T;
   float* Qs = reinterpret_cast<float*>(smem);          // [T][DH] f32 (broadcast reads, no padding needed)
@@ -164,6 +165,7 @@ attn_bwd_cols_kernel(const T* __restrict__ qkv, const T* __restrict__ probs, con
   }
   __syncthreads();
   const size_t base = (size_t)(b * g.H + h) * T_ * T_;
+  const size_t pbase = (size_t)(b * g.H + h) * T_ * ldp;
   const int nkc = (T_ + 63) / 64, nrc = (2 * T_ - 1 + 63) / 64;
   for (int item = wave; item < nkc + nrc; item += 4) {
     if (item < nkc) {
@@ -174,7 +176,7 @@ attn_bwd_cols_kernel(const T* __restrict__ qkv, const T* __restrict__ probs, con
       if (j < T_) {
         for (int i = 0; i < T_; ++i) {
           const float s = dscores[base + (size_t)i * T_ + j];
-          const float p = to_f(probs[base + (size_t)i * T_ + j]);
+          const float p = to_f(probs[pbase + (size_t)i * ldp + j]);
 #pragma unroll
           for (int d = 0; d < DH; ++d) { ak[d] = fmaf(s, Qs[i * DH + d], ak[d]); av[d] = fmaf(p, Ds[i * DH + d], av[d]); }
         }
@@ -203,6 +205,166 @@ attn_bwd_cols_kernel(const T* __restrict__ qkv, const T* __restrict__ probs, con
   }
 }
 
+// =====================================================================================================================
+// MFMA forward (bf16, dh in {32, 64}, T <= 256): one workgroup per (batch, head).
+//   LDS: Ks [Tp][DH+8], Vt [DH][Tp+8] (V transposed), Es [2*Tp+8][DH+8] (relative embeddings, index e = r + Tp), and one
+//   P tile [16][Tp+8] per wave.  Each wave walks 16-row query blocks:
+//     S tile (16x16)   = Q.K^T              (DH/32 MFMAs, v_mfma_f32_16x16x32_bf16)
+//     R tiles (16x32)  = Q.E[r0..r0+31]^T   with r0 = i0 - j0 - 15: exactly the offsets i-j this tile needs
+//     skew             : S[a][c] += R[a][a-c+15]; the source sits in the same register of a lane of the same 16-lane
+//                        group, so it is one ds_bpermute per R tile and register
+//     softmax          : row = one register across the 16 lanes of a group -> 4 xor-shuffles
+//     P -> LDS (bf16) -> 16-byte stores to probs[b][h][i][0..ldp) and A operand of O = P.V (B operand from Vt)
+// =====================================================================================================================
+#define AF_NJ_MAX 16
+
+template <int DH>
+__global__ void __launch_bounds__(256)
+attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT, bf16* __restrict__ out,
+                     bf16* __restrict__ probs, AttGeom g, int ldp, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int KS = DH / 32, LDK = DH + 8;
+  const int T_ = g.T, Tp = (T_ + 31) / 32 * 32, NJ = Tp / 16, LDV = Tp + 8, NE = 2 * Tp + 8;
+  bf16* Ks = reinterpret_cast<bf16*>(smem);
+  bf16* Vt = Ks + Tp * LDK;
+  bf16* Es = Vt + DH * LDV;
+  bf16* Ps = Es + NE * LDK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / g.H, h = blockIdx.x % g.H;
+  const bf16* base = qkv + (size_t)b * T_ * g.ld + h * DH;
+
+  // ---- stage K (row-major), V (transposed), E slice; 16-byte global loads
+  constexpr int CH = DH / 8;
+  for (int c = tid; c < Tp * CH; c += 256) {
+    int j = c / CH, dc = (c % CH) * 8;
+    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+    if (j < T_) {
+      kv = *reinterpret_cast<const uint4*>(base + (size_t)j * g.ld + g.inner + dc);
+      vv = *reinterpret_cast<const uint4*>(base + (size_t)j * g.ld + 2 * g.inner + dc);
+    }
+    *reinterpret_cast<uint4*>(&Ks[j * LDK + dc]) = kv;
+    const bf16* ve = reinterpret_cast<const bf16*>(&vv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Vt[(dc + e) * LDV + j] = ve[e];
+  }
+  for (int c = tid; c < NE * CH; c += 256) {
+    int e = c / CH, dc = (c % CH) * 8;
+    int r = max(-g.max_pos, min(g.max_pos, e - Tp)) + g.max_pos;
+    *reinterpret_cast<uint4*>(&Es[e * LDK + dc]) = *reinterpret_cast<const uint4*>(embT + (size_t)r * DH + dc);
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  bf16* Pw = Ps + wave * 16 * LDV;
+  const int nrb = (T_ + 15) / 16;
+  for (int rb = wave; rb < nrb; rb += 4) {
+    const int i0 = rb * 16;
+    // Q fragments straight from global: lane holds row i0+fr, k = 32*ks + 8*fq .. +8
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i0 + fr < T_) v = *reinterpret_cast<const uint4*>(base + (size_t)(i0 + fr) * g.ld + ks * 32 + fq * 8);
+      qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+    }
+    float s[AF_NJ_MAX][4];
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+      if (jt < NJ) {
+        const int j0 = jt * 16;
+        f32x4 as = {0.f, 0.f, 0.f, 0.f}, r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
+        const int eb = i0 - j0 - 15 + Tp;                       // LDS row of offset r0 = i0 - j0 - 15
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(j0 + fr) * LDK + ks * 32 + fq * 8]);
+          bf16x8 e0 = *reinterpret_cast<const bf16x8*>(&Es[(eb + fr) * LDK + ks * 32 + fq * 8]);
+          bf16x8 e1 = *reinterpret_cast<const bf16x8*>(&Es[(eb + 16 + fr) * LDK + ks * 32 + fq * 8]);
+          as = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, as, 0, 0, 0);
+          r0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], e0, r0, 0, 0, 0);
+          r1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], e1, r1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = fq * 4 + r;                               // row inside the tile
+          const int cp = a - fr + 15;                             // column of the R sub-block: 0..30
+          const int src = (lane & 48) | (cp & 15);
+          const float v0 = __shfl(r0[r], src, 64), v1 = __shfl(r1[r], src, 64);
+          float v = scale * (as[r] + (cp < 16 ? v0 : v1));
+          if (j0 + fr >= T_) v = -INFINITY;
+          s[jt][r] = v;
+          mx[r] = fmaxf(mx[r], v);
+        }
+      }
+    }
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+    }
+#pragma unroll
+    for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+      if (jt < NJ) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float p = __expf(s[jt][r] - mx[r]); s[jt][r] = p; sum[r] += p; }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sum[r] += __shfl_xor(sum[r], o, 64);
+      sum[r] = 1.0f / sum[r];
+    }
+#pragma unroll
+    for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+      if (jt < NJ) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pw[(fq * 4 + r) * LDV + jt * 16 + fr] = (bf16)(s[jt][r] * sum[r]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // P rows -> global, 16 bytes per lane
+    bf16* pg = probs + ((size_t)(b * g.H + h) * T_ + i0) * ldp;
+    for (int c = lane; c < 16 * (Tp / 8); c += 64) {
+      int row = c / (Tp / 8), col = (c % (Tp / 8)) * 8;
+      if (i0 + row < T_) *reinterpret_cast<uint4*>(pg + (size_t)row * ldp + col) = *reinterpret_cast<const uint4*>(&Pw[row * LDV + col]);
+    }
+    // O = P.V
+    f32x4 ao[DH / 16];
+#pragma unroll
+    for (int nt = 0; nt < DH / 16; ++nt) ao[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < Tp; k0 += 32) {
+      bf16x8 pf = *reinterpret_cast<const bf16x8*>(&Pw[fr * LDV + k0 + fq * 8]);
+#pragma unroll
+      for (int nt = 0; nt < DH / 16; ++nt) {
+        bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(nt * 16 + fr) * LDV + k0 + fq * 8]);
+        ao[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, ao[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < DH / 16; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = i0 + fq * 4 + r;
+        if (i < T_) out[(size_t)(b * T_ + i) * g.inner + h * DH + nt * 16 + fr] = (bf16)ao[nt][r];
+      }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+static size_t att_mfma_lds(int T_, int dh) {
+  int Tp = (T_ + 31) / 32 * 32;
+  return (size_t)2 * ((size_t)Tp * (dh + 8) + (size_t)dh * (Tp + 8) + (size_t)(2 * Tp + 8) * (dh + 8) + (size_t)4 * 16 * (Tp + 8));
+}
+
+extern "C" int lidk_attn_ldp(int T_, int dh, int dtype) {
+  // row stride of the probs buffer: padded to a multiple of 32 for the MFMA kernels, plain T otherwise
+  bool mfma = dtype == LIDK_BF16 && (dh == 32 || dh == 64) && T_ <= 16 * AF_NJ_MAX && att_mfma_lds(T_, dh) <= 160 * 1024;
+  return mfma ? (T_ + 31) / 32 * 32 : T_;
+}
+
+
 // ------------------------------------------------------------------------------------ host side
 template <typename T>
 static size_t att_rows_lds(int T_, int dh) {
@@ -212,24 +374,35 @@ static size_t att_rows_lds(int T_, int dh) {
 }
 static bool att_dh_ok(int dh) { return dh == 8 || dh == 16 || dh == 32 || dh == 64; }
 
-extern "C" int lidk_attn_fwd(const void* qkv, const float* rel_emb, void* out, void* probs, int B, int T_, int heads,
-                             int dh, int max_pos, int dtype, void* stream) {
-  if (!qkv || !rel_emb || !out || !probs || B <= 0 || T_ <= 0 || heads <= 0) return LIDK_ERR_ARG;
+extern "C" int lidk_attn_fwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, void* out, void* probs, int ldp,
+                             int B, int T_, int heads, int dh, int max_pos, int dtype, void* stream) {
+  if (!qkv || !rel_emb || !out || !probs || B <= 0 || T_ <= 0 || heads <= 0 || ldp < T_) return LIDK_ERR_ARG;
   if (!att_dh_ok(dh)) return LIDK_ERR_UNSUPPORTED;
   AttGeom g{B, T_, heads, dh, max_pos, heads * dh, 3 * heads * dh};
-  dim3 grid(cdiv(T_, ATT_ROWS), heads, B);
   const float scale = 1.0f / sqrtf((float)dh);
   hipStream_t s = as_stream(stream);
+  if (dtype == LIDK_BF16 && rel_emb_T && ldp == (T_ + 31) / 32 * 32 && lidk_attn_ldp(T_, dh, dtype) == ldp && (dh == 32 || dh == 64)) {
+    size_t lds = att_mfma_lds(T_, dh);
+    if (dh == 64) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attn_fwd_mfma_kernel<64><<<B * heads, 256, lds, s>>>((const bf16*)qkv, (const bf16*)rel_emb_T, (bf16*)out, (bf16*)probs, g, ldp, scale);
+    } else {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attn_fwd_mfma_kernel<32><<<B * heads, 256, lds, s>>>((const bf16*)qkv, (const bf16*)rel_emb_T, (bf16*)out, (bf16*)probs, g, ldp, scale);
+    }
+    return launch_status();
+  }
+  dim3 grid(cdiv(T_, ATT_ROWS), heads, B);
   if (dtype == LIDK_BF16) {
     size_t lds = att_rows_lds<bf16>(T_, dh);
     if (lds > 160 * 1024) return LIDK_ERR_UNSUPPORTED;
-    hipFuncSetAttribute((const void*)attn_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attn_fwd_kernel<bf16><<<grid, 256, lds, s>>>((const bf16*)qkv, rel_emb, (bf16*)out, (bf16*)probs, g, scale);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attn_fwd_kernel<bf16><<<grid, 256, lds, s>>>((const bf16*)qkv, rel_emb, (bf16*)out, (bf16*)probs, g, ldp, scale);
   } else if (dtype == LIDK_F32) {
     size_t lds = att_rows_lds<float>(T_, dh);
     if (lds > 160 * 1024) return LIDK_ERR_UNSUPPORTED;
-    hipFuncSetAttribute((const void*)attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attn_fwd_kernel<float><<<grid, 256, lds, s>>>((const float*)qkv, rel_emb, (float*)out, (float*)probs, g, scale);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attn_fwd_kernel<float><<<grid, 256, lds, s>>>((const float*)qkv, rel_emb, (float*)out, (float*)probs, g, ldp, scale);
   } else {
     return LIDK_ERR_ARG;
   }
@@ -238,42 +411,65 @@ extern "C" int lidk_attn_fwd(const void* qkv, const float* rel_emb, void* out, v
 
 template <typename T, int DH>
 static void att_cols_launch(const void* qkv, const void* probs, const void* dout, const float* dscores, void* dqkv,
-                            float* demb, AttGeom g, float scale, hipStream_t s) {
+                            float* demb, AttGeom g, int ldp, float scale, hipStream_t s) {
   size_t lds = (size_t)2 * g.T * DH * sizeof(float);
-  hipFuncSetAttribute((const void*)attn_bwd_cols_kernel<T, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_cols_kernel<T, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   attn_bwd_cols_kernel<T, DH><<<g.B * g.H, 256, lds, s>>>((const T*)qkv, (const T*)probs, (const T*)dout, dscores,
-                                                           (T*)dqkv, demb, g, scale);
+                                                           (T*)dqkv, demb, g, ldp, scale);
 }
 
 template <typename T>
-static int att_bwd_launch(const void* qkv, const float* rel_emb, const void* probs, const void* dout, void* dqkv,
+static int att_bwd_launch(const void* qkv, const float* rel_emb, const void* probs, int ldp, const void* dout, void* dqkv,
                           float* drel_emb, float* dscores, AttGeom g, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)g.dh);
   size_t lds = att_rows_lds<T>(g.T, g.dh);
   if (lds > 160 * 1024 || (size_t)2 * g.T * g.dh * sizeof(float) > 160 * 1024) return LIDK_ERR_UNSUPPORTED;
   dim3 grid(cdiv(g.T, ATT_ROWS), g.H, g.B);
-  hipFuncSetAttribute((const void*)attn_bwd_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   attn_bwd_rows_kernel<T><<<grid, 256, lds, s>>>((const T*)qkv, rel_emb, (const T*)probs, (const T*)dout, (T*)dqkv,
-                                                 dscores, g, scale);
+                                                 dscores, g, ldp, scale);
   switch (g.dh) {
-    case 8: att_cols_launch<T, 8>(qkv, probs, dout, dscores, dqkv, drel_emb, g, scale, s); break;
-    case 16: att_cols_launch<T, 16>(qkv, probs, dout, dscores, dqkv, drel_emb, g, scale, s); break;
-    case 32: att_cols_launch<T, 32>(qkv, probs, dout, dscores, dqkv, drel_emb, g, scale, s); break;
-    case 64: att_cols_launch<T, 64>(qkv, probs, dout, dscores, dqkv, drel_emb, g, scale, s); break;
+    case 8: att_cols_launch<T, 8>(qkv, probs, dout, dscores, dqkv, drel_emb, g, ldp, scale, s); break;
+    case 16: att_cols_launch<T, 16>(qkv, probs, dout, dscores, dqkv, drel_emb, g, ldp, scale, s); break;
+    case 32: att_cols_launch<T, 32>(qkv, probs, dout, dscores, dqkv, drel_emb, g, ldp, scale, s); break;
+    case 64: att_cols_launch<T, 64>(qkv, probs, dout, dscores, dqkv, drel_emb, g, ldp, scale, s); break;
     default: return LIDK_ERR_UNSUPPORTED;
   }
   return launch_status();
 }
 
-extern "C" int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* probs, const void* dout, void* dqkv,
-                             float* drel_emb, float* dscores, int B, int T_, int heads, int dh, int max_pos, int dtype,
-                             void* stream) {
-  if (!qkv || !rel_emb || !probs || !dout || !dqkv || !drel_emb || !dscores || B <= 0 || T_ <= 0 || heads <= 0)
+extern "C" int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, const void* probs, int ldp,
+                             const void* dout, void* dqkv, float* drel_emb, float* dscores, int B, int T_, int heads, int dh,
+                             int max_pos, int dtype, void* stream) {
+  (void)rel_emb_T;
+  if (!qkv || !rel_emb || !probs || !dout || !dqkv || !drel_emb || !dscores || B <= 0 || T_ <= 0 || heads <= 0 || ldp < T_)
     return LIDK_ERR_ARG;
   if (!att_dh_ok(dh)) return LIDK_ERR_UNSUPPORTED;
   AttGeom g{B, T_, heads, dh, max_pos, heads * dh, 3 * heads * dh};
   hipStream_t s = as_stream(stream);
-  if (dtype == LIDK_BF16) return att_bwd_launch<bf16>(qkv, rel_emb, probs, dout, dqkv, drel_emb, dscores, g, s);
-  if (dtype == LIDK_F32) return att_bwd_launch<float>(qkv, rel_emb, probs, dout, dqkv, drel_emb, dscores, g, s);
+  if (dtype == LIDK_BF16) return att_bwd_launch<bf16>(qkv, rel_emb, probs, ldp, dout, dqkv, drel_emb, dscores, g, s);
+  if (dtype == LIDK_F32) return att_bwd_launch<float>(qkv, rel_emb, probs, ldp, dout, dqkv, drel_emb, dscores, g, s);
   return LIDK_ERR_ARG;
+}
+
+// ------------------------------------------------------------------------------------ hardware self-test
+// ds_read_b64_tr_b16 (gfx950): within each 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
+// 4x16 block of 16-bit elements; lane i receives column i of the 4 rows (row q in element q).  The TN GEMM and the attention
+// backward rely on exactly this mapping; the self-test lets the test-suite pin it on the device.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__global__ void tr16_selftest_kernel(const short* __restrict__ in, short* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) short tile[8][64];
+  for (int i = threadIdx.x; i < 8 * 64; i += 64) tile[i / 64][i % 64] = in[i];
+  __syncthreads();
+  const int lane = threadIdx.x, g = lane >> 4, idx = lane & 15;
+  for (int half = 0; half < 2; ++half) {
+    const short* addr = &tile[(idx >> 2) + 4 * half][16 * g + 4 * (idx & 3)];
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)addr);
+    for (int q = 0; q < 4; ++q) out[(lane * 2 + half) * 4 + q] = v[q];
+  }
+}
+extern "C" int lidk_selftest_tr16(const void* in_8x64_i16, void* out_64x8_i16, void* stream) {
+  if (!in_8x64_i16 || !out_64x8_i16) return LIDK_ERR_ARG;
+  tr16_selftest_kernel<<<1, 64, 0, as_stream(stream)>>>((const short*)in_8x64_i16, (short*)out_64x8_i16);
+  return launch_status();
 }

@@ -136,13 +136,30 @@ __global__ void colsum_partial_kernel(const T* __restrict__ x, int ldx, float* _
   }
 }
 
-__global__ void partial_finalize_kernel(const float* __restrict__ partial, int nparts, int ncols, float* __restrict__ out,
-                                        float scale) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncols) return;
-  float acc = 0.f;
-  for (int p = 0; p < nparts; ++p) acc += partial[(size_t)p * ncols + c];
-  out[c] += scale * acc;
+// Second stage of every column reduction: out[c] (+)= scale * sum_p partial[p][c].  1024 threads = 16 waves: lane -> column,
+// wave -> every 16th partial row (independent loads in flight), then a fixed-order LDS combine: deterministic.
+// Columns c < split go to out0[c], the rest to out1[c - split] (LayerNorm: dgamma | dbeta).
+template <typename ACC, typename TOUT, bool ACCUM>
+__global__ void __launch_bounds__(1024)
+colreduce_kernel(const float* __restrict__ partial, int nparts, int ncols, TOUT* __restrict__ out0, TOUT* __restrict__ out1,
+                 int split, float scale) {
+  __shared__ ACC red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  ACC acc = 0;
+  if (c < ncols) {
+#pragma unroll 4
+    for (int p = w; p < nparts; p += 16) acc += (ACC)partial[(size_t)p * ncols + c];
+  }
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && c < ncols) {
+    ACC s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][lane];
+    TOUT* dst = (c < split) ? (out0 ? out0 + c : nullptr) : (out1 ? out1 + (c - split) : nullptr);
+    if (dst) *dst = ACCUM ? (TOUT)(*dst + (TOUT)scale * (TOUT)s) : (TOUT)s;
+  }
 }
 
 extern "C" int lidk_colsum(const void* x, int ldx, int xd, float* out, float* partial, int M, int N, float scale,
@@ -151,21 +168,14 @@ extern "C" int lidk_colsum(const void* x, int ldx, int xd, float* out, float* pa
   hipStream_t s = as_stream(stream);
   int G = M < LIDK_LN_PARTIAL_BLOCKS ? M : LIDK_LN_PARTIAL_BLOCKS;
   LIDK_DISPATCH(xd, colsum_partial_kernel<T><<<G, 256, 0, s>>>((const T*)x, ldx, partial, M, N));
-  partial_finalize_kernel<<<cdiv(N, 256), 256, 0, s>>>(partial, G, N, out, scale);
+  colreduce_kernel<float, float, true><<<cdiv(N, 64), 1024, 0, s>>>(partial, G, N, out, (float*)nullptr, N, scale);
   return launch_status();
-}
-
-__global__ void reduce_partials_f64_kernel(const float* __restrict__ partial, int nparts, int ncols, double* __restrict__ out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncols) return;
-  double acc = 0.0;
-  for (int p = 0; p < nparts; ++p) acc += (double)partial[(size_t)p * ncols + c];
-  out[c] = acc;
 }
 
 extern "C" int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double* out, void* stream) {
   if (!partial || !out || nparts <= 0 || ncols <= 0) return LIDK_ERR_ARG;
-  reduce_partials_f64_kernel<<<cdiv(ncols, 256), 256, 0, as_stream(stream)>>>(partial, nparts, ncols, out);
+  colreduce_kernel<double, double, false><<<cdiv(ncols, 64), 1024, 0, as_stream(stream)>>>(partial, nparts, ncols, out,
+                                                                                          (double*)nullptr, ncols, 1.0f);
   return launch_status();
 }
 
@@ -307,15 +317,6 @@ ln_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x, const flo
     partial[(size_t)blockIdx.x * 2 * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
-__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * C) return;
-  float acc = 0.f;
-  for (int p = 0; p < nparts; ++p) acc += partial[(size_t)p * 2 * C + c];
-  if (c < C) { if (dgamma) dgamma[c] += acc; } else { if (dbeta) dbeta[c - C] += acc; }
-}
-
 extern "C" int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
                                   const float* gamma, const float* dres, float* dx, void* dxT, float dxT_scale,
                                   float* dgamma, float* dbeta, float* partial, int M, int C, int dtype, void* stream) {
@@ -332,6 +333,6 @@ extern "C" int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, 
     LIDK_DISPATCH(dtype, ln_bwd_kernel<T, T><<<G, 256, 0, s>>>((const T*)dy, x, mean, rstd, gamma, dres, dx, (T*)dxT,
                                                               dxT_scale, partial, M, C));
   }
-  ln_bwd_finalize_kernel<<<cdiv(2 * C, 256), 256, 0, s>>>(partial, G, C, dgamma, dbeta);
+  colreduce_kernel<float, float, true><<<cdiv(2 * C, 64), 1024, 0, s>>>(partial, G, 2 * C, dgamma, dbeta, C, 1.0f);
   return launch_status();
 }

@@ -94,11 +94,27 @@ extern "C" int lidk_novograd_step(float* params, float* grads, float* exp_avg, f
 }
 
 // ------------------------------------------------------------------------------------ weight refresh (f32 master -> T operands)
+// ONE launch for all matrices: mats [n][8] int64 (device) = (src offset, rows R, cols C, dst offset of W or -1, dst offset of
+// W^T or -1, leading dim of W^T, first tile index, tiles per row).  A workgroup handles one 32x32 tile; it finds its matrix
+// by binary search over the tile prefix.
 template <typename T>
-__global__ void cast_matrix_kernel(const float* __restrict__ src, T* __restrict__ w, T* __restrict__ wt, int R, int C, int ldt) {
+__global__ void __launch_bounds__(256)
+cast_weights_kernel(const float* __restrict__ params, T* __restrict__ wT, const int64_t* __restrict__ mats, int n_mats) {
   __shared__ float tile[32][33];
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: 8 rows per pass
+  const long tid = blockIdx.x;
+  int lo = 0, hi = n_mats - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (mats[(size_t)mid * 8 + 6] <= tid) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* m = mats + (size_t)lo * 8;
+  const int R = (int)m[1], C = (int)m[2], ldt = (int)m[5], tx_n = (int)m[7];
+  const long local = tid - m[6];
+  const int r0 = (int)(local / tx_n) * 32, c0 = (int)(local % tx_n) * 32;
+  const float* src = params + m[0];
+  T* w = m[3] >= 0 ? wT + m[3] : nullptr;
+  T* wt = m[4] >= 0 ? wT + m[4] : nullptr;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int i = ty; i < 32; i += 8) {
     int r = r0 + i, c = c0 + tx;
     if (r < R && c < C) {
@@ -107,35 +123,19 @@ __global__ void cast_matrix_kernel(const float* __restrict__ src, T* __restrict_
       if (w) w[(size_t)r * C + c] = from_f<T>(v);
     }
   }
-  if (!wt) return;
   __syncthreads();
+  if (!wt) return;
   for (int i = ty; i < 32; i += 8) {
     int c = c0 + i, r = r0 + tx;
     if (r < R && c < C) wt[(size_t)c * ldt + r] = from_f<T>(tile[tx][i]);
   }
 }
 
-extern "C" int lidk_cast_weights(const float* params, void* wT, const int64_t* mats, int n_mats, int dtype, void* stream) {
-  if (!params || !wT || !mats || n_mats < 0) return LIDK_ERR_ARG;
+extern "C" int lidk_cast_weights(const float* params, void* wT, const int64_t* mats, int n_mats, long total_tiles, int dtype,
+                                 void* stream) {
+  if (!params || !wT || !mats || n_mats <= 0 || total_tiles <= 0) return LIDK_ERR_ARG;
   hipStream_t s = as_stream(stream);
-  for (int i = 0; i < n_mats; ++i) {
-    const int64_t* m = mats + (size_t)i * 6;
-    const int R = (int)m[1], C = (int)m[2];
-    const int ldt = m[5] > 0 ? (int)m[5] : R;
-    if (R <= 0 || C <= 0 || ldt < R) return LIDK_ERR_ARG;
-    dim3 grid(cdiv(C, 32), cdiv(R, 32));
-    if (dtype == LIDK_BF16) {
-      bf16* base = (bf16*)wT;
-      cast_matrix_kernel<bf16><<<grid, 256, 0, s>>>(params + m[0], m[3] >= 0 ? base + m[3] : nullptr,
-                                                    m[4] >= 0 ? base + m[4] : nullptr, R, C, ldt);
-    } else if (dtype == LIDK_F32) {
-      float* base = (float*)wT;
-      cast_matrix_kernel<float><<<grid, 256, 0, s>>>(params + m[0], m[3] >= 0 ? base + m[3] : nullptr,
-                                                     m[4] >= 0 ? base + m[4] : nullptr, R, C, ldt);
-    } else {
-      return LIDK_ERR_ARG;
-    }
-  }
+  LIDK_DISPATCH(dtype, cast_weights_kernel<T><<<(unsigned)total_tiles, 256, 0, s>>>(params, (T*)wT, mats, n_mats));
   return launch_status();
 }
 

@@ -47,8 +47,10 @@ SIGNATURES = {
     "lidk_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "lidk_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_gemm_nt": (_I, [C.POINTER(GemmArgs), _I, _P]),
-    "lidk_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "lidk_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lidk_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "lidk_attn_bwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lidk_attn_ldp": (_I, [_I, _I, _I]),
+    "lidk_selftest_tr16": (_I, [_P, _P, _P]),
     "lidk_glu_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "lidk_glu_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "lidk_dwconv_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -65,7 +67,7 @@ SIGNATURES = {
     "lidk_ctc_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "lidk_lid_score": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "lidk_novograd_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P]),
-    "lidk_cast_weights": (_I, [_P, _P, _P, _I, _I, _P]),
+    "lidk_cast_weights": (_I, [_P, _P, _P, _I, _L, _I, _P]),
 }
 
 _lib = None

@@ -46,7 +46,8 @@ class _BlockParams:
                          wqkv=eng.wview_qkv(a + ".fn"), dwqkv=eng.gview_qkv(a + ".fn"),
                          wo=w(a + ".fn.to_out.weight"), bo=v(a + ".fn.to_out.bias"),
                          dwo=g(a + ".fn.to_out.weight"), dbo=g(a + ".fn.to_out.bias"),
-                         emb=v(a + ".fn.rel_pos_emb.weight"), demb=g(a + ".fn.rel_pos_emb.weight"))
+                         emb=v(a + ".fn.rel_pos_emb.weight"), demb=g(a + ".fn.rel_pos_emb.weight"),
+                         embT=eng.wview(a + ".fn.rel_pos_emb.weight")[0])
         c = p + ".conv.net"
         self.conv = dict(ln_w=v(c + ".0.weight"), ln_b=v(c + ".0.bias"), dln_w=g(c + ".0.weight"), dln_b=g(c + ".0.bias"),
                          w1=w(c + ".2.weight"), b1=v(c + ".2.bias"), dw1=g(c + ".2.weight"), db1=g(c + ".2.bias"),
@@ -71,7 +72,8 @@ class _BlockBuf:
         self.mean = [f(M) for _ in range(5)]
         self.rstd = [f(M) for _ in range(5)]
         self.h1, self.a1, self.u1, self.x1 = e(M, d), e(M, ff), e(M, ff), f(M, d)
-        self.h2, self.qkv, self.probs, self.o, self.x2 = e(M, d), e(M, 3 * inner), e(B, heads, T, T), e(M, inner), f(M, d)
+        self.h2, self.qkv, self.o, self.x2 = e(M, d), e(M, 3 * inner), e(M, inner), f(M, d)
+        self.probs = e(B, heads, T, eng.k.attn_ldp(T, dh, dt))
         self.h3, self.y, self.g, self.c, self.s, self.x3 = e(M, d), e(M, 2 * ci), e(M, ci), e(M, ci), e(M, ci), f(M, d)
         self.bn_mean, self.bn_rstd = f(ci), f(ci)
         self.h4, self.a4, self.u4, self.x4 = e(M, d), e(M, ff), e(M, ff), f(M, d)
@@ -240,6 +242,11 @@ class Engine:
 
         skip = set()
         for s in self.specs:
+            if s.kind == "emb":                                   # T-typed copy of the relative embeddings (MFMA attention)
+                w_off, off = off, off + _ceil(s.numel, ALIGN)
+                mats.append([s.offset, s.shape[0], s.shape[1], w_off, -1, 0])
+                views[s.name] = (w_off, -1, s.shape[0], s.shape[1], 0)
+                continue
             if s.kind != "w" or s.name in skip:
                 continue
             if s.name.endswith(".to_q.weight"):
@@ -252,10 +259,11 @@ class Engine:
         c3 = self.by_name["model.featurizer.sub_sampling.sub_sampling.0.weight"]
         self._c3_off, off = off, off + _ceil(c3.shape[0] * 3 * c3.shape[1], ALIGN)
         self.wT = torch.zeros(off, device=self.device, dtype=self.act_dtype)
-        self.mats = torch.tensor(mats, dtype=torch.int64)
+        self.mats, self.mat_tiles = self.k.build_cast_table(mats, self.device)
         self._wviews = {}
         for key, (w_off, t_off, n, k, ldt) in views.items():
-            self._wviews[key] = (self.wT[w_off:w_off + n * k].view(n, k), self.wT[t_off:t_off + k * ldt].view(k, ldt))
+            self._wviews[key] = (self.wT[w_off:w_off + n * k].view(n, k),
+                                 self.wT[t_off:t_off + k * ldt].view(k, ldt) if t_off >= 0 else None)
         self.w_conv3 = self.wT[self._c3_off:self._c3_off + c3.shape[0] * 3 * c3.shape[1]].view(c3.shape[0], 3 * c3.shape[1])
         fz = "model.featurizer"
         self.enc_params = [_BlockParams(self, f"{fz}.encoders.{i}", self.cfg.heads, self.cfg.dim_head)
@@ -268,7 +276,7 @@ class Engine:
 
     def refresh_weights(self):
         """f32 master -> T operands (after an optimizer step, load_state_dict or reset)."""
-        self.k.cast_weights(self.flat, self.wT, self.mats)
+        self.k.cast_weights(self.flat, self.wT, self.mats, self.mat_tiles)
         c3 = self.pview("model.featurizer.sub_sampling.sub_sampling.0.weight")       # [Co][Ci][3] -> [Co][k*Ci+ci]
         self.w_conv3.copy_(c3.permute(0, 2, 1).reshape(c3.shape[0], -1))             # 19 K elements: layout glue, not math
 
@@ -305,7 +313,7 @@ class Engine:
         A = bp.attn
         self.k.layernorm_fwd(bb.x1, A["ln_w"], A["ln_b"], yT=bb.h2, mean=bb.mean[1], rstd=bb.rstd[1])
         self.k.gemm_nt(bb.h2, A["wqkv"][0], bb.qkv)
-        self.k.attn_fwd(bb.qkv, A["emb"], bb.o, bb.probs, B, T, bp.heads, bp.dh)
+        self.k.attn_fwd(bb.qkv, A["emb"], bb.o, bb.probs, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
         self.k.gemm_nt(bb.o, A["wo"][0], bb.x2, bias=A["bo"], res=bb.x1)
         C = bp.conv
         ci, K = C["dw"].shape[0], C["dw"].shape[2]
@@ -455,7 +463,7 @@ class Engine:
         do = w.dmid.view(-1)[:M * inner].view(M, inner)
         self.k.gemm_nt(w.dyT, A["wo"][1], do, N=inner, K=d)
         dqkv = w.dbig.view(-1)[:M * 3 * inner].view(M, 3 * inner)
-        self.k.attn_bwd(bb.qkv, A["emb"], bb.probs, do, dqkv, A["demb"], w.dsc, B, T, bp.heads, bp.dh)
+        self.k.attn_bwd(bb.qkv, A["emb"], bb.probs, do, dqkv, A["demb"], w.dsc, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
         self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
         self.k.gemm_nt(dqkv, A["wqkv"][1], w.dh, N=d, K=3 * inner)
         self.k.layernorm_bwd(w.dh, bb.x1, bb.mean[1], bb.rstd[1], A["ln_w"], w.partial, dres=dx2, dx=a, dxT=w.dyT,

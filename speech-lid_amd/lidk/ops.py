@@ -185,16 +185,25 @@ def gemm_nt(A, B, out, bias=None, act=L.ACT_NONE, alpha=1.0, res=None, out2=None
 
 
 # ----------------------------------------------------------------------------------------------- attention
-def attn_fwd(qkv, rel_emb, out, probs, B, T, heads, dh):
-    max_pos = (rel_emb.shape[0] - 1) // 2
-    check(lib().lidk_attn_fwd(_p(qkv), _p(rel_emb), _p(out), _p(probs), B, T, heads, dh, max_pos, _code(qkv), _stream()),
-          "attn_fwd")
+def attn_ldp(T, dh, dtype):
+    """Row stride of the probs buffer for this (T, dh, dtype): padded to 32 when the MFMA kernels apply."""
+    return lib().lidk_attn_ldp(T, dh, dtype_code(dtype))
 
 
-def attn_bwd(qkv, rel_emb, probs, dout, dqkv, drel_emb, dscores, B, T, heads, dh):
+def attn_fwd(qkv, rel_emb, out, probs, B, T, heads, dh, rel_emb_T=None):
     max_pos = (rel_emb.shape[0] - 1) // 2
-    check(lib().lidk_attn_bwd(_p(qkv), _p(rel_emb), _p(probs), _p(dout), _p(dqkv), _p(drel_emb), _p(dscores), B, T, heads,
-                              dh, max_pos, _code(qkv), _stream()), "attn_bwd")
+    check(lib().lidk_attn_fwd(_p(qkv), _p(rel_emb), _p(rel_emb_T), _p(out), _p(probs), probs.shape[-1], B, T, heads, dh,
+                              max_pos, _code(qkv), _stream()), "attn_fwd")
+
+
+def attn_bwd(qkv, rel_emb, probs, dout, dqkv, drel_emb, dscores, B, T, heads, dh, rel_emb_T=None):
+    max_pos = (rel_emb.shape[0] - 1) // 2
+    check(lib().lidk_attn_bwd(_p(qkv), _p(rel_emb), _p(rel_emb_T), _p(probs), probs.shape[-1], _p(dout), _p(dqkv),
+                              _p(drel_emb), _p(dscores), B, T, heads, dh, max_pos, _code(qkv), _stream()), "attn_bwd")
+
+
+def selftest_tr16(inp, out):
+    check(lib().lidk_selftest_tr16(_p(inp), _p(out), _stream()), "selftest_tr16")
 
 
 # ----------------------------------------------------------------------------------------------- conv module
@@ -292,9 +301,17 @@ def novograd_step(params, grads, exp_avg, exp_avg_sq, work, n_tensors, lr, betas
                                    _p(total_norm), _stream()), "novograd_step")
 
 
-def cast_weights(params, wT, mats_host):
-    """mats_host: CPU int64 tensor (n, 6) — the only host pointer in the ABI."""
-    if mats_host.is_cuda or mats_host.dtype != torch.int64 or not mats_host.is_contiguous():
-        raise LidkError("cast_weights: mats must be a contiguous CPU int64 tensor")
-    check(lib().lidk_cast_weights(_p(params), _p(wT), mats_host.data_ptr(), mats_host.shape[0], _code(wT), _stream()),
+def cast_weights(params, wT, mats, total_tiles):
+    """mats: device int64 (n, 8) tile table built by ``build_cast_table``."""
+    check(lib().lidk_cast_weights(_p(params), _p(wT), _p(mats), mats.shape[0], int(total_tiles), _code(wT), _stream()),
           "cast_weights")
+
+
+def build_cast_table(entries, device):
+    """entries: iterable of (src_off, R, C, w_off, t_off, ldt) -> (device table (n, 8) int64, total 32x32 tiles)."""
+    rows, tiles = [], 0
+    for src, R, C, w_off, t_off, ldt in entries:
+        tx = (C + 31) // 32
+        rows.append([src, R, C, w_off, t_off, ldt or R, tiles, tx])
+        tiles += ((R + 31) // 32) * tx
+    return torch.tensor(rows, dtype=torch.int64, device=device), tiles

@@ -131,14 +131,18 @@ def _attn(qkv, emb, B, T, H, dh):
     return (p @ v).transpose(1, 2).reshape(B * T, inner), p
 
 
-def attn_fwd(qkv, rel_emb, out, probs, B, T, heads, dh):
+def attn_ldp(T, dh, dtype):
+    return T
+
+
+def attn_fwd(qkv, rel_emb, out, probs, B, T, heads, dh, rel_emb_T=None):
     o, p = _attn(qkv, rel_emb, B, T, heads, dh)
     out.copy_(o.to(out.dtype))
-    probs.copy_(p.to(probs.dtype))
+    probs[..., :T].copy_(p.to(probs.dtype))
 
 
 @torch.enable_grad()
-def attn_bwd(qkv, rel_emb, probs, dout, dqkv, drel_emb, dscores, B, T, heads, dh):
+def attn_bwd(qkv, rel_emb, probs, dout, dqkv, drel_emb, dscores, B, T, heads, dh, rel_emb_T=None):
     q = _f(qkv).detach().clone().requires_grad_()
     e = rel_emb.detach().clone().requires_grad_()
     o, _ = _attn(q, e, B, T, heads, dh)
@@ -255,8 +259,12 @@ def im2col_k3s2(mel, out, T):
     out.copy_(cols.to(out.dtype))
 
 
-def cast_weights(params, wT, mats_host):
-    for src, R, C, w_off, t_off, ldt in mats_host.tolist():
+def build_cast_table(entries, device):
+    return torch.tensor([list(e) + [0, 0] for e in entries], dtype=torch.int64), 1
+
+
+def cast_weights(params, wT, mats, total_tiles):
+    for src, R, C, w_off, t_off, ldt, _, _ in mats.tolist():
         W = params[src:src + R * C].view(R, C)
         if w_off >= 0:
             wT[w_off:w_off + R * C] = W.reshape(-1).to(wT.dtype)

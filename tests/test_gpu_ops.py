@@ -197,10 +197,13 @@ def _attn_ref(qkv, emb, B, T, H, dh):
     return (p @ v).transpose(1, 2).reshape(B * T, inner), p
 
 
+@pytest.mark.parametrize("path", ["v1", "mfma"])
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("B,T,H,dh,maxpos", [(2, 51, 4, 16, 512), (2, 151, 4, 64, 512), (1, 70, 8, 32, 512),
-                                             (2, 51, 8, 8, 512), (2, 60, 2, 16, 20)])
-def test_attention_fwd_bwd(dt, B, T, H, dh, maxpos):
+                                             (2, 51, 8, 8, 512), (2, 60, 2, 16, 20), (2, 100, 2, 64, 30), (3, 33, 2, 32, 512)])
+def test_attention_fwd_bwd(dt, B, T, H, dh, maxpos, path):
+    if path == "mfma" and (dt != torch.bfloat16 or dh not in (32, 64)):
+        pytest.skip("MFMA attention kernels are bf16, dh in {32, 64}")
     inner = H * dh
     qkv = (0.7 * torch.randn(B * T, 3 * inner, generator=g(20)))
     emb = (0.5 * torch.randn(2 * maxpos + 1, dh, generator=g(21)))
@@ -210,18 +213,37 @@ def test_attention_fwd_bwd(dt, B, T, H, dh, maxpos):
     dout = torch.randn(B * T, inner, generator=g(22))
     out_ref.backward(rt(dout, dt))
     qd, ed = dev(qkv, dt), dev(emb)
+    embT = dev(emb, dt) if path == "mfma" else None
+    ldp = ops.attn_ldp(T, dh, dt) if path == "mfma" else T
+    if path == "mfma":
+        assert ldp == (T + 31) // 32 * 32
     out = torch.empty(B * T, inner, device=DEV, dtype=dt)
-    probs = torch.empty(B, H, T, T, device=DEV, dtype=dt)
-    ops.attn_fwd(qd, ed, out, probs, B, T, H, dh)
-    check("attn_probs", probs, p_ref, tol(dt, 2e-6, 4e-3))
-    check("attn_out", out, out_ref, tol(dt, 1e-5, 1.5e-2))
+    probs = torch.zeros(B, H, T, ldp, device=DEV, dtype=dt)
+    ops.attn_fwd(qd, ed, out, probs, B, T, H, dh, rel_emb_T=embT)
+    check(f"attn_probs[{path}]", probs[..., :T], p_ref, tol(dt, 2e-6, 4e-3))
+    if ldp > T:
+        assert float(probs[..., T:].float().abs().max()) == 0.0          # padded keys get exactly zero probability
+    check(f"attn_out[{path}]", out, out_ref, tol(dt, 1e-5, 1.5e-2))
     dqkv = torch.zeros(B * T, 3 * inner, device=DEV, dtype=dt)
     demb = torch.zeros_like(ed)
     dsc = torch.empty(B, H, T, T, device=DEV)
-    ops.attn_bwd(qd, ed, probs, dev(dout, dt), dqkv, demb, dsc, B, T, H, dh)
+    ops.attn_bwd(qd, ed, probs, dev(dout, dt), dqkv, demb, dsc, B, T, H, dh, rel_emb_T=embT)
     gs = float(qkv_r.grad.abs().max())
-    check("attn_dqkv", dqkv, qkv_r.grad, tol(dt, 2e-5 * max(1, gs), 3e-2 * max(1, gs)))
-    check("attn_demb", demb, emb_r.grad, tol(dt, 1e-4, 6e-2) * max(1.0, float(emb_r.grad.abs().max())))
+    check(f"attn_dqkv[{path}]", dqkv, qkv_r.grad, tol(dt, 2e-5 * max(1, gs), 3e-2 * max(1, gs)))
+    check(f"attn_demb[{path}]", demb, emb_r.grad, tol(dt, 1e-4, 6e-2) * max(1.0, float(emb_r.grad.abs().max())))
+
+
+def test_tr16_hardware_mapping():
+    """Pins the ds_read_b64_tr_b16 lane mapping (MI355X guide, T10) that the transposed-operand kernels are written against."""
+    tile = (torch.arange(8)[:, None] * 100 + torch.arange(64)[None, :]).to(torch.int16)
+    out = torch.zeros(64, 2, 4, dtype=torch.int16, device=DEV)
+    ops.selftest_tr16(dev(tile), out)
+    got = out.cpu()
+    for lane in range(64):
+        gidx, idx = lane >> 4, lane & 15
+        for half in range(2):
+            want = [int(tile[q + 4 * half, 16 * gidx + idx]) for q in range(4)]
+            assert got[lane, half].tolist() == want, (lane, half, got[lane, half].tolist(), want)
 
 
 # ------------------------------------------------------------------------------------------------ conv module
@@ -455,8 +477,12 @@ def test_novograd_clip_and_cast():
     # cast_weights: W and W^T in the T arena
     for dt in DT:
         wT = torch.zeros(2 * 64 * 48 + 16, device=DEV, dtype=dt)
-        mats = torch.tensor([[offs[0], 64, 48, 0, 64 * 48 + 8, 0]], dtype=torch.int64)
-        ops.cast_weights(pd, wT, mats)
+        mats, tiles = ops.build_cast_table([(offs[0], 64, 48, 0, 64 * 48 + 8, 0), (offs[4], 16, 16, -1, 2 * 64 * 48 + 16, 24)], DEV)
+        wT = torch.zeros(2 * 64 * 48 + 16 + 16 * 24, device=DEV, dtype=dt)
+        ops.cast_weights(pd, wT, mats, tiles)
+        W4 = pd[offs[4]:offs[4] + 256].reshape(16, 16).cpu()
+        t4 = wT[2 * 64 * 48 + 16:].reshape(16, 24).cpu()
+        assert torch.equal(t4[:, :16], W4.t().contiguous().to(dt)) and float(t4[:, 16:].abs().max()) == 0.0   # padded ld
         W = pd[offs[0]:offs[0] + 64 * 48].reshape(64, 48).cpu()
         assert torch.equal(wT[:64 * 48].reshape(64, 48).cpu(), W.to(dt))
         assert torch.equal(wT[64 * 48 + 8:64 * 48 + 8 + 64 * 48].reshape(48, 64).cpu(), W.t().contiguous().to(dt))
