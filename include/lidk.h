@@ -105,7 +105,7 @@ int lidk_gemm_nt(const lidk_gemm_args* args, int dtype, void* stream);
  * probs [B][heads][T][ldp] (T) is saved for backward. */
 int lidk_attn_fwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, void* out, void* probs, int ldp, int B, int T,
                   int heads, int dh, int max_pos, int dtype, void* stream);
-/* dqkv [B*T][3*heads*dh] (T) written; drel_emb += (atomic f32).  dscores: scratch [B][heads][T][T] f32. */
+/* dqkv [B*T][3*heads*dh] (T) written; drel_emb += (atomic f32).  dscores: scratch of B*heads*T*ldp floats. */
 int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, const void* probs, int ldp, const void* dout,
                   void* dqkv, float* drel_emb, float* dscores, int B, int T, int heads, int dh, int max_pos, int dtype,
                   void* stream);

@@ -365,6 +365,276 @@ extern "C" int lidk_attn_ldp(int T_, int dh, int dtype) {
 }
 
 
+// =====================================================================================================================
+// MFMA backward (bf16).  Operands whose contraction index is the ROW index of a row-major LDS tile are read with
+// ds_read_b64_tr_b16 (tr_frag): lane (fq, fr) gets X[k0 + 8*fq + jj][n0 + fr], jj = 0..7 — the 16x16x32 A/B fragment of
+// X^T — from two transposed reads, so nothing is ever transposed in memory.
+//   K1 (row blocks): dP = dO.V^T ; delta = rowsum(P*dP) ; dS = P*(dP - delta) -> dS (bf16, global + LDS)
+//                    dq = scale * (dS.K + skew(dS).E)
+//   K2 (per b,h)   : dv = P^T.dO ; dk = scale * dS^T.Q ; dE[r] += scale * sum_i dS[i][i-r] q[i]
+// =====================================================================================================================
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* X, int ld, int k0, int n0, int fq, int fr) {
+  const bf16* p0 = X + (size_t)(k0 + 8 * fq + (fr >> 2)) * ld + n0 + 4 * (fr & 3);
+  union { struct { s16x4_t lo, hi; } h; bf16x8 v; } u;
+  u.h.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)p0);
+  u.h.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p0 + 4 * ld));
+  return u.v;
+}
+
+template <int DH>
+__global__ void __launch_bounds__(256)
+attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT, const bf16* __restrict__ probs,
+                          const bf16* __restrict__ dout, bf16* __restrict__ dqkv, bf16* __restrict__ dsT, AttGeom g,
+                          int ldp, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int KS = DH / 32, LDK = DH + 8, CH = DH / 8;
+  const int T_ = g.T, Tp = (T_ + 31) / 32 * 32, NJ = Tp / 16, LDV = Tp + 8, NE = 2 * Tp + 8;
+  bf16* Ks = reinterpret_cast<bf16*>(smem);
+  bf16* Vs = Ks + Tp * LDK;
+  bf16* Es = Vs + Tp * LDK;
+  bf16* Pall = Es + NE * LDK;
+  bf16* Sall = Pall + 4 * 16 * LDV;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / g.H, h = blockIdx.x % g.H;
+  const bf16* base = qkv + (size_t)b * T_ * g.ld + h * DH;
+  for (int c = tid; c < Tp * CH; c += 256) {
+    int j = c / CH, dc = (c % CH) * 8;
+    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+    if (j < T_) {
+      kv = *reinterpret_cast<const uint4*>(base + (size_t)j * g.ld + g.inner + dc);
+      vv = *reinterpret_cast<const uint4*>(base + (size_t)j * g.ld + 2 * g.inner + dc);
+    }
+    *reinterpret_cast<uint4*>(&Ks[j * LDK + dc]) = kv;
+    *reinterpret_cast<uint4*>(&Vs[j * LDK + dc]) = vv;
+  }
+  for (int c = tid; c < NE * CH; c += 256) {
+    int e = c / CH, dc = (c % CH) * 8;
+    int r = max(-g.max_pos, min(g.max_pos, e - Tp)) + g.max_pos;
+    *reinterpret_cast<uint4*>(&Es[e * LDK + dc]) = *reinterpret_cast<const uint4*>(embT + (size_t)r * DH + dc);
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  bf16* Pw = Pall + wave * 16 * LDV;
+  bf16* Sw = Sall + wave * 16 * LDV;
+  const int nrb = (T_ + 15) / 16;
+  const size_t bh = (size_t)(b * g.H + h) * T_;
+  for (int rb = wave; rb < nrb; rb += 4) {
+    const int i0 = rb * 16;
+    // P rows of this block -> LDS (16-byte chunks); rows >= T are zero
+    for (int c = lane; c < 16 * (Tp / 8); c += 64) {
+      int row = c / (Tp / 8), col = (c % (Tp / 8)) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i0 + row < T_) v = *reinterpret_cast<const uint4*>(probs + (bh + i0 + row) * ldp + col);
+      *reinterpret_cast<uint4*>(&Pw[row * LDV + col]) = v;
+    }
+    bf16x8 dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i0 + fr < T_) v = *reinterpret_cast<const uint4*>(dout + (size_t)(b * T_ + i0 + fr) * g.inner + h * DH + ks * 32 + fq * 8);
+      dof[ks] = *reinterpret_cast<bf16x8*>(&v);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float dp[AF_NJ_MAX][4];
+    float delta[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+      if (jt < NJ) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vs[(jt * 16 + fr) * LDK + ks * 32 + fq * 8]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[ks], vf, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dp[jt][r] = acc[r];
+          delta[r] = fmaf((float)Pw[(fq * 4 + r) * LDV + jt * 16 + fr], acc[r], delta[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) delta[r] += __shfl_xor(delta[r], o, 64);
+    }
+#pragma unroll
+    for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+      if (jt < NJ) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = (float)Pw[(fq * 4 + r) * LDV + jt * 16 + fr];
+          Sw[(fq * 4 + r) * LDV + jt * 16 + fr] = (bf16)(p * (dp[jt][r] - delta[r]));
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // dS rows -> global (consumed by the column kernel)
+    for (int c = lane; c < 16 * (Tp / 8); c += 64) {
+      int row = c / (Tp / 8), col = (c % (Tp / 8)) * 8;
+      if (i0 + row < T_) *reinterpret_cast<uint4*>(dsT + (bh + i0 + row) * ldp + col) = *reinterpret_cast<const uint4*>(&Sw[row * LDV + col]);
+    }
+    // dq = scale * (dS.K + skew(dS).E)
+    f32x4 aq[DH / 16];
+#pragma unroll
+    for (int nt = 0; nt < DH / 16; ++nt) aq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < Tp; k0 += 32) {
+      bf16x8 sf = *reinterpret_cast<const bf16x8*>(&Sw[fr * LDV + k0 + fq * 8]);
+#pragma unroll
+      for (int nt = 0; nt < DH / 16; ++nt)
+        aq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, tr_frag(Ks, LDK, k0, nt * 16, fq, fr), aq[nt], 0, 0, 0);
+    }
+    for (int jt = 0; jt < NJ; ++jt) {
+      const int j0 = jt * 16;
+      const int eb = i0 - j0 - 16 + Tp;                 // Es row of offset r0 = i0 - j0 - 16;  k index c' <-> r = r0 + c'
+      union { bf16 e[8]; bf16x8 v; } sk;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int c = fr - (8 * fq + jj) + 16;           // column of the dS tile that has offset r0 + c' on row fr
+        const bf16 val = Sw[fr * LDV + j0 + (c & 15)];
+        sk.e[jj] = (c >= 0 && c <= 15) ? val : (bf16)0.f;
+      }
+#pragma unroll
+      for (int nt = 0; nt < DH / 16; ++nt)
+        aq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sk.v, tr_frag(Es, LDK, eb, nt * 16, fq, fr), aq[nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < DH / 16; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = i0 + fq * 4 + r;
+        if (i < T_) dqkv[(size_t)(b * T_ + i) * g.ld + h * DH + nt * 16 + fr] = (bf16)(aq[nt][r] * scale);
+      }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int DH>
+__global__ void __launch_bounds__(256)
+attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ probs, const bf16* __restrict__ dout,
+                          const bf16* __restrict__ dsT, bf16* __restrict__ dqkv, float* __restrict__ demb, AttGeom g, int ldp,
+                          float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int LDK = DH + 8, CH = DH / 8;
+  const int T_ = g.T, Tp = (T_ + 31) / 32 * 32, NJ = Tp / 16, LDV = Tp + 8;
+  bf16* X = reinterpret_cast<bf16*>(smem);             // [Tp][LDV]: P, then dS
+  bf16* Y = X + Tp * LDV;                               // [Tp][LDK]: dO, then Q
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.x / g.H, h = blockIdx.x % g.H;
+  const size_t bh = (size_t)(b * g.H + h) * T_;
+  auto stage = [&](const bf16* sq, const bf16* rows, size_t row_stride) {
+    for (int c = tid; c < Tp * (Tp / 8); c += 256) {
+      int i = c / (Tp / 8), col = (c % (Tp / 8)) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i < T_) v = *reinterpret_cast<const uint4*>(sq + (bh + i) * ldp + col);
+      *reinterpret_cast<uint4*>(&X[i * LDV + col]) = v;
+    }
+    for (int c = tid; c < Tp * CH; c += 256) {
+      int i = c / CH, dc = (c % CH) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i < T_) v = *reinterpret_cast<const uint4*>(rows + (size_t)i * row_stride + dc);
+      *reinterpret_cast<uint4*>(&Y[i * LDK + dc]) = v;
+    }
+  };
+  // ---- phase A: dv[j][d] = sum_i P[i][j] dO[i][d]
+  stage(probs, dout + (size_t)b * T_ * g.inner + h * DH, g.inner);
+  __syncthreads();
+  for (int jt = wave; jt < NJ; jt += 4) {
+    f32x4 acc[DH / 16];
+#pragma unroll
+    for (int nt = 0; nt < DH / 16; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < Tp; k0 += 32) {
+      bf16x8 af = tr_frag(X, LDV, k0, jt * 16, fq, fr);
+#pragma unroll
+      for (int nt = 0; nt < DH / 16; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, tr_frag(Y, LDK, k0, nt * 16, fq, fr), acc[nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < DH / 16; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int j = jt * 16 + fq * 4 + r;
+        if (j < T_) dqkv[(size_t)(b * T_ + j) * g.ld + 2 * g.inner + h * DH + nt * 16 + fr] = (bf16)acc[nt][r];
+      }
+  }
+  __syncthreads();
+  // ---- phase B: dk[j][d] = scale * sum_i dS[i][j] q[i][d] ; dE[r][d] += scale * sum_i dS[i][i-r] q[i][d]
+  stage(dsT, qkv + (size_t)b * T_ * g.ld + h * DH, g.ld);
+  __syncthreads();
+  const int n_rt = 2 * Tp / 16;                          // offset tiles covering r in [-Tp, Tp)
+  for (int item = wave; item < NJ + n_rt; item += 4) {
+    f32x4 acc[DH / 16];
+#pragma unroll
+    for (int nt = 0; nt < DH / 16; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (item < NJ) {
+      const int jt = item;
+      for (int k0 = 0; k0 < Tp; k0 += 32) {
+        bf16x8 af = tr_frag(X, LDV, k0, jt * 16, fq, fr);
+#pragma unroll
+        for (int nt = 0; nt < DH / 16; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, tr_frag(Y, LDK, k0, nt * 16, fq, fr), acc[nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < DH / 16; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int j = jt * 16 + fq * 4 + r;
+          if (j < T_) dqkv[(size_t)(b * T_ + j) * g.ld + g.inner + h * DH + nt * 16 + fr] = (bf16)(acc[nt][r] * scale);
+        }
+    } else {
+      const int rt = -Tp + 16 * (item - NJ);             // offsets rt .. rt+15
+      const int klo = max(0, rt) / 32 * 32, khi = min(Tp, rt + 15 + Tp);
+      for (int k0 = klo; k0 < khi; k0 += 32) {           // wave-uniform bounds: every lane runs the transposed reads
+        union { bf16 e[8]; bf16x8 v; } ga;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int i = k0 + 8 * fq + jj, col = i - rt - fr;    // dS[i][i - r], r = rt + fr
+          const bool ok = col >= 0 && col < Tp;
+          const bf16 val = X[i * LDV + (ok ? col : 0)];
+          ga.e[jj] = ok ? val : (bf16)0.f;
+        }
+#pragma unroll
+        for (int nt = 0; nt < DH / 16; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga.v, tr_frag(Y, LDK, k0, nt * 16, fq, fr), acc[nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int roff = rt + fq * 4 + r;
+        if (roff > -T_ && roff < T_) {
+          const int row = max(-g.max_pos, min(g.max_pos, roff)) + g.max_pos;
+#pragma unroll
+          for (int nt = 0; nt < DH / 16; ++nt) atomicAdd(&demb[(size_t)row * DH + nt * 16 + fr], acc[nt][r] * scale);
+        }
+      }
+    }
+  }
+}
+
+static size_t att_bwd_rows_mfma_lds(int T_, int dh) {
+  int Tp = (T_ + 31) / 32 * 32;
+  return (size_t)2 * ((size_t)2 * Tp * (dh + 8) + (size_t)(2 * Tp + 8) * (dh + 8) + (size_t)2 * 4 * 16 * (Tp + 8));
+}
+static size_t att_bwd_cols_mfma_lds(int T_, int dh) {
+  int Tp = (T_ + 31) / 32 * 32;
+  return (size_t)2 * ((size_t)Tp * (Tp + 8) + (size_t)Tp * (dh + 8));
+}
+
+template <int DH>
+static void att_bwd_mfma_launch(const void* qkv, const void* embT, const void* probs, int ldp, const void* dout, void* dqkv,
+                                float* demb, void* dsT, AttGeom g, hipStream_t s) {
+  const float scale = 1.0f / sqrtf((float)DH);
+  size_t l1 = att_bwd_rows_mfma_lds(g.T, DH), l2 = att_bwd_cols_mfma_lds(g.T, DH);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_rows_mfma_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
+  attn_bwd_rows_mfma_kernel<DH><<<g.B * g.H, 256, l1, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)probs,
+                                                           (const bf16*)dout, (bf16*)dqkv, (bf16*)dsT, g, ldp, scale);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_cols_mfma_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+  attn_bwd_cols_mfma_kernel<DH><<<g.B * g.H, 256, l2, s>>>((const bf16*)qkv, (const bf16*)probs, (const bf16*)dout,
+                                                           (const bf16*)dsT, (bf16*)dqkv, demb, g, ldp, scale);
+}
+
 // ------------------------------------------------------------------------------------ host side
 template <typename T>
 static size_t att_rows_lds(int T_, int dh) {
@@ -441,12 +711,17 @@ static int att_bwd_launch(const void* qkv, const float* rel_emb, const void* pro
 extern "C" int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, const void* probs, int ldp,
                              const void* dout, void* dqkv, float* drel_emb, float* dscores, int B, int T_, int heads, int dh,
                              int max_pos, int dtype, void* stream) {
-  (void)rel_emb_T;
   if (!qkv || !rel_emb || !probs || !dout || !dqkv || !drel_emb || !dscores || B <= 0 || T_ <= 0 || heads <= 0 || ldp < T_)
     return LIDK_ERR_ARG;
   if (!att_dh_ok(dh)) return LIDK_ERR_UNSUPPORTED;
   AttGeom g{B, T_, heads, dh, max_pos, heads * dh, 3 * heads * dh};
   hipStream_t s = as_stream(stream);
+  if (dtype == LIDK_BF16 && rel_emb_T && (dh == 32 || dh == 64) && ldp == (T_ + 31) / 32 * 32 && T_ <= 16 * AF_NJ_MAX &&
+      att_bwd_rows_mfma_lds(T_, dh) <= 160 * 1024 && att_bwd_cols_mfma_lds(T_, dh) <= 160 * 1024) {
+    if (dh == 64) att_bwd_mfma_launch<64>(qkv, rel_emb_T, probs, ldp, dout, dqkv, drel_emb, dscores, g, s);
+    else att_bwd_mfma_launch<32>(qkv, rel_emb_T, probs, ldp, dout, dqkv, drel_emb, dscores, g, s);
+    return launch_status();
+  }
   if (dtype == LIDK_BF16) return att_bwd_launch<bf16>(qkv, rel_emb, probs, ldp, dout, dqkv, drel_emb, dscores, g, s);
   if (dtype == LIDK_F32) return att_bwd_launch<float>(qkv, rel_emb, probs, ldp, dout, dqkv, drel_emb, dscores, g, s);
   return LIDK_ERR_ARG;

@@ -226,7 +226,7 @@ def test_attention_fwd_bwd(dt, B, T, H, dh, maxpos, path):
     check(f"attn_out[{path}]", out, out_ref, tol(dt, 1e-5, 1.5e-2))
     dqkv = torch.zeros(B * T, 3 * inner, device=DEV, dtype=dt)
     demb = torch.zeros_like(ed)
-    dsc = torch.empty(B, H, T, T, device=DEV)
+    dsc = torch.empty(B, H, T, (T + 31) // 32 * 32, device=DEV)
     ops.attn_bwd(qd, ed, probs, dev(dout, dt), dqkv, demb, dsc, B, T, H, dh, rel_emb_T=embT)
     gs = float(qkv_r.grad.abs().max())
     check(f"attn_dqkv[{path}]", dqkv, qkv_r.grad, tol(dt, 2e-5 * max(1, gs), 3e-2 * max(1, gs)))
