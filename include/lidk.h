@@ -99,6 +99,13 @@ typedef struct lidk_gemm_args {
 } lidk_gemm_args;
 int lidk_gemm_nt(const lidk_gemm_args* args, int dtype, void* stream);
 
+/* Weight-gradient GEMM ("TN"): C[N1][N2] (f32) += alpha * sum_{m<M} X[m][n1] * Y[m][n2]; colsum[n1] (f32, optional) += alpha *
+ * sum_m X[m][n1] (the bias gradient).  X [M][ldx], Y [M][ldy] are the activations as stored (T, row-major); rows are readable
+ * (zero padded) up to the next multiple of 8 columns; ldx, ldy % 8 == 0.  The contraction over M is split `splitk` ways with
+ * float atomics.  This is the autograd of every nn.Linear / 1x1 Conv1d weight on the path (dW = dY^T . X). */
+int lidk_gemm_tn(const void* X, int ldx, const void* Y, int ldy, float* C, int ldc, float* colsum, int M, int N1, int N2,
+                 float alpha, int splitk, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ Attention core with Shaw relative positions (lid/conformer.py:117-148)
  * qkv [B*T][3*heads*dh] (T): q | k | v column blocks, head h at columns h*dh.. within each.  rel_emb [2*max_pos+1][dh] f32.
  * scores = (q.k^T + q.rel_emb[clamp(i-j)+max_pos]) * dh^-0.5 ; probs = softmax_j ; out = probs.v -> [B*T][heads*dh] (T).

@@ -373,16 +373,6 @@ extern "C" int lidk_attn_ldp(int T_, int dh, int dtype) {
 //                    dq = scale * (dS.K + skew(dS).E)
 //   K2 (per b,h)   : dv = P^T.dO ; dk = scale * dS^T.Q ; dE[r] += scale * sum_i dS[i][i-r] q[i]
 // =====================================================================================================================
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ bf16x8 tr_frag(const bf16* X, int ld, int k0, int n0, int fq, int fr) {
-  const bf16* p0 = X + (size_t)(k0 + 8 * fq + (fr >> 2)) * ld + n0 + 4 * (fr & 3);
-  union { struct { s16x4_t lo, hi; } h; bf16x8 v; } u;
-  u.h.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)p0);
-  u.h.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p0 + 4 * ld));
-  return u.v;
-}
-
 template <int DH>
 __global__ void __launch_bounds__(256)
 attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT, const bf16* __restrict__ probs,

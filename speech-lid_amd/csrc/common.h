@@ -44,6 +44,18 @@ __device__ __forceinline__ void store4(bf16* p, float4 v) {
   *reinterpret_cast<uint2*>(p) = t.u;
 }
 
+// Fragment of X^T for v_mfma_f32_16x16x32_bf16 from a ROW-MAJOR LDS tile X[k][n] (leading dimension ld elements, ld*2 % 8 == 0):
+// lane (fq = lane>>4, fr = lane&15) receives X[k0 + 8*fq + jj][n0 + fr], jj = 0..7, through two ds_read_b64_tr_b16.  EXEC must be
+// all ones at the call (the transposed read gathers across lanes); lane mapping pinned by lidk_selftest_tr16.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* X, int ld, int k0, int n0, int fq, int fr) {
+  const bf16* p0 = X + (size_t)(k0 + 8 * fq + (fr >> 2)) * ld + n0 + 4 * (fr & 3);
+  union { struct { s16x4_t lo, hi; } h; bf16x8 v; } u;
+  u.h.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)p0);
+  u.h.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p0 + 4 * ld));
+  return u.v;
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? LIDK_OK : LIDK_ERR_LAUNCH; }
 

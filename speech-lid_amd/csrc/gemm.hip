@@ -39,6 +39,38 @@ __device__ __forceinline__ void epi_store(const Epi& e, int m, int n, float acc)
   else ((T*)e.out)[(size_t)m * e.ldo + n] = from_f<T>(v);
 }
 
+// 4 consecutive columns n..n+3 of row m (n % 4 == 0): 16-byte loads of bias/res/aux and one 8/16-byte store.  Falls back to
+// the scalar form at the N tail or when a leading dimension is not a multiple of 4.
+template <typename T>
+__device__ __forceinline__ void epi_store4(const Epi& e, int m, int n, int N, float4 acc) {
+  const bool vec = (n + 3 < N) && !(e.ldo & 3) && !e.atomic && (!e.res || !(e.ldres & 3)) && (!e.out2 || !(e.ldo2 & 3)) &&
+                   (!e.aux || !(e.ldaux & 3));
+  if (!vec) {
+    const float a[4] = {acc.x, acc.y, acc.z, acc.w};
+    for (int i = 0; i < 4; ++i) if (n + i < N) epi_store<T>(e, m, n + i, a[i]);
+    return;
+  }
+  float4 v = acc;
+  if (e.bias) { float4 b = load4(e.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+  if (e.act == LIDK_ACT_SWISH) {
+    if (e.out2) store4((T*)e.out2 + (size_t)m * e.ldo2 + n, v);
+    v.x *= sigmoidf_(v.x); v.y *= sigmoidf_(v.y); v.z *= sigmoidf_(v.z); v.w *= sigmoidf_(v.w);
+  } else if (e.act == LIDK_ACT_RELU) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  } else if (e.act == LIDK_ACT_SWISH_GRAD) {
+    float4 a = load4((const T*)e.aux + (size_t)m * e.ldaux + n);
+    float s;
+    s = sigmoidf_(a.x); v.x *= s * (1.f + a.x * (1.f - s));
+    s = sigmoidf_(a.y); v.y *= s * (1.f + a.y * (1.f - s));
+    s = sigmoidf_(a.z); v.z *= s * (1.f + a.z * (1.f - s));
+    s = sigmoidf_(a.w); v.w *= s * (1.f + a.w * (1.f - s));
+  }
+  v.x *= e.alpha; v.y *= e.alpha; v.z *= e.alpha; v.w *= e.alpha;
+  if (e.res) { float4 r = load4(e.res + (size_t)m * e.ldres + n); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+  if (e.out_f32) store4((float*)e.out + (size_t)m * e.ldo + n, v);
+  else store4((T*)e.out + (size_t)m * e.ldo + n, v);
+}
+
 // ------------------------------------------------------------------------------------ bf16 MFMA kernel
 #define BK 64
 #define LDS_STRIDE (BK + 8)   // bf16 elements; 144-byte rows keep 16-byte alignment and break the power-of-2 stride
@@ -49,8 +81,11 @@ gemm_nt_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int 
                     int kchunk, Epi e) {
   constexpr int TM = BM / 32, TN = BN / 32;        // 16x16 tiles per wave along M / N
   constexpr int CA = BM / 32, CB = BN / 32;        // 16-byte chunks per thread per K tile
-  __shared__ __attribute__((aligned(16))) bf16 As[BM * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) bf16 Bs[BN * LDS_STRIDE];
+  constexpr int WM = BM / 2, WN = BN / 2, CST = WN + 4;          // per-wave C tile, f32, padded rows
+  constexpr int AB_BYTES = (BM + BN) * LDS_STRIDE * 2, C_BYTES = 4 * WM * CST * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES];
+  bf16* As = reinterpret_cast<bf16*>(smem);
+  bf16* Bs = As + BM * LDS_STRIDE;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -118,16 +153,33 @@ gemm_nt_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int 
     if (more) { lstore(); __syncthreads(); }
   }
 
+  // Epilogue: accumulators -> this wave's f32 LDS tile -> row-major pass with 16-byte accesses (the K loop ended with a
+  // workgroup barrier, so the A/B tiles are dead and the space is reused).
+  float* Cw = reinterpret_cast<float*>(smem) + wid * WM * CST;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int m = m0 + wm * (BM / 2) + i * 16 + fq * 4 + r;
-        int n = n0 + wn * (BN / 2) + j * 16 + fr;
-        if (m < M && n < N) epi_store<bf16>(e, m, n, acc[i][j][r]);
-      }
+      for (int r = 0; r < 4; ++r) Cw[(i * 16 + fq * 4 + r) * CST + j * 16 + fr] = acc[i][j][r];
+  __builtin_amdgcn_wave_barrier();
+  if (e.atomic) {
+    // split-K accumulation: consecutive lanes -> consecutive columns, so one wave-instruction adds to 64 (or 2 x 32)
+    // contiguous floats - the access shape float atomics run fastest on (MI355X_MICROARCH.md, "Global float atomics")
+    constexpr int RPA = 64 / WN;
+    for (int row = lane / WN; row < WM; row += RPA) {
+      const int col = lane % WN, m = m0 + wm * WM + row, n = n0 + wn * WN + col;
+      if (m < M && n < N) atomicAdd(&((float*)e.out)[(size_t)m * e.ldo + n], Cw[row * CST + col] * e.alpha);
+    }
+    return;
+  }
+  constexpr int LPR = WN / 4, RPI = 64 / LPR;                     // lanes per row, rows per wave-instruction
+  const int crow = lane / LPR, ccol = (lane % LPR) * 4;
+#pragma unroll 4
+  for (int row = crow; row < WM; row += RPI) {
+    const int m = m0 + wm * WM + row, n = n0 + wn * WN + ccol;
+    if (m < M && n < N) epi_store4<bf16>(e, m, n, N, *reinterpret_cast<const float4*>(&Cw[row * CST + ccol]));
+  }
 }
 
 // ------------------------------------------------------------------------------------ f32 kernel (parity mode)
@@ -199,6 +251,199 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
     dim3 grid(cdiv(g->N, 64), cdiv(g->M, 64), splitk);
     gemm_nt_f32_kernel<<<grid, 256, 0, s>>>((const float*)g->A, (const float*)g->B, g->M, g->N, g->K, g->lda, g->ldb,
                                             kchunk, e);
+  } else {
+    return LIDK_ERR_ARG;
+  }
+  return launch_status();
+}
+
+
+// =====================================================================================================================
+// Weight-gradient GEMM, "TN":  C[N1][N2] += alpha * sum_m X[m][N1]^T-row * Y[m][N2]   (dW = dY^T . X), f32 accumulate.
+// Both operands are consumed as stored (row-major, contraction index = row): tiles of BKM rows are staged row-major in LDS
+// with 16-byte loads and the MFMA fragments come from transposed LDS reads (tr_frag), so no transposed copies exist in
+// HBM.  The contraction (M = B*T rows) is split over grid.z; partial tiles are added with contiguous float atomics.
+// colsum (optional): colsum[n1] += sum_m X[m][n1] — the bias gradient, accumulated from the X chunks as they are staged.
+// =====================================================================================================================
+#define BKM 64
+
+template <int BN1, int BN2>
+__global__ void __launch_bounds__(256)
+gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict__ Y, int ldy, float* __restrict__ C, int ldc,
+                    float* __restrict__ colsum, int M, int N1, int N2, int mchunk, float alpha) {
+  constexpr int LDX = BN1 + 8, LDY = BN2 + 8, TM = BN1 / 32, TN = BN2 / 32, WM = BN1 / 2, WN = BN2 / 2, CST = WN + 4;
+  constexpr int CX = BKM * BN1 / 8 / 256, CY = BKM * BN2 / 8 / 256, PX = BN1 / 8, PY = BN2 / 8;
+  constexpr int AB_BYTES = BKM * (LDX + LDY) * 2, C_BYTES = 4 * WM * CST * 4, R_BYTES = 256 * 8 * 4;
+  constexpr int SM = AB_BYTES > C_BYTES ? (AB_BYTES > R_BYTES ? AB_BYTES : R_BYTES) : (C_BYTES > R_BYTES ? C_BYTES : R_BYTES);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
+  bf16* Xs = reinterpret_cast<bf16*>(smem);
+  bf16* Ys = Xs + BKM * LDX;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1, fr = lane & 15, fq = lane >> 4;
+  const int n1_0 = blockIdx.y * BN1, n2_0 = blockIdx.x * BN2;
+  const int mbeg = blockIdx.z * mchunk, mend = min(M, mbeg + mchunk);
+  const int N1p = (N1 + 7) & ~7, N2p = (N2 + 7) & ~7;           // operands are readable (zero padded) up to a multiple of 8
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool want_cs = colsum != nullptr && blockIdx.x == 0;
+
+  uint4 rx[CX], ry[CY];
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < CX; ++i) {
+      int c = tid + i * 256, row = c / PX, col = (c % PX) * 8;
+      rx[i] = (m0 + row < mend && n1_0 + col < N1p) ? *reinterpret_cast<const uint4*>(X + (size_t)(m0 + row) * ldx + n1_0 + col)
+                                                     : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < CY; ++i) {
+      int c = tid + i * 256, row = c / PY, col = (c % PY) * 8;
+      ry[i] = (m0 + row < mend && n2_0 + col < N2p) ? *reinterpret_cast<const uint4*>(Y + (size_t)(m0 + row) * ldy + n2_0 + col)
+                                                     : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < CX; ++i) {
+      int c = tid + i * 256, row = c / PX, col = (c % PX) * 8;
+      *reinterpret_cast<uint4*>(&Xs[row * LDX + col]) = rx[i];
+      if (want_cs) {
+        const bf16* e = reinterpret_cast<const bf16*>(&rx[i]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cs[q] += (float)e[q];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CY; ++i) {
+      int c = tid + i * 256, row = c / PY, col = (c % PY) * 8;
+      *reinterpret_cast<uint4*>(&Ys[row * LDY + col]) = ry[i];
+    }
+  };
+
+  gload(mbeg);
+  lstore();
+  __syncthreads();
+  for (int m0 = mbeg; m0 < mend; m0 += BKM) {
+    const bool more = m0 + BKM < mend;
+    if (more) gload(m0 + BKM);
+#pragma unroll
+    for (int kk = 0; kk < BKM; kk += 32) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = tr_frag(Xs, LDX, kk, wm * WM + i * 16, fq, fr);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = tr_frag(Ys, LDY, kk, wn * WN + j * 16, fq, fr);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) { lstore(); __syncthreads(); }
+  }
+  // bias gradient: threads with equal tid % PX hold partial sums of the same 8 columns
+  if (colsum != nullptr && blockIdx.x == 0) {      // block-uniform
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[tid * 8 + q] = cs[q];
+    __syncthreads();
+    if (tid < BN1) {
+      const int c8 = tid >> 3, q = tid & 7;
+      float t = 0.f;
+      for (int u = c8; u < 256; u += PX) t += red[u * 8 + q];
+      if (n1_0 + tid < N1) atomicAdd(&colsum[n1_0 + tid], t * alpha);
+    }
+    __syncthreads();
+  }
+  float* Cw = reinterpret_cast<float*>(smem) + wid * WM * CST;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cw[(i * 16 + fq * 4 + r) * CST + j * 16 + fr] = acc[i][j][r];
+  __builtin_amdgcn_wave_barrier();
+  constexpr int RPA = 64 / WN;
+  for (int row = lane / WN; row < WM; row += RPA) {
+    const int col = lane % WN, n1 = n1_0 + wm * WM + row, n2 = n2_0 + wn * WN + col;
+    if (n1 < N1 && n2 < N2) atomicAdd(&C[(size_t)n1 * ldc + n2], Cw[row * CST + col] * alpha);
+  }
+}
+
+// f32 (parity mode): 64x64 tile, 16 rows of m per step, 4x4 outputs per thread; tiles are used as stored.
+__global__ void __launch_bounds__(256)
+gemm_tn_f32_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ Y, int ldy, float* __restrict__ C, int ldc,
+                   float* __restrict__ colsum, int M, int N1, int N2, int mchunk, float alpha) {
+  __shared__ float Xs[16][64 + 4];
+  __shared__ float Ys[16][64 + 4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int n1_0 = blockIdx.y * 64, n2_0 = blockIdx.x * 64;
+  const int mbeg = blockIdx.z * mchunk, mend = min(M, mbeg + mchunk);
+  const int lr = tid >> 4, lc = (tid & 15) * 4;          // stage row lr (of 16), columns lc..lc+3
+  float acc[4][4] = {};
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int m0 = mbeg; m0 < mend; m0 += 16) {
+    float xv[4] = {0.f, 0.f, 0.f, 0.f}, yv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m0 + lr < mend) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (n1_0 + lc + q < N1) xv[q] = X[(size_t)(m0 + lr) * ldx + n1_0 + lc + q];
+        if (n2_0 + lc + q < N2) yv[q] = Y[(size_t)(m0 + lr) * ldy + n2_0 + lc + q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { Xs[lr][lc + q] = xv[q]; Ys[lr][lc + q] = yv[q]; cs[q] += xv[q]; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = Xs[k][ty * 4 + i]; bv[i] = Ys[k][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  if (colsum != nullptr && blockIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (n1_0 + lc + q < N1) atomicAdd(&colsum[n1_0 + lc + q], cs[q] * alpha);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int n1 = n1_0 + ty * 4 + i, n2 = n2_0 + tx * 4 + j;
+      if (n1 < N1 && n2 < N2) atomicAdd(&C[(size_t)n1 * ldc + n2], acc[i][j] * alpha);
+    }
+}
+
+extern "C" int lidk_gemm_tn(const void* X, int ldx, const void* Y, int ldy, float* C, int ldc, float* colsum, int M, int N1,
+                            int N2, float alpha, int splitk, int dtype, void* stream) {
+  if (!X || !Y || !C || M <= 0 || N1 <= 0 || N2 <= 0 || ldc < N2) return LIDK_ERR_ARG;
+  if (ldx < ((N1 + 7) & ~7) || ldy < ((N2 + 7) & ~7) || (ldx & 7) || (ldy & 7)) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  if (splitk < 1) splitk = 1;
+  if (dtype == LIDK_BF16) {
+    int mchunk = cdiv(cdiv(M, splitk), BKM) * BKM;
+    splitk = cdiv(M, mchunk);
+    if (N1 >= 128 && N2 >= 128 && (long)cdiv(N1, 128) * cdiv(N2, 128) * splitk >= 256) {
+      dim3 grid(cdiv(N2, 128), cdiv(N1, 128), splitk);
+      gemm_tn_bf16_kernel<128, 128><<<grid, 256, 0, s>>>((const bf16*)X, ldx, (const bf16*)Y, ldy, C, ldc, colsum, M, N1, N2, mchunk, alpha);
+    } else {
+      dim3 grid(cdiv(N2, 64), cdiv(N1, 64), splitk);
+      gemm_tn_bf16_kernel<64, 64><<<grid, 256, 0, s>>>((const bf16*)X, ldx, (const bf16*)Y, ldy, C, ldc, colsum, M, N1, N2, mchunk, alpha);
+    }
+  } else if (dtype == LIDK_F32) {
+    int mchunk = cdiv(cdiv(M, splitk), 16) * 16;
+    splitk = cdiv(M, mchunk);
+    dim3 grid(cdiv(N2, 64), cdiv(N1, 64), splitk);
+    gemm_tn_f32_kernel<<<grid, 256, 0, s>>>((const float*)X, ldx, (const float*)Y, ldy, C, ldc, colsum, M, N1, N2, mchunk, alpha);
   } else {
     return LIDK_ERR_ARG;
   }

@@ -111,7 +111,6 @@ class _Work:
         cmax = max(ff, 2 * ci, 3 * cfg.heads * cfg.dim_head, 3 * cfg.last_heads * cfg.last_dim_head, 4 * d, 3 * cfg.n_mels,
                    self.v1p)
         self.cmax = cmax
-        self.tA, self.tB = z(cmax, Mp), z(cmax, Mp)          # transposed operands; pad columns stay zero
         self.dbig = e(M, cmax)                                # da / dy_pw1 / dqkv
         self.dmid = e(M, max(ci, cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head, d))   # ds / do
         self.dmid2 = e(M, ci)
@@ -394,26 +393,24 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ backward pieces
-    def _splitk(self, n, k, Mp):
+    @staticmethod
+    def _splitk(n, k):
+        """Split of the M = B*T contraction for a [n, k] weight gradient: enough workgroups to fill 256 CUs, but few enough
+        that the float-atomic traffic (splitk * |dW|) stays small next to the operand reads."""
         tiles = -(-n // 64) * -(-k // 64)
-        return max(1, min(-(-768 // tiles), Mp // 128 if Mp >= 128 else 1))
+        return max(1, min(16, round(512 / tiles)))
 
-    def _wgrad(self, w: _Work, dyT, xT, dW, n, k):
-        """dW [n,k] (f32) += dyT[M,n]^T @ xT[M,k] via two transposes and a split-K NT GEMM."""
-        tA, tB = w.tA[:n], w.tB[:k]
-        self.k.transpose(dyT, tA)
-        self.k.transpose(xT, tB)
-        self.k.gemm_nt(tA, tB, dW, splitk=self._splitk(n, k, w.Mp), M=n, N=k, K=w.Mp)
+    def _wgrad(self, w: _Work, dyT, xT, dW, n, k, db=None):
+        """dW [n,k] (f32) += dyT[M,n]^T @ xT[M,k] and db [n] += column sums of dyT, straight from the row-major activations."""
+        self.k.gemm_tn(dyT, xT, dW, colsum=db, splitk=self._splitk(n, k), M=w.M, N1=n, N2=k)
 
     def _ff_bwd(self, w: _Work, dx_res, dyT, x_in, P, h, a, u, mean, rstd, dx_out, dxT_out, dxT_scale):
         """dyT = 0.5*dx_res (T).  Produces dx_out = dx_res + LN'(dh) and optional T copy for the next stage."""
         M, d, ff = w.M, self.cfg.d, a.shape[1]
-        self._wgrad(w, dyT, u, P["dw2"], d, ff)
-        self.k.colsum(dyT, P["db2"], w.partial)
+        self._wgrad(w, dyT, u, P["dw2"], d, ff, P["db2"])
         da = w.dbig[:, :ff] if w.dbig.shape[1] == ff else w.dbig.view(-1)[:M * ff].view(M, ff)
         self.k.gemm_nt(dyT, P["w2"][1], da, act=L.ACT_SWISH_GRAD, aux=a, N=ff, K=d)
-        self._wgrad(w, da, h, P["dw1"], ff, d)
-        self.k.colsum(da, P["db1"], w.partial)
+        self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
         self.k.gemm_nt(da, P["w1"][1], w.dh, N=d, K=ff)
         self.k.layernorm_bwd(w.dh, x_in, mean, rstd, P["ln_w"], w.partial, dres=dx_res, dx=dx_out, dxT=dxT_out,
                           dxT_scale=dxT_scale, dgamma=P["dln_w"], dbeta=P["dln_b"], dtype=self.act_dtype)
@@ -430,8 +427,7 @@ class Engine:
         C = bp.conv
         ci, K = C["dw"].shape[0], C["dw"].shape[2]
         pad_left = K // 2
-        self._wgrad(w, w.dyT, bb.s, C["dw2"].view(d, ci), d, ci)
-        self.k.colsum(w.dyT, C["db2"], w.partial)
+        self._wgrad(w, w.dyT, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
         ds = w.dmid.view(-1)[:M * ci].view(M, ci)
         self.k.gemm_nt(w.dyT, C["w2"][1], ds, N=ci, K=d)
         self.k.bn_swish_bwd_reduce(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial)
@@ -449,8 +445,7 @@ class Engine:
         self.k.dwconv_bwd_input(dc, C["dw"].view(ci, K), dg, B, T, pad_left)
         dy1 = w.dbig.view(-1)[:M * 2 * ci].view(M, 2 * ci)
         self.k.glu_bwd(bb.y, dg, dy1)
-        self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d)
-        self.k.colsum(dy1, C["db1"], w.partial)
+        self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
         self.k.gemm_nt(dy1, C["w1"][1], w.dh, N=d, K=2 * ci)
         self.k.layernorm_bwd(w.dh, bb.x2, bb.mean[2], bb.rstd[2], C["ln_w"], w.partial, dres=dx3, dx=b, dxT=w.dyT,
                           dxT_scale=1.0, dgamma=C["dln_w"], dbeta=C["dln_b"], dtype=self.act_dtype)
@@ -458,8 +453,7 @@ class Engine:
         # ---- attention: y = x1 + attn(x1)
         A = bp.attn
         inner = bp.heads * bp.dh
-        self._wgrad(w, w.dyT, bb.o, A["dwo"], d, inner)
-        self.k.colsum(w.dyT, A["dbo"], w.partial)
+        self._wgrad(w, w.dyT, bb.o, A["dwo"], d, inner, A["dbo"])
         do = w.dmid.view(-1)[:M * inner].view(M, inner)
         self.k.gemm_nt(w.dyT, A["wo"][1], do, N=inner, K=d)
         dqkv = w.dbig.view(-1)[:M * 3 * inner].view(M, 3 * inner)
@@ -488,8 +482,7 @@ class Engine:
             dlT.zero_()
         self.k.scale_cast_2d(dl, dlT, M, v1)
         # vocabulary projection
-        self._wgrad(w, dlT[:, :v1], w.head_h, self.gview(p + ".weight"), v1, d)
-        self.k.colsum(dl, self.gview(p + ".bias"), w.partial)
+        self._wgrad(w, dlT, w.head_h, self.gview(p + ".weight"), v1, d, self.gview(p + ".bias"))
         self.k.gemm_nt(dlT, self.wview(p + ".weight")[1][:, :v1p], w.dh, N=d, K=v1p)
         bp, bb = self.head_params[lang], w.head
         dy_ln = w.dh
@@ -526,15 +519,13 @@ class Engine:
             dy = w.dxa
         self.k.scale_cast(dy, w.dyT, math.sqrt(d))
         nm = cfg.n_mels
-        self._wgrad(w, w.dyT, w.r, self.gview(fz + ".linear.weight"), d, nm)
-        self.k.colsum(w.dyT, self.gview(fz + ".linear.bias"), w.partial)
+        self._wgrad(w, w.dyT, w.r, self.gview(fz + ".linear.weight"), d, nm, self.gview(fz + ".linear.bias"))
         dr = w.dmid.view(-1)[:M * nm].view(M, nm)
         self.k.gemm_nt(w.dyT, self.wview(fz + ".linear.weight")[1], dr, N=nm, K=d)
         self.k.relu_bwd(dr, w.r, dr)
         w.dconv3.zero_()
-        self._wgrad(w, dr, w.col, w.dconv3, nm, 3 * nm)
+        self._wgrad(w, dr, w.col, w.dconv3, nm, 3 * nm, self.gview(fz + ".sub_sampling.0.bias"))
         self.gview(fz + ".sub_sampling.0.weight").add_(w.dconv3.view(nm, 3, nm).permute(0, 2, 1))   # layout glue
-        self.k.colsum(dr, self.gview(fz + ".sub_sampling.0.bias"), w.partial)
         if self.on_stage_grads_ready:
             self.on_stage_grads_ready("front")
 

@@ -184,6 +184,18 @@ def gemm_nt(A, B, out, bias=None, act=L.ACT_NONE, alpha=1.0, res=None, out2=None
     return out
 
 
+def gemm_tn(X, Y, C, colsum=None, alpha=1.0, splitk=1, M=None, N1=None, N2=None):
+    """C[N1,N2] (f32) += alpha * X[:M,:N1]^T @ Y[:M,:N2]; colsum[N1] (f32, optional) += alpha * X.sum(0)."""
+    M = X.shape[0] if M is None else M
+    N1 = X.shape[1] if N1 is None else N1
+    N2 = Y.shape[1] if N2 is None else N2
+    if X.dtype != Y.dtype or C.dtype != torch.float32:
+        raise LidkError("gemm_tn: X and Y share the activation dtype, C is float32")
+    check(lib().lidk_gemm_tn(_pv(X), X.stride(0), _pv(Y), Y.stride(0), _pv(C), C.stride(0), _p(colsum), M, N1, N2, alpha,
+                             splitk, _code(X), _stream()), "gemm_tn")
+    return C
+
+
 # ----------------------------------------------------------------------------------------------- attention
 def attn_ldp(T, dh, dtype):
     """Row stride of the probs buffer for this (T, dh, dtype): padded to 32 when the MFMA kernels apply."""

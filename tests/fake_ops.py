@@ -118,6 +118,17 @@ def gemm_nt(A, B, out, bias=None, act=ACT_NONE, alpha=1.0, res=None, out2=None, 
     return out
 
 
+def gemm_tn(X, Y, C, colsum=None, alpha=1.0, splitk=1, M=None, N1=None, N2=None):
+    M = X.shape[0] if M is None else M
+    N1 = X.shape[1] if N1 is None else N1
+    N2 = Y.shape[1] if N2 is None else N2
+    x, y = _f(X[:M, :N1]), _f(Y[:M, :N2])
+    C[:N1, :N2] += alpha * (x.t() @ y)
+    if colsum is not None:
+        colsum[:N1] += alpha * x.sum(0)
+    return C
+
+
 def _attn(qkv, emb, B, T, H, dh):
     inner = H * dh
     q, k, v = _f(qkv).split(inner, dim=-1)

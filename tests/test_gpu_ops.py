@@ -186,6 +186,24 @@ def test_gemm_epilogues(dt):
     check("gemm_splitk", o, base + _gemm_ref(A2, B2, dt).float(), 5e-4)
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N1,N2,splitk", [(9664, 1024, 256, 8), (9664, 256, 1024, 8), (204, 256, 64, 4), (1000, 41, 256, 16),
+                                            (333, 80, 240, 3), (4100, 768, 256, 5), (130, 64, 64, 1), (2048, 256, 256, 16)])
+def test_gemm_tn_wgrad(dt, M, N1, N2, splitk):
+    """dW = dY^T . X from the row-major activations (no transposes), bias gradient fused as a column sum."""
+    N1p = (N1 + 7) // 8 * 8
+    X = torch.zeros(M, N1p)
+    X[:, :N1] = torch.randn(M, N1, generator=g(90)) * (0.5 + torch.arange(N1) / N1)
+    Y = torch.randn(M, N2, generator=g(91)) + 0.2 * torch.arange(N2) / N2
+    base, cbase = torch.randn(N1, N2, generator=g(92)), torch.randn(N1, generator=g(93))
+    ref = base.double() + 0.5 * rt(X[:, :N1], dt).double().t() @ rt(Y, dt).double()
+    cref = cbase.double() + 0.5 * rt(X[:, :N1], dt).double().sum(0)
+    C, cs = dev(base.clone()), dev(cbase.clone())
+    ops.gemm_tn(dev(X, dt), dev(Y, dt), C, colsum=cs, alpha=0.5, splitk=splitk, N1=N1)
+    check(f"gemm_tn_{M}x{N1}x{N2}", C, ref.float(), 3e-4 * float(ref.abs().max()))
+    check(f"gemm_tn_colsum_{M}x{N1}", cs, cref.float(), 3e-4 * float(cref.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_ref(qkv, emb, B, T, H, dh):
     inner = H * dh
