@@ -123,35 +123,46 @@ def cpu_baseline(module, ds, steps, batch, threads):
 
 
 def gemm_roofline(trainer, batches, step_fn):
-    """Bracket every GEMM launch of one training step with HIP events on the launch stream; FLOPs are 2*M*N*K."""
+    """Bracket every MFMA GEMM launch (gemm_nt forward/dgrad, gemm_tn wgrad) of ONE training step with HIP events on the
+    launch stream; algorithmic FLOPs are 2*M*N*K per launch.  The step runs through the eager launch path (graph replay
+    bypasses the Python wrappers and events cannot be recorded inside a capture); the kernels and shapes are identical."""
     eng = trainer.engine
     k = eng.k
-    orig = k.gemm_nt
+    orig_nt, orig_tn = k.gemm_nt, k.gemm_tn
     rec = []
 
-    def timed(A, B, out, *a, M=None, N=None, K=None, **kw):
-        m = A.shape[0] if M is None else M
-        kk = A.shape[1] if K is None else K
-        n = B.shape[0] if N is None else N
+    def bracket(fn, flops, *a, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        r = orig(A, B, out, *a, M=M, N=N, K=K, **kw)
+        r = fn(*a, **kw)
         e1.record()
-        rec.append((e0, e1, 2.0 * m * n * kk))
+        rec.append((e0, e1, flops))
         return r
 
-    k.gemm_nt = timed
+    def timed_nt(A, B, out, *a, M=None, N=None, K=None, **kw):
+        m, kk, n = (A.shape[0] if M is None else M), (A.shape[1] if K is None else K), (B.shape[0] if N is None else N)
+        return bracket(orig_nt, 2.0 * m * n * kk, A, B, out, *a, M=M, N=N, K=K, **kw)
+
+    def timed_tn(X, Y, C, *a, M=None, N1=None, N2=None, **kw):
+        m, n1, n2 = (X.shape[0] if M is None else M), (X.shape[1] if N1 is None else N1), (Y.shape[1] if N2 is None else N2)
+        return bracket(orig_tn, 2.0 * m * n1 * n2, X, Y, C, *a, M=M, N1=N1, N2=N2, **kw)
+
+    graphs_on = eng.graphs.enabled
+    eng.graphs.enabled = False
+    k.gemm_nt, k.gemm_tn = timed_nt, timed_tn
     try:
         step_fn(0, batches[0])
         torch.cuda.synchronize()
     finally:
-        k.gemm_nt = orig
+        k.gemm_nt, k.gemm_tn = orig_nt, orig_tn
+        eng.graphs.enabled = graphs_on
     ms = sum(a.elapsed_time(b) for a, b, _ in rec)
     flops = sum(f for _, _, f in rec)
     return {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": "gemm_nt_bf16_kernel", "launches_per_step": len(rec), "gemm_ms_per_step": round(ms, 3),
-            "gemm_gflop_per_step": round(flops / 1e9, 1), "avg_launch_us": round(ms * 1e3 / len(rec), 2)}
+            "kernel": "gemm_nt_bf16_kernel + gemm_tn_bf16_kernel", "launches_per_step": len(rec),
+            "gemm_ms_per_step": round(ms, 3), "gemm_gflop_per_step": round(flops / 1e9, 1),
+            "avg_launch_us": round(ms * 1e3 / len(rec), 2)}
 
 
 def main():
@@ -191,12 +202,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed set-up (the analogue of JIT compilation): each language head's block sequence is captured into a hipGraph on
+    # its second use, so visit every language three times before the contract's W warm-up steps.  These are ordinary training
+    # steps; nothing they compute is reused by the timed steps.
+    if trainer.engine.graphs.enabled and not args.stochastic_depth:
+        for i in range(3 * N_LANGS):
+            step_fn(i, batches[i % N_LANGS])
     for i in range(args.warmup):
         step_fn(i, batches[i % N_LANGS])
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step_fn(args.warmup + i, batches[(args.warmup + i) % N_LANGS])
+    host_issue = time.perf_counter() - t0          # host time to enqueue the K steps (no device sync inside)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -221,7 +239,7 @@ def main():
                                        f"3 s@16 kHz, batch={args.batch}/GPU, Novograd+clip, features on GPU",
                            "global_batch": world * args.batch, "utterance_seconds": SECONDS,
                            "parallelism": f"dp{world}", "stochastic_depth": bool(args.stochastic_depth)},
-                "roofline": roof, "cpu_baseline": cpu}
+                "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 3), "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -8,6 +8,7 @@
 //   C/D lane l, reg r -> row 4*(l>>4)+r, col (l&15).
 // f32 path (parity mode): 64x64 tile, BK = 16, 4x4 outputs per thread, plain FMA.
 #include "common.h"
+#include <stdlib.h>
 
 struct Epi {
   const float* bias; int act; float alpha;
@@ -234,9 +235,12 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
   if (dtype == LIDK_BF16) {
     int kchunk = cdiv(cdiv(g->K, splitk), BK) * BK;
     splitk = cdiv(g->K, kchunk);
-    // tile choice: big tiles when the grid still fills 256 CUs, otherwise 64x64 for more workgroups
+    // tile choice: measured on MI355X (tools/gemm_bench.py), the 64x64 tile wins on every shape of this model (K = 256..1024:
+    // only 4..16 K-tiles, so many small workgroups per CU hide the load latency better than one big tile does); the 128x128
+    // variant is kept for long-K problems and can be forced with LIDK_GEMM_TILE=128.
     long big = (long)cdiv(g->M, 128) * cdiv(g->N, 128) * splitk;
-    if (big >= 384) {
+    static const int force_tile = getenv("LIDK_GEMM_TILE") ? atoi(getenv("LIDK_GEMM_TILE")) : 0;
+    if (force_tile == 128 || (force_tile != 64 && big >= 384 && g->K >= 4096)) {
       dim3 grid(cdiv(g->N, 128), cdiv(g->M, 128), splitk);
       gemm_nt_bf16_kernel<128, 128><<<grid, 256, 0, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->K, g->lda,
                                                         g->ldb, kchunk, e);

@@ -25,6 +25,37 @@ def _ceil(a, b):
     return (a + b - 1) // b * b
 
 
+class _GraphCache:
+    """hipGraph capture of fixed launch sequences (one ConformerBlock forward or backward).
+
+    A block's kernels always touch the same preallocated buffers and carry no per-step scalars, so the ~25 (forward) /
+    ~45 (backward) launches can be recorded once and replayed with a single host call: the Python/ctypes launch path costs
+    ~13 us per kernel, a graph replay ~15 us per block.  First use of a key runs eagerly (allocations, lazy views), second
+    use captures, later uses replay.  Disabled with LIDK_GRAPHS=0, on the CPU test backend, and for sequences that contain a
+    collective (SyncBatchNorm under data parallelism)."""
+
+    def __init__(self, enabled: bool):
+        self.enabled = enabled
+        self.state = {}
+
+    def run(self, key, fn):
+        if not self.enabled:
+            return fn()
+        st = self.state.get(key)
+        if st is None:
+            self.state[key] = [None]
+            return fn()
+        if st[0] is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            st[0] = g
+        st[0].replay()
+
+    def clear(self):
+        self.state.clear()
+
+
 class _BlockParams:
     """Views of one ConformerBlock's parameters: f32 master / gradient views and T-typed GEMM operands."""
 
@@ -149,6 +180,8 @@ class Engine:
         self._built = False
         self.reset_parameters()
         self._work: Dict[tuple, _Work] = {}
+        import os as _os
+        self.graphs = _GraphCache(self._hip and _os.environ.get("LIDK_GRAPHS", "1") != "0")
         # data-parallel hooks (set by the Trainer): all-reduce of f64 BatchNorm sums, and "gradients of stage ready"
         self.stat_allreduce: Optional[Callable[[torch.Tensor], None]] = None
         self.on_stage_grads_ready: Optional[Callable[[str], None]] = None
@@ -271,6 +304,7 @@ class Engine:
                             for l in self.cfg.lang2vocab}
         self._built = True
         self._work.clear()
+        self.graphs.clear()
         self.refresh_weights()
 
     def refresh_weights(self):
@@ -284,6 +318,7 @@ class Engine:
         if key not in self._work:
             if len(self._work) >= 4:
                 self._work.pop(next(iter(self._work)))
+                self.graphs.clear()                    # captured graphs point into the evicted workspace
             self._work[key] = _Work(self, B, F_)
         return self._work[key]
 
@@ -335,10 +370,29 @@ class Engine:
         self._ff_fwd(bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.x4, bb.mean[3], bb.rstd[3])
         return bb.x4
 
+    def _graphed(self, key, fn):
+        """Run a fixed launch sequence through the hipGraph cache unless it contains a collective (SyncBN under DP)."""
+        if self.stat_allreduce is not None:
+            return fn()
+        return self.graphs.run(key, fn)
+
+    def _enc_block_fwd(self, x, i, w: _Work, training: bool):
+        bp, bb = self.enc_params[i], w.enc[i]
+        x4 = self._block_fwd(x, bp, bb, w, training)
+        self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
+                             dtype=self.act_dtype)
+
+    def _enc_block_bwd(self, dy, x_in, i, w: _Work, dfeat):
+        bp, bb = self.enc_params[i], w.enc[i]
+        self.k.layernorm_bwd(dy, bb.x4, bb.mean[4], bb.rstd[4], bp.post["w"], w.partial, dx=w.dxa, dxT=w.dyT,
+                             dxT_scale=0.5, dgamma=bp.post["dw"], dbeta=bp.post["db"], dtype=self.act_dtype)
+        self._block_bwd(w, x_in, bp, bb, w.dxa, w.dyT, dfeat)
+
     def _head_fwd(self, w: _Work, feat, lang, training, seed, logits):
         cfg = self.cfg
         bp, bb = self.head_params[lang], w.head
-        x4 = self._block_fwd(feat, bp, bb, w, training)
+        x4 = bb.x4
+        self._graphed(("hf", id(w), lang, feat.data_ptr(), training), lambda: self._block_fwd(feat, bp, bb, w, training))
         p = f"model.last_projects.{lang}.linear"
         if training and cfg.dropout > 0:
             self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
@@ -374,11 +428,8 @@ class Engine:
         for i in range(self.cfg.n_blocks):
             if not keep[i]:
                 continue
-            bp, bb = self.enc_params[i], w.enc[i]
-            x4 = self._block_fwd(x, bp, bb, w, training)
-            self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
-                              dtype=self.act_dtype)
-            x = bb.out
+            self._graphed(("ef", id(w), i, x.data_ptr(), training), lambda: self._enc_block_fwd(x, i, w, training))
+            x = w.enc[i].out
         out = {}
         langs = [lang] if lang is not None else list(self.cfg.lang2vocab)
         for l in langs:
@@ -496,7 +547,8 @@ class Engine:
                           dxT_scale=0.5, dgamma=bp.post["dw"], dbeta=bp.post["db"], dtype=self.act_dtype)
         dfeat = torch.empty_like(w.dxa) if not hasattr(w, "dfeat") else w.dfeat
         w.dfeat = dfeat
-        self._block_bwd(w, ctx["feat"], bp, bb, w.dxa, w.dyT, dfeat)
+        feat = ctx["feat"]
+        self._graphed(("hb", id(w), lang, feat.data_ptr()), lambda: self._block_bwd(w, feat, bp, bb, w.dxa, w.dyT, dfeat))
         if self.on_stage_grads_ready:
             self.on_stage_grads_ready(f"head.{lang}")
         # encoder blocks in reverse
@@ -504,12 +556,8 @@ class Engine:
         kept = [i for i in range(cfg.n_blocks) if ctx["keep"][i]]
         for idx in reversed(range(len(kept))):
             i = kept[idx]
-            bp, bb = self.enc_params[i], w.enc[i]
             x_in = w.enc[kept[idx - 1]].out if idx > 0 else (w.x0d if (cfg.pos_dropout > 0) else w.x0)
-            self.k.layernorm_bwd(dy, bb.x4, bb.mean[4], bb.rstd[4], bp.post["w"], w.partial, dx=w.dxa, dxT=w.dyT,
-                              dxT_scale=0.5, dgamma=bp.post["dw"], dbeta=bp.post["db"], dtype=self.act_dtype)
-            self._block_bwd(w, x_in, bp, bb, w.dxa, w.dyT, dfeat)
-            dy = dfeat
+            self._graphed(("eb", id(w), i, x_in.data_ptr()), lambda: self._enc_block_bwd(dfeat, x_in, i, w, dfeat))
             if self.on_stage_grads_ready:
                 self.on_stage_grads_ready(f"enc.{i}")
         # front end: x0 = sqrt(d) * (r @ Wl^T + b) [dropout]; r = relu(col @ Wc^T + bc)

@@ -156,3 +156,31 @@ def test_own_dropout_masks_are_consistent_between_fwd_and_bwd():
     n = "model.featurizer.sub_sampling.linear.weight"
     got, want = eng.gview(n).cpu(), sdr[n].grad
     assert float((got - want).norm() / want.norm()) < 2e-3
+
+
+def test_graph_replay_matches_eager(cfg1_weights):
+    """Block sequences replayed from captured hipGraphs must give what the eager launch path gives (third call = replay)."""
+    g = load_npz("cfg1_trainA.npz")
+    mel = torch.from_numpy(load_npz("cfg1_eval.npz")["mel"]).to(DEV)
+    results = []
+    for graphs in (False, True):
+        eng = make_engine(make_cfg(dropout=0.0, pos_dropout=0.0), cfg1_weights, torch.bfloat16)
+        eng.graphs.enabled = graphs
+        for _ in range(3):                      # eager, capture(+replay), replay
+            eng.load_state({k: v.to(DEV) for k, v in cfg1_weights.items()})      # same BN buffers every round
+            eng.zero_grad()
+            out = eng.forward(mel, "b", training=True, keep_layers=[True, True])
+            logits = out["b"].clone()
+            loss, dl = gpu_ctc(out["b"], g)
+            eng.backward(dl)
+        torch.cuda.synchronize()
+        if graphs:
+            assert sum(1 for st in eng.graphs.state.values() if st[0] is not None) >= 6
+        results.append((logits.cpu(), eng.grad.cpu().clone(), {k: v.cpu().clone() for k, v in eng.buffers.items()}))
+    (l0, g0, b0), (l1, g1, b1) = results
+    assert torch.equal(l0, l1)
+    rel = float((g0 - g1).norm() / g0.norm())
+    print(f"[graph vs eager] grad rel diff {rel:.3e}")
+    assert rel < 1e-5                            # split-K float atomics make the sum order run-dependent
+    for k in b0:
+        assert torch.allclose(b0[k].float(), b1[k].float(), atol=1e-6), k
