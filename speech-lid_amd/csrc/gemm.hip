@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 struct Epi {
+  int dbg;                 // tuning aid (LIDK_GEMM_DBG): 1 = skip the epilogue stores, 2 = skip the K loop
   const float* bias; int act; float alpha;
   const float* res; int ldres;
   void* out; int ldo; int out_f32;
@@ -100,58 +101,67 @@ gemm_nt_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int 
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[CA], rb[CB];
-  auto gload = [&](int k0) {
+  // PD K-tiles of global loads are kept in flight per thread (registers); loads complete in order, so consuming stage st
+  // waits only for that stage.  (Ablation on MI355X, ff-up shape M=9664 N=1024 K=256: operand fetch ~9 us — the 64x64 tiles
+  // re-read A and W through L2 — MFMA/LDS loop +6 us, epilogue stores +9 us, with little overlap between the phases.)
+  constexpr int PD = 2;          // measured: 2 and 4 tiles in flight perform the same (tools/gemm_bench.py); 2 keeps 76 VGPRs
+  uint4 ra[PD][CA], rb[PD][CB];
+  auto gload = [&](int st, int k0) {
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
       int c = tid + i * 256, row = c >> 3, kc = (c & 7) * 8;
       int gm = m0 + row, gk = k0 + kc;
-      ra[i] = (gm < M && gk < kend) ? *reinterpret_cast<const uint4*>(A + (size_t)gm * lda + gk) : make_uint4(0, 0, 0, 0);
+      ra[st][i] = (gm < M && gk < kend) ? *reinterpret_cast<const uint4*>(A + (size_t)gm * lda + gk) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
       int c = tid + i * 256, row = c >> 3, kc = (c & 7) * 8;
       int gn = n0 + row, gk = k0 + kc;
-      rb[i] = (gn < N && gk < kend) ? *reinterpret_cast<const uint4*>(B + (size_t)gn * ldb + gk) : make_uint4(0, 0, 0, 0);
+      rb[st][i] = (gn < N && gk < kend) ? *reinterpret_cast<const uint4*>(B + (size_t)gn * ldb + gk) : make_uint4(0, 0, 0, 0);
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int st) {
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
       int c = tid + i * 256, row = c >> 3, kc = (c & 7) * 8;
-      *reinterpret_cast<uint4*>(&As[row * LDS_STRIDE + kc]) = ra[i];
+      *reinterpret_cast<uint4*>(&As[row * LDS_STRIDE + kc]) = ra[st][i];
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
       int c = tid + i * 256, row = c >> 3, kc = (c & 7) * 8;
-      *reinterpret_cast<uint4*>(&Bs[row * LDS_STRIDE + kc]) = rb[i];
+      *reinterpret_cast<uint4*>(&Bs[row * LDS_STRIDE + kc]) = rb[st][i];
     }
   };
 
-  gload(kbeg);
-  lstore();
-  __syncthreads();
+#pragma unroll
+  for (int st = 0; st < PD; ++st) gload(st, kbeg + st * BK);
   const int fr = lane & 15, fq = lane >> 4;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    if (more) gload(k0 + BK);
+  for (int kt = kbeg; kt < ((e.dbg & 2) ? kbeg : kend); kt += PD * BK) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 32) {
-      bf16x8 af[TM], bfr[TN];
+    for (int st = 0; st < PD; ++st) {
+      const int k0 = kt + st * BK;
+      if (k0 < kend) {                                   // block-uniform
+        lstore(st);
+        __syncthreads();
+        gload(st, k0 + PD * BK);                         // refill this stage (zero fill past the end: no memory access)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * (BM / 2) + i * 16 + fr) * LDS_STRIDE + kk + fq * 8]);
+        for (int kk = 0; kk < BK; kk += 32) {
+          bf16x8 af[TM], bfr[TN];
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * (BN / 2) + j * 16 + fr) * LDS_STRIDE + kk + fq * 8]);
+          for (int i = 0; i < TM; ++i)
+            af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * (BM / 2) + i * 16 + fr) * LDS_STRIDE + kk + fq * 8]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+          for (int j = 0; j < TN; ++j)
+            bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * (BN / 2) + j * 16 + fr) * LDS_STRIDE + kk + fq * 8]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+      }
     }
-    __syncthreads();
-    if (more) { lstore(); __syncthreads(); }
   }
 
   // Epilogue: accumulators -> this wave's f32 LDS tile -> row-major pass with 16-byte accesses (the K loop ended with a
@@ -179,7 +189,7 @@ gemm_nt_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int 
 #pragma unroll 4
   for (int row = crow; row < WM; row += RPI) {
     const int m = m0 + wm * WM + row, n = n0 + wn * WN + ccol;
-    if (m < M && n < N) epi_store4<bf16>(e, m, n, N, *reinterpret_cast<const float4*>(&Cw[row * CST + ccol]));
+    if (m < M && n < N && !(e.dbg & 1)) epi_store4<bf16>(e, m, n, N, *reinterpret_cast<const float4*>(&Cw[row * CST + ccol]));
   }
 }
 
@@ -229,7 +239,8 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
   if (g->act == LIDK_ACT_SWISH_GRAD && !g->aux) return LIDK_ERR_ARG;
   int splitk = g->splitk > 1 ? g->splitk : 1;
   if (splitk > 1 && (g->bias || g->res || g->act != LIDK_ACT_NONE || !g->out_f32)) return LIDK_ERR_ARG;
-  Epi e{g->bias, g->act, g->alpha, g->res, g->ldres, g->out, g->ldo, g->out_f32, g->out2, g->ldo2, g->aux, g->ldaux,
+  static const int dbg = getenv("LIDK_GEMM_DBG") ? atoi(getenv("LIDK_GEMM_DBG")) : 0;
+  Epi e{dbg, g->bias, g->act, g->alpha, g->res, g->ldres, g->out, g->ldo, g->out_f32, g->out2, g->ldo2, g->aux, g->ldaux,
         splitk > 1 ? 1 : 0};
   hipStream_t s = as_stream(stream);
   if (dtype == LIDK_BF16) {
@@ -295,28 +306,29 @@ gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict_
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool want_cs = colsum != nullptr && blockIdx.x == 0;
 
-  uint4 rx[CX], ry[CY];
-  auto gload = [&](int m0) {
+  constexpr int PD = 2;                                   // row-tiles of global loads in flight (see gemm_nt_bf16_kernel)
+  uint4 rx[PD][CX], ry[PD][CY];
+  auto gload = [&](int st, int m0) {
 #pragma unroll
     for (int i = 0; i < CX; ++i) {
       int c = tid + i * 256, row = c / PX, col = (c % PX) * 8;
-      rx[i] = (m0 + row < mend && n1_0 + col < N1p) ? *reinterpret_cast<const uint4*>(X + (size_t)(m0 + row) * ldx + n1_0 + col)
-                                                     : make_uint4(0, 0, 0, 0);
+      rx[st][i] = (m0 + row < mend && n1_0 + col < N1p) ? *reinterpret_cast<const uint4*>(X + (size_t)(m0 + row) * ldx + n1_0 + col)
+                                                         : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < CY; ++i) {
       int c = tid + i * 256, row = c / PY, col = (c % PY) * 8;
-      ry[i] = (m0 + row < mend && n2_0 + col < N2p) ? *reinterpret_cast<const uint4*>(Y + (size_t)(m0 + row) * ldy + n2_0 + col)
-                                                     : make_uint4(0, 0, 0, 0);
+      ry[st][i] = (m0 + row < mend && n2_0 + col < N2p) ? *reinterpret_cast<const uint4*>(Y + (size_t)(m0 + row) * ldy + n2_0 + col)
+                                                         : make_uint4(0, 0, 0, 0);
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int st) {
 #pragma unroll
     for (int i = 0; i < CX; ++i) {
       int c = tid + i * 256, row = c / PX, col = (c % PX) * 8;
-      *reinterpret_cast<uint4*>(&Xs[row * LDX + col]) = rx[i];
+      *reinterpret_cast<uint4*>(&Xs[row * LDX + col]) = rx[st][i];
       if (want_cs) {
-        const bf16* e = reinterpret_cast<const bf16*>(&rx[i]);
+        const bf16* e = reinterpret_cast<const bf16*>(&rx[st][i]);
 #pragma unroll
         for (int q = 0; q < 8; ++q) cs[q] += (float)e[q];
       }
@@ -324,30 +336,35 @@ gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict_
 #pragma unroll
     for (int i = 0; i < CY; ++i) {
       int c = tid + i * 256, row = c / PY, col = (c % PY) * 8;
-      *reinterpret_cast<uint4*>(&Ys[row * LDY + col]) = ry[i];
+      *reinterpret_cast<uint4*>(&Ys[row * LDY + col]) = ry[st][i];
     }
   };
 
-  gload(mbeg);
-  lstore();
-  __syncthreads();
-  for (int m0 = mbeg; m0 < mend; m0 += BKM) {
-    const bool more = m0 + BKM < mend;
-    if (more) gload(m0 + BKM);
 #pragma unroll
-    for (int kk = 0; kk < BKM; kk += 32) {
-      bf16x8 af[TM], bfr[TN];
+  for (int st = 0; st < PD; ++st) gload(st, mbeg + st * BKM);
+  for (int mt = mbeg; mt < mend; mt += PD * BKM) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = tr_frag(Xs, LDX, kk, wm * WM + i * 16, fq, fr);
+    for (int st = 0; st < PD; ++st) {
+      const int m0 = mt + st * BKM;
+      if (m0 < mend) {                                    // block-uniform: every lane runs the transposed reads
+        lstore(st);
+        __syncthreads();
+        gload(st, m0 + PD * BKM);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bfr[j] = tr_frag(Ys, LDY, kk, wn * WN + j * 16, fq, fr);
+        for (int kk = 0; kk < BKM; kk += 32) {
+          bf16x8 af[TM], bfr[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i) af[i] = tr_frag(Xs, LDX, kk, wm * WM + i * 16, fq, fr);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) bfr[j] = tr_frag(Ys, LDY, kk, wn * WN + j * 16, fq, fr);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+      }
     }
-    __syncthreads();
-    if (more) { lstore(); __syncthreads(); }
   }
   // bias gradient: threads with equal tid % PX hold partial sums of the same 8 columns
   if (colsum != nullptr && blockIdx.x == 0) {      // block-uniform

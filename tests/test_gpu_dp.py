@@ -1,0 +1,61 @@
+"""Data-parallel path on real kernels: 2 ranks sharing the one GPU of the test box over gloo (RCCL refuses two ranks on one
+device) must match a single process training on the concatenated batch: SyncBN statistics, averaged gradients of the flat
+arena issued per stage from the backward hooks, identical parameters on both ranks afterwards."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out_dir, amp):
+    sys.path[:0] = [ROOT, PKG]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from ccml import seed_everything
+    from ccml.trainer import Trainer
+    from lid import hydra_lite
+    import lid.main as launcher
+    seed_everything(0)
+    ov = ["trainer.gpu_id=0", f"trainer.use_amp={'true' if amp else 'false'}", "trainer.total_epoch=1", "model.dropout=0.0",
+          "data.feature.mask_times=0", f"data.sampler_common.train_batch_size={4 // world}", "data.synthetic.items_per_lang=8",
+          "data.synthetic.val_items_per_lang=2", "data.synthetic.seconds=0.5", f"trainer.ddp={'true' if world > 1 else 'false'}",
+          f"trainer.world_size={world}", f"trainer.local_rank={rank}", "trainer.backend=gloo", f"trainer.master_port={port}",
+          "module.interval=1000", "trainer.log_interval=1000"]
+    cfg = hydra_lite.load_config(os.path.join(PKG, "lid", "conf"), "synthetic_cfg1", ov)
+    module, sets, params = launcher.build(cfg, rank, world)
+    module.model.lidk_engine.cfg.pos_dropout = 0.0
+    module.model.use_stochastic_depth = False
+    for ds in sets.values():
+        ds.train = False
+    params["train_batch_sampler"].seed = 0
+    trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
+    trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=params)
+    torch.save({k: v.detach().cpu().clone() for k, v in module.model.state_dict().items()},
+               os.path.join(out_dir, f"w{world}_r{rank}.pt"))
+
+
+@pytest.mark.parametrize("amp", [False])
+def test_two_ranks_match_one_process_on_gpu(tmp_path, amp):
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_worker, args=(0, 1, 29711, str(tmp_path), amp))
+    p.start(); p.join(400)
+    assert p.exitcode == 0
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29713, str(tmp_path), amp)) for r in range(2)]
+    [q.start() for q in procs]
+    [q.join(500) for q in procs]
+    assert [q.exitcode for q in procs] == [0, 0]
+    one = torch.load(tmp_path / "w1_r0.pt")
+    r0, r1 = torch.load(tmp_path / "w2_r0.pt"), torch.load(tmp_path / "w2_r1.pt")
+    worst = 0.0
+    for k in one:
+        assert torch.equal(r0[k], r1[k]), f"ranks diverged on {k}"
+        if one[k].is_floating_point() and not k.endswith(("conv.net.4.conv.bias", "conv.net.5.running_mean")):
+            worst = max(worst, float((r0[k] - one[k]).abs().max()))
+            np.testing.assert_allclose(r0[k].numpy(), one[k].numpy(), rtol=5e-3, atol=5e-5, err_msg=k)
+    print(f"[dp 2x2 vs 1x4] max |param diff| = {worst:.3e}")

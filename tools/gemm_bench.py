@@ -8,14 +8,19 @@ from lidk import ops, _lib as L
 
 dev = "cuda:0"
 M = 9664
-def t(fn, n=30):
-    for _ in range(3): fn()
+def t(fn, n=20):
+    """GPU time per call: n launches captured in one hipGraph and replayed (no host launch gaps)."""
+    for _ in range(2): fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n): fn()
+    g.replay(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(n): fn()
+    for _ in range(5): g.replay()
     b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / n * 1e3   # us
+    return a.elapsed_time(b) / (5 * n) * 1e3   # us
 
 def run(name, m, n, k, **kw):
     A = torch.randn(m, k, device=dev).bfloat16(); B = torch.randn(n, k, device=dev).bfloat16()

@@ -14,5 +14,6 @@ step() {
 step t_ops   python -m pytest tests/test_gpu_ops.py -m gpu -q -rA -p no:cacheprovider -k "${OPS_K:-test}"
 step t_model python -m pytest tests/test_gpu_model.py -m gpu -q -rA -p no:cacheprovider
 step t_train python -m pytest tests/test_gpu_train.py -m gpu -q -rA -p no:cacheprovider
+step t_dp    python -m pytest tests/test_gpu_dp.py -m gpu -q -rA -p no:cacheprovider
 step bench   python bench.py --steps 20 --warmup 5 ${BENCH_ARGS:---no-cpu-baseline}
 exit $fail
