@@ -341,58 +341,75 @@ class Engine:
         self.k.gemm_nt(h, P["w1"][0], u, bias=P["b1"], act=L.ACT_SWISH, out2=a)
         self.k.gemm_nt(u, P["w2"][0], xo, bias=P["b2"], alpha=0.5, res=x)
 
-    def _block_fwd(self, x, bp: _BlockParams, bb: _BlockBuf, w: _Work, training: bool):
+    def _block_fwd(self, x, bp: _BlockParams, bb: _BlockBuf, w: _Work, training: bool, part: str = "all"):
+        """One ConformerBlock up to x4 (before post_norm).  ``part`` splits the launch sequence at the SyncBatchNorm
+        collective: 'a' = up to the BatchNorm partial sums, 'b' = from the BatchNorm statistics on, 'all' = both."""
         B, T, M = w.B, w.T, w.M
-        self._ff_fwd(x, bp.ff1, bb.h1, bb.a1, bb.u1, bb.x1, bb.mean[0], bb.rstd[0])
-        A = bp.attn
-        self.k.layernorm_fwd(bb.x1, A["ln_w"], A["ln_b"], yT=bb.h2, mean=bb.mean[1], rstd=bb.rstd[1])
-        self.k.gemm_nt(bb.h2, A["wqkv"][0], bb.qkv)
-        self.k.attn_fwd(bb.qkv, A["emb"], bb.o, bb.probs, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
-        self.k.gemm_nt(bb.o, A["wo"][0], bb.x2, bias=A["bo"], res=bb.x1)
         C = bp.conv
         ci, K = C["dw"].shape[0], C["dw"].shape[2]
-        self.k.layernorm_fwd(bb.x2, C["ln_w"], C["ln_b"], yT=bb.h3, mean=bb.mean[2], rstd=bb.rstd[2])
-        self.k.gemm_nt(bb.h3, C["w1"][0], bb.y, bias=C["b1"])
-        self.k.glu_fwd(bb.y, bb.g)
-        dw2d = C["dw"].view(ci, K)
-        pad_left = K // 2
-        if training:
-            self.k.dwconv_fwd(bb.g, dw2d, C["dwb"], bb.c, w.stat_partial, B, T, pad_left)
-            self.k.reduce_partials_f64(w.stat_partial, w.stat_parts, 2 * ci, w.sums[:2 * ci])
-            if self.stat_allreduce is not None:
-                self.stat_allreduce(w.sums[:2 * ci])
-            self.k.bn_train_stats(w.sums[:2 * ci], M * self.world_size, bb.bn_mean, bb.bn_rstd, C["rm"], C["rv"], C["nbt"])
-        else:
-            self.k.dwconv_fwd(bb.g, dw2d, C["dwb"], bb.c, None, B, T, pad_left)
-            self.k.bn_eval_stats(C["rm"], C["rv"], bb.bn_mean, bb.bn_rstd)
-        self.k.bn_swish_fwd(bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], bb.s)
-        self.k.gemm_nt(bb.s, C["w2"][0], bb.x3, bias=C["b2"], res=bb.x2)
-        self._ff_fwd(bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.x4, bb.mean[3], bb.rstd[3])
+        if part in ("all", "a"):
+            self._ff_fwd(x, bp.ff1, bb.h1, bb.a1, bb.u1, bb.x1, bb.mean[0], bb.rstd[0])
+            A = bp.attn
+            self.k.layernorm_fwd(bb.x1, A["ln_w"], A["ln_b"], yT=bb.h2, mean=bb.mean[1], rstd=bb.rstd[1])
+            self.k.gemm_nt(bb.h2, A["wqkv"][0], bb.qkv)
+            self.k.attn_fwd(bb.qkv, A["emb"], bb.o, bb.probs, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
+            self.k.gemm_nt(bb.o, A["wo"][0], bb.x2, bias=A["bo"], res=bb.x1)
+            self.k.layernorm_fwd(bb.x2, C["ln_w"], C["ln_b"], yT=bb.h3, mean=bb.mean[2], rstd=bb.rstd[2])
+            self.k.gemm_nt(bb.h3, C["w1"][0], bb.y, bias=C["b1"])
+            self.k.glu_fwd(bb.y, bb.g)
+            dw2d = C["dw"].view(ci, K)
+            pad_left = K // 2
+            if training:
+                self.k.dwconv_fwd(bb.g, dw2d, C["dwb"], bb.c, w.stat_partial, B, T, pad_left)
+                self.k.reduce_partials_f64(w.stat_partial, w.stat_parts, 2 * ci, w.sums[:2 * ci])
+            else:
+                self.k.dwconv_fwd(bb.g, dw2d, C["dwb"], bb.c, None, B, T, pad_left)
+        if part in ("all", "b"):
+            if training:
+                self.k.bn_train_stats(w.sums[:2 * ci], M * self.world_size, bb.bn_mean, bb.bn_rstd, C["rm"], C["rv"], C["nbt"])
+            else:
+                self.k.bn_eval_stats(C["rm"], C["rv"], bb.bn_mean, bb.bn_rstd)
+            self.k.bn_swish_fwd(bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], bb.s)
+            self.k.gemm_nt(bb.s, C["w2"][0], bb.x3, bias=C["b2"], res=bb.x2)
+            self._ff_fwd(bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.x4, bb.mean[3], bb.rstd[3])
         return bb.x4
 
-    def _graphed(self, key, fn):
-        """Run a fixed launch sequence through the hipGraph cache unless it contains a collective (SyncBN under DP)."""
-        if self.stat_allreduce is not None:
-            return fn()
-        return self.graphs.run(key, fn)
+    def _run_split(self, key, fn, collective):
+        """``fn(part)`` issues a block's launches; they are replayed from captured hipGraphs.  Under data parallelism the
+        sequence is cut at the SyncBatchNorm all-reduce (``collective``), which runs eagerly between the two graphs."""
+        if collective is None:
+            self.graphs.run(key + ("all",), lambda: fn("all"))
+        else:
+            self.graphs.run(key + ("a",), lambda: fn("a"))
+            collective()
+            self.graphs.run(key + ("b",), lambda: fn("b"))
 
-    def _enc_block_fwd(self, x, i, w: _Work, training: bool):
-        bp, bb = self.enc_params[i], w.enc[i]
-        x4 = self._block_fwd(x, bp, bb, w, training)
-        self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
-                             dtype=self.act_dtype)
+    def _bn_collective(self, w: _Work, ci: int, training: bool = True):
+        if self.stat_allreduce is None or not training:
+            return None
+        return lambda: self.stat_allreduce(w.sums[:2 * ci])
 
-    def _enc_block_bwd(self, dy, x_in, i, w: _Work, dfeat):
+    def _enc_block_fwd(self, x, i, w: _Work, training: bool, part: str):
         bp, bb = self.enc_params[i], w.enc[i]
-        self.k.layernorm_bwd(dy, bb.x4, bb.mean[4], bb.rstd[4], bp.post["w"], w.partial, dx=w.dxa, dxT=w.dyT,
-                             dxT_scale=0.5, dgamma=bp.post["dw"], dbeta=bp.post["db"], dtype=self.act_dtype)
-        self._block_bwd(w, x_in, bp, bb, w.dxa, w.dyT, dfeat)
+        x4 = self._block_fwd(x, bp, bb, w, training, part)
+        if part in ("all", "b"):
+            self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
+                                 dtype=self.act_dtype)
+
+    def _enc_block_bwd(self, dy, x_in, i, w: _Work, dfeat, part: str):
+        bp, bb = self.enc_params[i], w.enc[i]
+        if part in ("all", "a"):
+            self.k.layernorm_bwd(dy, bb.x4, bb.mean[4], bb.rstd[4], bp.post["w"], w.partial, dx=w.dxa, dxT=w.dyT,
+                                 dxT_scale=0.5, dgamma=bp.post["dw"], dbeta=bp.post["db"], dtype=self.act_dtype)
+        self._block_bwd(w, x_in, bp, bb, w.dxa, w.dyT, dfeat, part)
 
     def _head_fwd(self, w: _Work, feat, lang, training, seed, logits):
         cfg = self.cfg
         bp, bb = self.head_params[lang], w.head
         x4 = bb.x4
-        self._graphed(("hf", id(w), lang, feat.data_ptr(), training), lambda: self._block_fwd(feat, bp, bb, w, training))
+        ci = bp.conv["dw"].shape[0]
+        self._run_split(("hf", id(w), lang, feat.data_ptr(), training), lambda part: self._block_fwd(feat, bp, bb, w, training, part),
+                        self._bn_collective(w, ci, training))
         p = f"model.last_projects.{lang}.linear"
         if training and cfg.dropout > 0:
             self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
@@ -428,7 +445,8 @@ class Engine:
         for i in range(self.cfg.n_blocks):
             if not keep[i]:
                 continue
-            self._graphed(("ef", id(w), i, x.data_ptr(), training), lambda: self._enc_block_fwd(x, i, w, training))
+            self._run_split(("ef", id(w), i, x.data_ptr(), training), lambda part: self._enc_block_fwd(x, i, w, training, part),
+                            self._bn_collective(w, self.enc_params[i].conv["dw"].shape[0], training))
             x = w.enc[i].out
         out = {}
         langs = [lang] if lang is not None else list(self.cfg.lang2vocab)
@@ -466,56 +484,54 @@ class Engine:
         self.k.layernorm_bwd(w.dh, x_in, mean, rstd, P["ln_w"], w.partial, dres=dx_res, dx=dx_out, dxT=dxT_out,
                           dxT_scale=dxT_scale, dgamma=P["dln_w"], dbeta=P["dln_b"], dtype=self.act_dtype)
 
-    def _block_bwd(self, w: _Work, x_in, bp: _BlockParams, bb: _BlockBuf, dx4, dyT_half, dx_in_out, want_T=None):
+    def _block_bwd(self, w: _Work, x_in, bp: _BlockParams, bb: _BlockBuf, dx4, dyT_half, dx_in_out, part: str = "all"):
         """dx4: f32 gradient at x4 (after post_norm backward); dyT_half = 0.5*dx4 in T.  Writes the gradient w.r.t. the
-        block input into dx_in_out (f32)."""
+        block input into dx_in_out (f32).  ``part`` cuts the sequence at the SyncBatchNorm backward all-reduce."""
         B, T, M, d = w.B, w.T, w.M, self.cfg.d
         a, b = (w.dxa, w.dxb) if dx4 is w.dxb else (w.dxb, w.dxa)     # two f32 ping-pong buffers
-        # ---- ff2: y = x3 + 0.5*ff(x3)
-        self._ff_bwd(w, dx4, dyT_half, bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.mean[3], bb.rstd[3], a, w.dyT, 1.0)
-        dx3 = a
-        # ---- conv module: y = x2 + conv(x2)
         C = bp.conv
         ci, K = C["dw"].shape[0], C["dw"].shape[2]
         pad_left = K // 2
-        self._wgrad(w, w.dyT, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
         ds = w.dmid.view(-1)[:M * ci].view(M, ci)
-        self.k.gemm_nt(w.dyT, C["w2"][1], ds, N=ci, K=d)
-        self.k.bn_swish_bwd_reduce(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial)
-        self.k.reduce_partials_f64(w.partial, L.LN_PARTIAL_BLOCKS, 2 * ci, w.sums_local[:2 * ci])
-        sums = w.sums_local
-        if self.stat_allreduce is not None:
-            w.sums[:2 * ci].copy_(w.sums_local[:2 * ci])
-            self.stat_allreduce(w.sums[:2 * ci])
-            sums = w.sums
-        dc = w.dmid2
-        self.k.bn_swish_bwd_apply(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], sums[:2 * ci], w.sums_local[:2 * ci],
-                               M * self.world_size, dc, C["dbn_w"], C["dbn_b"])
-        self.k.dwconv_bwd_weight(dc, bb.g, C["ddw"].view(ci, K), C["ddwb"], w.dw_partial, B, T, pad_left)
-        dg = w.dmid3
-        self.k.dwconv_bwd_input(dc, C["dw"].view(ci, K), dg, B, T, pad_left)
-        dy1 = w.dbig.view(-1)[:M * 2 * ci].view(M, 2 * ci)
-        self.k.glu_bwd(bb.y, dg, dy1)
-        self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
-        self.k.gemm_nt(dy1, C["w1"][1], w.dh, N=d, K=2 * ci)
-        self.k.layernorm_bwd(w.dh, bb.x2, bb.mean[2], bb.rstd[2], C["ln_w"], w.partial, dres=dx3, dx=b, dxT=w.dyT,
-                          dxT_scale=1.0, dgamma=C["dln_w"], dbeta=C["dln_b"], dtype=self.act_dtype)
-        dx2 = b
-        # ---- attention: y = x1 + attn(x1)
-        A = bp.attn
-        inner = bp.heads * bp.dh
-        self._wgrad(w, w.dyT, bb.o, A["dwo"], d, inner, A["dbo"])
-        do = w.dmid.view(-1)[:M * inner].view(M, inner)
-        self.k.gemm_nt(w.dyT, A["wo"][1], do, N=inner, K=d)
-        dqkv = w.dbig.view(-1)[:M * 3 * inner].view(M, 3 * inner)
-        self.k.attn_bwd(bb.qkv, A["emb"], bb.probs, do, dqkv, A["demb"], w.dsc, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
-        self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
-        self.k.gemm_nt(dqkv, A["wqkv"][1], w.dh, N=d, K=3 * inner)
-        self.k.layernorm_bwd(w.dh, bb.x1, bb.mean[1], bb.rstd[1], A["ln_w"], w.partial, dres=dx2, dx=a, dxT=w.dyT,
-                          dxT_scale=0.5, dgamma=A["dln_w"], dbeta=A["dln_b"], dtype=self.act_dtype)
-        dx1 = a
-        # ---- ff1
-        self._ff_bwd(w, dx1, w.dyT, x_in, bp.ff1, bb.h1, bb.a1, bb.u1, bb.mean[0], bb.rstd[0], dx_in_out, None, 1.0)
+        dx3 = a
+        if part in ("all", "a"):
+            # ---- ff2: y = x3 + 0.5*ff(x3)
+            self._ff_bwd(w, dx4, dyT_half, bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.mean[3], bb.rstd[3], a, w.dyT, 1.0)
+            # ---- conv module: y = x2 + conv(x2)
+            self._wgrad(w, w.dyT, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
+            self.k.gemm_nt(w.dyT, C["w2"][1], ds, N=ci, K=d)
+            self.k.bn_swish_bwd_reduce(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial)
+            self.k.reduce_partials_f64(w.partial, L.LN_PARTIAL_BLOCKS, 2 * ci, w.sums_local[:2 * ci])
+            w.sums[:2 * ci].copy_(w.sums_local[:2 * ci])          # all-reduced in place by the SyncBN collective under DP
+        if part in ("all", "b"):
+            dc = w.dmid2
+            self.k.bn_swish_bwd_apply(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.sums[:2 * ci],
+                                      w.sums_local[:2 * ci], M * self.world_size, dc, C["dbn_w"], C["dbn_b"])
+            self.k.dwconv_bwd_weight(dc, bb.g, C["ddw"].view(ci, K), C["ddwb"], w.dw_partial, B, T, pad_left)
+            dg = w.dmid3
+            self.k.dwconv_bwd_input(dc, C["dw"].view(ci, K), dg, B, T, pad_left)
+            dy1 = w.dbig.view(-1)[:M * 2 * ci].view(M, 2 * ci)
+            self.k.glu_bwd(bb.y, dg, dy1)
+            self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
+            self.k.gemm_nt(dy1, C["w1"][1], w.dh, N=d, K=2 * ci)
+            self.k.layernorm_bwd(w.dh, bb.x2, bb.mean[2], bb.rstd[2], C["ln_w"], w.partial, dres=dx3, dx=b, dxT=w.dyT,
+                                 dxT_scale=1.0, dgamma=C["dln_w"], dbeta=C["dln_b"], dtype=self.act_dtype)
+            dx2 = b
+            # ---- attention: y = x1 + attn(x1)
+            A = bp.attn
+            inner = bp.heads * bp.dh
+            self._wgrad(w, w.dyT, bb.o, A["dwo"], d, inner, A["dbo"])
+            do = w.dmid.view(-1)[:M * inner].view(M, inner)
+            self.k.gemm_nt(w.dyT, A["wo"][1], do, N=inner, K=d)
+            dqkv = w.dbig.view(-1)[:M * 3 * inner].view(M, 3 * inner)
+            self.k.attn_bwd(bb.qkv, A["emb"], bb.probs, do, dqkv, A["demb"], w.dsc, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
+            self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
+            self.k.gemm_nt(dqkv, A["wqkv"][1], w.dh, N=d, K=3 * inner)
+            self.k.layernorm_bwd(w.dh, bb.x1, bb.mean[1], bb.rstd[1], A["ln_w"], w.partial, dres=dx2, dx=a, dxT=w.dyT,
+                                 dxT_scale=0.5, dgamma=A["dln_w"], dbeta=A["dln_b"], dtype=self.act_dtype)
+            dx1 = a
+            # ---- ff1
+            self._ff_bwd(w, dx1, w.dyT, x_in, bp.ff1, bb.h1, bb.a1, bb.u1, bb.mean[0], bb.rstd[0], dx_in_out, None, 1.0)
 
     def backward(self, dlogits: torch.Tensor):
         """dlogits (B, T, V+1) f32 for the language of the last training forward.  Accumulates into ``grad``."""
@@ -548,7 +564,8 @@ class Engine:
         dfeat = torch.empty_like(w.dxa) if not hasattr(w, "dfeat") else w.dfeat
         w.dfeat = dfeat
         feat = ctx["feat"]
-        self._graphed(("hb", id(w), lang, feat.data_ptr()), lambda: self._block_bwd(w, feat, bp, bb, w.dxa, w.dyT, dfeat))
+        self._run_split(("hb", id(w), lang, feat.data_ptr()), lambda part: self._block_bwd(w, feat, bp, bb, w.dxa, w.dyT, dfeat, part),
+                        self._bn_collective(w, bp.conv["dw"].shape[0]))
         if self.on_stage_grads_ready:
             self.on_stage_grads_ready(f"head.{lang}")
         # encoder blocks in reverse
@@ -557,7 +574,8 @@ class Engine:
         for idx in reversed(range(len(kept))):
             i = kept[idx]
             x_in = w.enc[kept[idx - 1]].out if idx > 0 else (w.x0d if (cfg.pos_dropout > 0) else w.x0)
-            self._graphed(("eb", id(w), i, x_in.data_ptr()), lambda: self._enc_block_bwd(dfeat, x_in, i, w, dfeat))
+            self._run_split(("eb", id(w), i, x_in.data_ptr()), lambda part: self._enc_block_bwd(dfeat, x_in, i, w, dfeat, part),
+                            self._bn_collective(w, self.enc_params[i].conv["dw"].shape[0]))
             if self.on_stage_grads_ready:
                 self.on_stage_grads_ready(f"enc.{i}")
         # front end: x0 = sqrt(d) * (r @ Wl^T + b) [dropout]; r = relu(col @ Wc^T + bc)
