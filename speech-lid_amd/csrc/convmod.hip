@@ -52,17 +52,28 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
               float* __restrict__ stat_partial, int B, int T_, int C, int K, int pad_left, int flip) {
-  __shared__ T tile[DW_ROWS][64];
+  __shared__ __attribute__((aligned(16))) T tile[DW_ROWS][64];
   __shared__ float red[4][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * 64, b = blockIdx.z;
   const int ch = c0 + lane;
   const bool chok = ch < C;
-  for (int r = wave; r < DW_ROWS; r += 4) {
-    int t = t0 - pad_left + r;
-    T v = from_f<T>(0.f);
-    if (chok && t >= 0 && t < T_ && r < DW_TT + K - 1) v = in[((size_t)b * T_ + t) * C + ch];
-    tile[r][lane] = v;
+  // stage [rows][64 channels] with 16-byte loads (8 bf16 / 4 f32 channels per lane) when the channel chunk is full
+  constexpr int VE = 16 / sizeof(T), CPR = 64 / VE;
+  if (c0 + 64 <= C && (C % VE) == 0) {
+    for (int q = threadIdx.x; q < DW_ROWS * CPR; q += 256) {
+      int r = q / CPR, cc = (q % CPR) * VE, t = t0 - pad_left + r;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (t >= 0 && t < T_ && r < DW_TT + K - 1) v = *reinterpret_cast<const uint4*>(in + ((size_t)b * T_ + t) * C + c0 + cc);
+      *reinterpret_cast<uint4*>(&tile[r][cc]) = v;
+    }
+  } else {
+    for (int r = wave; r < DW_ROWS; r += 4) {
+      int t = t0 - pad_left + r;
+      T v = from_f<T>(0.f);
+      if (chok && t >= 0 && t < T_ && r < DW_TT + K - 1) v = in[((size_t)b * T_ + t) * C + ch];
+      tile[r][lane] = v;
+    }
   }
   float wr[DW_KMAX];
 #pragma unroll
@@ -121,8 +132,8 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 dwconv_wgrad_kernel(const T* __restrict__ dc, const T* __restrict__ g, float* __restrict__ partial, int B, int T_, int C,
                     int K, int pad_left) {
-  __shared__ T gt[DW_ROWS][64];
-  __shared__ T dt[DW_TT][64];
+  __shared__ __attribute__((aligned(16))) T gt[DW_ROWS][64];
+  __shared__ __attribute__((aligned(16))) T dt[DW_TT][64];
   __shared__ float red[4][DW_KMAX + 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = blockIdx.x * 64, b = blockIdx.y, ch = c0 + lane;
@@ -132,13 +143,29 @@ dwconv_wgrad_kernel(const T* __restrict__ dc, const T* __restrict__ g, float* __
   for (int k = 0; k <= DW_KMAX; ++k) acc[k] = 0.f;
   for (int t0 = 0; t0 < T_; t0 += DW_TT) {
     __syncthreads();
-    for (int r = wave; r < DW_ROWS; r += 4) {
-      int t = t0 - pad_left + r;
-      gt[r][lane] = (chok && t >= 0 && t < T_) ? g[((size_t)b * T_ + t) * C + ch] : from_f<T>(0.f);
-    }
-    for (int r = wave; r < DW_TT; r += 4) {
-      int t = t0 + r;
-      dt[r][lane] = (chok && t < T_) ? dc[((size_t)b * T_ + t) * C + ch] : from_f<T>(0.f);
+    constexpr int VE = 16 / sizeof(T), CPR = 64 / VE;
+    if (c0 + 64 <= C && (C % VE) == 0) {
+      for (int q = threadIdx.x; q < DW_ROWS * CPR; q += 256) {
+        int r = q / CPR, cc = (q % CPR) * VE, t = t0 - pad_left + r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t >= 0 && t < T_) v = *reinterpret_cast<const uint4*>(g + ((size_t)b * T_ + t) * C + c0 + cc);
+        *reinterpret_cast<uint4*>(&gt[r][cc]) = v;
+      }
+      for (int q = threadIdx.x; q < DW_TT * CPR; q += 256) {
+        int r = q / CPR, cc = (q % CPR) * VE, t = t0 + r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t < T_) v = *reinterpret_cast<const uint4*>(dc + ((size_t)b * T_ + t) * C + c0 + cc);
+        *reinterpret_cast<uint4*>(&dt[r][cc]) = v;
+      }
+    } else {
+      for (int r = wave; r < DW_ROWS; r += 4) {
+        int t = t0 - pad_left + r;
+        gt[r][lane] = (chok && t >= 0 && t < T_) ? g[((size_t)b * T_ + t) * C + ch] : from_f<T>(0.f);
+      }
+      for (int r = wave; r < DW_TT; r += 4) {
+        int t = t0 + r;
+        dt[r][lane] = (chok && t < T_) ? dc[((size_t)b * T_ + t) * C + ch] : from_f<T>(0.f);
+      }
     }
     __syncthreads();
     float x[8 + DW_KMAX - 1];
@@ -247,26 +274,48 @@ extern "C" int lidk_bn_swish_fwd(const void* c, const float* mean, const float* 
 // ------------------------------------------------------------------------------------ BatchNorm + Swish backward
 __device__ __forceinline__ float swish_grad(float z) { float s = sigmoidf_(z); return s * (1.f + z * (1.f - s)); }
 
+// Column reduction over M rows of (dz, dz*xhat): a thread owns 4 consecutive channels (8/16-byte loads) and every
+// (256 / (C/4))-th row of its workgroup's row set; row-lanes are combined through LDS.  C % 4 == 0, C <= 1024.
 template <typename T>
-__global__ void bn_swish_bwd_reduce_kernel(const T* __restrict__ ds, const T* __restrict__ c, const float* __restrict__ mean,
-                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                           const float* __restrict__ beta, float* __restrict__ partial, int M, int C) {
-  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
-    const float mu = mean[ch], rs = rstd[ch], g = gamma[ch], b = beta[ch];
-    float a0 = 0.f, a1 = 0.f;
-    for (int m = blockIdx.x; m < M; m += gridDim.x) {
-      float xh = (to_f(c[(size_t)m * C + ch]) - mu) * rs;
-      float dz = to_f(ds[(size_t)m * C + ch]) * swish_grad(xh * g + b);
-      a0 += dz; a1 = fmaf(dz, xh, a1);
+__global__ void __launch_bounds__(256)
+bn_swish_bwd_reduce_kernel(const T* __restrict__ ds, const T* __restrict__ c, const float* __restrict__ mean,
+                           const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                           float* __restrict__ partial, int M, int C) {
+  __shared__ float red[256][8];
+  const int groups = C / 4, rl_n = 256 / groups;          // channel groups, row lanes
+  const int cg = threadIdx.x % groups, rl = threadIdx.x / groups;
+  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (rl < rl_n) {
+    const int ch = cg * 4;
+    const float4 mu = load4(mean + ch), rs = load4(rstd + ch), g = load4(gamma + ch), b = load4(beta + ch);
+    for (int m = blockIdx.x * rl_n + rl; m < M; m += gridDim.x * rl_n) {
+      float4 x = load4(c + (size_t)m * C + ch), d = load4(ds + (size_t)m * C + ch);
+      float xh, dz;
+      xh = (x.x - mu.x) * rs.x; dz = d.x * swish_grad(xh * g.x + b.x); a0[0] += dz; a1[0] = fmaf(dz, xh, a1[0]);
+      xh = (x.y - mu.y) * rs.y; dz = d.y * swish_grad(xh * g.y + b.y); a0[1] += dz; a1[1] = fmaf(dz, xh, a1[1]);
+      xh = (x.z - mu.z) * rs.z; dz = d.z * swish_grad(xh * g.z + b.z); a0[2] += dz; a1[2] = fmaf(dz, xh, a1[2]);
+      xh = (x.w - mu.w) * rs.w; dz = d.w * swish_grad(xh * g.w + b.w); a0[3] += dz; a1[3] = fmaf(dz, xh, a1[3]);
     }
-    partial[((size_t)blockIdx.x * 2 + 0) * C + ch] = a0;
-    partial[((size_t)blockIdx.x * 2 + 1) * C + ch] = a1;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { red[threadIdx.x][q] = a0[q]; red[threadIdx.x][4 + q] = a1[q]; }
+  __syncthreads();
+  if (threadIdx.x < groups) {
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < rl_n; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { s0[q] += red[r * groups + cg][q]; s1[q] += red[r * groups + cg][4 + q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      partial[((size_t)blockIdx.x * 2 + 0) * C + cg * 4 + q] = s0[q];
+      partial[((size_t)blockIdx.x * 2 + 1) * C + cg * 4 + q] = s1[q];
+    }
   }
 }
 extern "C" int lidk_bn_swish_bwd_reduce(const void* ds, const void* c, const float* mean, const float* rstd,
                                         const float* gamma, const float* beta, float* partial, int M, int C, int dtype,
                                         void* stream) {
-  if (!ds || !c || !mean || !rstd || !gamma || !beta || !partial || M <= 0 || C <= 0) return LIDK_ERR_ARG;
+  if (!ds || !c || !mean || !rstd || !gamma || !beta || !partial || M <= 0 || C <= 0 || (C & 3) || C > 1024) return LIDK_ERR_ARG;
   // always LIDK_LN_PARTIAL_BLOCKS partial rows; blocks beyond M write zeros
   LIDK_DISPATCH(dtype, bn_swish_bwd_reduce_kernel<T><<<LIDK_LN_PARTIAL_BLOCKS, 256, 0, as_stream(stream)>>>(
                            (const T*)ds, (const T*)c, mean, rstd, gamma, beta, partial, M, C));

@@ -325,7 +325,7 @@ extern "C" int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, 
     return LIDK_ERR_ARG;
   if (dy_dtype != LIDK_F32 && dy_dtype != dtype) return LIDK_ERR_ARG;
   hipStream_t s = as_stream(stream);
-  int G = cdiv(M, 4) < LIDK_LN_PARTIAL_BLOCKS ? cdiv(M, 4) : LIDK_LN_PARTIAL_BLOCKS;
+  int G = cdiv(M, 4) < LIDK_LN_BWD_BLOCKS ? cdiv(M, 4) : LIDK_LN_BWD_BLOCKS;   // one wave per row in flight: latency-bound otherwise
   if (dy_dtype == LIDK_F32) {
     LIDK_DISPATCH(dtype, ln_bwd_kernel<T, float><<<G, 256, 0, s>>>((const float*)dy, x, mean, rstd, gamma, dres, dx,
                                                                   (T*)dxT, dxT_scale, partial, M, C));

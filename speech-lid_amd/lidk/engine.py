@@ -151,7 +151,7 @@ class _Work:
         self.dxa, self.dxb = f(M, d), f(M, d)
         hmax = max(cfg.heads, cfg.last_heads)
         self.dsc = f(B, hmax, T, (T + 31) // 32 * 32)
-        self.partial = f(L.LN_PARTIAL_BLOCKS * 2 * cmax)
+        self.partial = f(max(L.LN_PARTIAL_BLOCKS * 2 * cmax, L.LN_BWD_BLOCKS * 2 * d))
         self.stat_parts = eng.k.dwconv_stat_parts(B, T)
         self.stat_partial = f(self.stat_parts * 2 * ci)
         self.dw_partial = f(B * ci * (max(cfg.conv_kernel_size, 31) + 1))

@@ -114,7 +114,7 @@ def test_layernorm_fwd_bwd(dt, M, C):
     dxT = torch.empty(M, C, device=DEV, dtype=dt)
     dgam = torch.full((C,), 1.0, device=DEV)
     dbet = torch.full((C,), -1.0, device=DEV)
-    partial = torch.empty(L.LN_PARTIAL_BLOCKS * 2 * C, device=DEV)
+    partial = torch.empty(L.LN_BWD_BLOCKS * 2 * C, device=DEV)
     ops.layernorm_bwd(dev(dy, dt), xd, mean, rstd, gd, partial, dres=dev(dres), dx=dx, dxT=dxT, dxT_scale=0.5,
                       dgamma=dgam, dbeta=dbet)
     check("ln_bwd_dx", dx, x.grad + dres, 5e-5, 1e-5)
