@@ -18,10 +18,6 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
   return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
 }
 
-extern "C" long lidk_ctc_workspace_bytes(int B, int T_, int V1, int Lmax) {
-  (void)V1;
-  return (long)B * T_ * (2 * Lmax + 1) * (long)sizeof(float);
-}
 
 // dynamic LDS: lse[T] | beta0[Smax] | beta1[Smax] | ab[Smax] | lab[Smax] (int) | nxt[Smax] (int) | first[Smax] (int)
 __global__ void __launch_bounds__(256)
@@ -138,6 +134,157 @@ ctc_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets
 #undef LP
 }
 
+
+// ------------------------------------------------------------------------------------ CTC fast path (3 launches)
+// The O(T) recursions are the only sequential part of CTC, so they get a kernel of their own that touches nothing but LDS;
+// everything that is parallel over frames runs chip-wide, one wave per (utterance, frame) row:
+//   1. ctc_prep_kernel     row log-sum-exp + label log-probs lpl[b][t][s] = log_softmax(logits)[b][t][l'_s]
+//   2. ctc_lattice_kernel  per utterance: wave 0 runs alpha, wave 1 runs beta (independent recursions, concurrently),
+//                          wave 2 builds the same-label chains; rows are streamed to the workspace as they are produced
+//   3. ctc_grad_kernel     dlogits row = gscale * (softmax - sum_{s: l'_s = c} posterior(s, t))
+// workspace (4-byte words): lse[B*T] | nll[B] | lpl[B*T*Smax] | alpha[B*T*Smax] | beta[B*T*Smax] | nxt[B*Smax] | first[B*Smax]
+struct CtcWs { float *lse, *nll, *lpl, *alpha, *beta; int *nxt, *first; };
+static inline CtcWs ctc_ws(void* w, int B, int T_, int Smax) {
+  CtcWs r; float* f = (float*)w; size_t lat = (size_t)B * T_ * Smax;
+  r.lse = f; f += (size_t)B * T_; r.nll = f; f += B; r.lpl = f; f += lat; r.alpha = f; f += lat; r.beta = f; f += lat;
+  r.nxt = (int*)f; r.first = r.nxt + (size_t)B * Smax; return r;
+}
+extern "C" long lidk_ctc_workspace_bytes(int B, int T_, int V1, int Lmax) {
+  (void)V1; long S = 2 * Lmax + 1;
+  return ((long)B * T_ * (3 * S + 1) + B + 2 * (long)B * S) * (long)sizeof(float);
+}
+
+__global__ void __launch_bounds__(256)
+ctc_prep_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets, const int64_t* __restrict__ tg_len,
+                float* __restrict__ lse, float* __restrict__ lpl, int rows, int T_, int V1, int Lmax, int blank) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int b = row / T_, Smax = 2 * Lmax + 1;
+  const float* lg = logits + (size_t)row * V1;
+  float mx = NEG_INF;
+  for (int c = lane; c < V1; c += 64) mx = fmaxf(mx, lg[c]);
+  mx = wave_max(mx);
+  float sm = 0.f;
+  for (int c = lane; c < V1; c += 64) sm += __expf(lg[c] - mx);
+  sm = wave_sum(sm);
+  const float l = mx + __logf(sm);
+  if (lane == 0) lse[row] = l;
+  int Lb = (int)tg_len[b]; if (Lb > Lmax) Lb = Lmax; if (Lb < 0) Lb = 0;
+  const int S = 2 * Lb + 1;
+  for (int s = lane; s < S; s += 64) {
+    int c = (s & 1) ? (int)targets[(size_t)b * Lmax + (s >> 1)] : blank;
+    lpl[(size_t)row * Smax + s] = lg[c] - l;
+  }
+}
+
+// dynamic LDS: lp[T][Smax] | a0 a1 b0 b1 [Smax] | lab[Smax] (int)
+__global__ void __launch_bounds__(192)
+ctc_lattice_kernel(const int64_t* __restrict__ targets, const int64_t* __restrict__ in_len, const int64_t* __restrict__ tg_len,
+                   float* __restrict__ loss, CtcWs ws, int T_, int Lmax, int blank, int zero_inf) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int Smax = 2 * Lmax + 1;
+  float* lp = reinterpret_cast<float*>(smem);
+  float* rowbuf = lp + (size_t)T_ * Smax;
+  int* lab = reinterpret_cast<int*>(rowbuf + 4 * Smax);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int Tb = (int)in_len[b]; if (Tb > T_) Tb = T_; if (Tb < 0) Tb = 0;
+  int Lb = (int)tg_len[b]; if (Lb > Lmax) Lb = Lmax; if (Lb < 0) Lb = 0;
+  const int S = 2 * Lb + 1;
+  const float* glp = ws.lpl + (size_t)b * T_ * Smax;
+  for (int i = tid; i < Tb * Smax; i += 192) lp[i] = glp[i];
+  for (int s = tid; s < S; s += 192) lab[s] = (s & 1) ? (int)targets[(size_t)b * Lmax + (s >> 1)] : blank;
+  __syncthreads();
+  if (Tb == 0) {
+    if (tid == 0) { float v = (Lb == 0) ? 0.f : INFINITY; ws.nll[b] = v; loss[b] = (v == INFINITY && zero_inf) ? 0.f : v; }
+    return;
+  }
+  if (wave == 0) {                                   // alpha, forwards
+    float* ga = ws.alpha + (size_t)b * T_ * Smax;
+    float* cur = rowbuf; float* prv = rowbuf + Smax;
+    for (int s = lane; s < S; s += 64) { float v = (s < 2) ? lp[s] : NEG_INF; cur[s] = v; ga[s] = v; }
+    __builtin_amdgcn_wave_barrier();
+    for (int t = 1; t < Tb; ++t) {
+      float* tmp = cur; cur = prv; prv = tmp;
+      for (int s = lane; s < S; s += 64) {
+        float a0 = prv[s];
+        float a1 = s >= 1 ? prv[s - 1] : NEG_INF;
+        float a2 = (s >= 2 && (s & 1) && lab[s] != lab[s - 2]) ? prv[s - 2] : NEG_INF;
+        float v = lse3(a0, a1, a2) + lp[(size_t)t * Smax + s];
+        cur[s] = v; ga[(size_t)t * Smax + s] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+      float nll = -lse2(cur[S - 1], S >= 2 ? cur[S - 2] : NEG_INF);
+      ws.nll[b] = nll;
+      loss[b] = (nll == INFINITY && zero_inf) ? 0.f : nll;
+    }
+  } else if (wave == 1) {                            // beta, backwards
+    float* gb = ws.beta + (size_t)b * T_ * Smax;
+    float* cur = rowbuf + 2 * Smax; float* nx = rowbuf + 3 * Smax;
+    for (int s = lane; s < S; s += 64) {
+      float v = (s >= S - 2) ? lp[(size_t)(Tb - 1) * Smax + s] : NEG_INF; cur[s] = v; gb[(size_t)(Tb - 1) * Smax + s] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int t = Tb - 2; t >= 0; --t) {
+      float* tmp = cur; cur = nx; nx = tmp;
+      for (int s = lane; s < S; s += 64) {
+        float b0 = nx[s];
+        float b1 = s + 1 < S ? nx[s + 1] : NEG_INF;
+        float b2 = (s + 2 < S && (s & 1) && lab[s] != lab[s + 2]) ? nx[s + 2] : NEG_INF;
+        float v = lse3(b0, b1, b2) + lp[(size_t)t * Smax + s];
+        cur[s] = v; gb[(size_t)t * Smax + s] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {                                           // same-label chains (first occurrence + next occurrence)
+    for (int s = lane; s < S; s += 64) {
+      int me = lab[s], n = -1, f = 1;
+      for (int u = s + 1; u < S; ++u) if (lab[u] == me) { n = u; break; }
+      for (int u = 0; u < s; ++u) if (lab[u] == me) { f = 0; break; }
+      ws.nxt[(size_t)b * Smax + s] = n; ws.first[(size_t)b * Smax + s] = f;
+    }
+  }
+}
+
+// dynamic LDS per wave: post[Smax] | corr[V1]
+__global__ void __launch_bounds__(256)
+ctc_grad_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets, const int64_t* __restrict__ in_len,
+                const int64_t* __restrict__ tg_len, float* __restrict__ dlogits, CtcWs ws, int rows, int T_, int V1, int Lmax,
+                int blank, float gscale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int Smax = 2 * Lmax + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  float* post = reinterpret_cast<float*>(smem) + (size_t)wave * (Smax + V1);
+  float* corr = post + Smax;
+  const int b = row / T_, t = row - b * T_;
+  float* dl = dlogits + (size_t)row * V1;
+  int Tb = (int)in_len[b]; if (Tb > T_) Tb = T_; if (Tb < 0) Tb = 0;
+  const float nll = ws.nll[b];
+  if (t >= Tb || nll == INFINITY || nll != nll) {    // padded frame, or zero_infinity: zero gradient as torch does
+    for (int c = lane; c < V1; c += 64) dl[c] = 0.f;
+    return;
+  }
+  int Lb = (int)tg_len[b]; if (Lb > Lmax) Lb = Lmax; if (Lb < 0) Lb = 0;
+  const int S = 2 * Lb + 1;
+  const size_t lo = (size_t)row * Smax;
+  for (int s = lane; s < S; s += 64) post[s] = ws.alpha[lo + s] + ws.beta[lo + s] + nll - ws.lpl[lo + s];   // log posterior
+  for (int c = lane; c < V1; c += 64) corr[c] = 0.f;
+  __builtin_amdgcn_wave_barrier();
+  for (int s = lane; s < S; s += 64) {
+    if (!ws.first[(size_t)b * Smax + s]) continue;
+    float acc = post[s];
+    for (int u = ws.nxt[(size_t)b * Smax + s]; u >= 0; u = ws.nxt[(size_t)b * Smax + u]) acc = lse2(acc, post[u]);
+    int c = (s & 1) ? (int)targets[(size_t)b * Lmax + (s >> 1)] : blank;
+    corr[c] = __expf(acc);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float* lg = logits + (size_t)row * V1;
+  const float l = ws.lse[row];
+  for (int c = lane; c < V1; c += 64) dl[c] = gscale * (__expf(lg[c] - l) - corr[c]);
+}
+
 extern "C" int lidk_ctc_loss(const float* logits, const int64_t* targets, const int64_t* in_len, const int64_t* tg_len,
                              float* loss, float* dlogits, void* workspace, int B, int T_, int V1, int Lmax, int blank,
                              float grad_scale, int zero_infinity, void* stream) {
@@ -145,6 +292,22 @@ extern "C" int lidk_ctc_loss(const float* logits, const int64_t* targets, const 
       blank < 0 || blank >= V1)
     return LIDK_ERR_ARG;
   const int Smax = 2 * Lmax + 1;
+  const size_t fast = ((size_t)T_ * Smax + 4 * Smax) * sizeof(float) + (size_t)Smax * sizeof(int);
+  const size_t glds = (size_t)4 * (Smax + V1) * sizeof(float);
+  if (fast <= 150 * 1024 && glds <= 150 * 1024) {
+    hipStream_t st = as_stream(stream);
+    CtcWs ws = ctc_ws(workspace, B, T_, Smax);
+    const int rows = B * T_;
+    ctc_prep_kernel<<<(rows + 3) / 4, 256, 0, st>>>(logits, targets, tg_len, ws.lse, ws.lpl, rows, T_, V1, Lmax, blank);
+    (void)hipFuncSetAttribute((const void*)ctc_lattice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);
+    ctc_lattice_kernel<<<B, 192, fast, st>>>(targets, in_len, tg_len, loss, ws, T_, Lmax, blank, zero_infinity);
+    if (dlogits) {
+      (void)hipFuncSetAttribute((const void*)ctc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+      ctc_grad_kernel<<<(rows + 3) / 4, 256, glds, st>>>(logits, targets, in_len, tg_len, dlogits, ws, rows, T_, V1, Lmax, blank,
+                                                         grad_scale);
+    }
+    return launch_status();
+  }
   size_t lds = (size_t)(T_ + 3 * Smax) * sizeof(float) + (size_t)3 * Smax * sizeof(int);
   if (lds > 150 * 1024) return LIDK_ERR_UNSUPPORTED;
   (void)hipFuncSetAttribute((const void*)ctc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -423,6 +423,9 @@ def _ctc_case(B, T, V, Lmax, seed, in_len, tg_len, force_repeat=True):
     dict(B=3, T=151, V=40, Lmax=20, in_len=[151, 151, 100], tg_len=[20, 20, 20]),
     dict(B=3, T=20, V=5, Lmax=12, in_len=[20, 8, 20], tg_len=[12, 12, 0]),        # utt 1 infeasible -> zero_infinity
     dict(B=2, T=300, V=4441, Lmax=60, in_len=[300, 280], tg_len=[60, 33]),        # large vocabulary (the reference's "cn")
+    dict(B=2, T=400, V=40, Lmax=60, in_len=[400, 333], tg_len=[60, 41]),          # lattice > LDS: one-workgroup fallback kernel
+    dict(B=3, T=20, V=5, Lmax=4, in_len=[20, 0, 0], tg_len=[4, 0, 3]),            # empty inputs
+    dict(B=2, T=100, V=30, Lmax=40, in_len=[100, 90], tg_len=[40, 35]),           # S = 81 > one wave
 ])
 def test_ctc_loss_and_grad(case):
     B, T, V, Lmax = case["B"], case["T"], case["V"], case["Lmax"]
