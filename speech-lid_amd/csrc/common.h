@@ -26,7 +26,8 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the GEMM epilogues were VALU-issue bound on it
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // 4-wide load/store of activations held as T (float or bf16); p must be 4-element aligned.
 __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -193,6 +193,172 @@ gemm_nt_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int 
   }
 }
 
+// ------------------------------------------------------------------------------------ bf16 MFMA kernel, direct epilogue
+// Same operand staging as gemm_nt_bf16_kernel (full 128-byte row segments global -> registers -> LDS, one K tile ahead),
+// with the three changes the counters asked for (rocprofv3 --pmc on the ff-up shape: 32 % of the LDS cycles were bank
+// conflicts, the epilogue was VALU-issue bound):
+//   * LDS tiles are unpadded [rows][64] bf16 with the 16-byte chunk index XOR-ed by (row & 7): every 16-lane group of a
+//     ds_read_b128 then covers all 16 slots of the 256-byte bank row, and the ds_write_b128 groups stay one full row;
+//   * the MFMA is issued "transposed" (B fragment as the first operand), so a lane's 4 accumulator registers are 4
+//     CONSECUTIVE output columns of one row: bias/residual/aux loads and the stores are 16-byte accesses straight from
+//     registers, no LDS staging pass and no barrier after the K loop;
+//   * for bf16 outputs the rows of the B tile are permuted when written to LDS so that two adjacent 16-column tiles give a
+//     lane 8 consecutive columns (one 16-byte store; a wave instruction covers 16 rows x 64 contiguous bytes).
+__device__ __forceinline__ float4 epi_math4(const Epi& e, int m, int n, float4 v, float4* pre) {
+  if (e.bias) { float4 b = load4(e.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+  if (e.act == LIDK_ACT_SWISH) {
+    *pre = v;
+    v.x *= sigmoidf_(v.x); v.y *= sigmoidf_(v.y); v.z *= sigmoidf_(v.z); v.w *= sigmoidf_(v.w);
+  } else if (e.act == LIDK_ACT_RELU) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  } else if (e.act == LIDK_ACT_SWISH_GRAD) {
+    float4 a = load4((const bf16*)e.aux + (size_t)m * e.ldaux + n);
+    float s;
+    s = sigmoidf_(a.x); v.x *= s * (1.f + a.x * (1.f - s));
+    s = sigmoidf_(a.y); v.y *= s * (1.f + a.y * (1.f - s));
+    s = sigmoidf_(a.z); v.z *= s * (1.f + a.z * (1.f - s));
+    s = sigmoidf_(a.w); v.w *= s * (1.f + a.w * (1.f - s));
+  }
+  v.x *= e.alpha; v.y *= e.alpha; v.z *= e.alpha; v.w *= e.alpha;
+  if (e.res) { float4 r = load4(e.res + (size_t)m * e.ldres + n); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+  return v;
+}
+__device__ __forceinline__ uint4 pack8(float4 a, float4 b) {
+  union { bf16 h[8]; uint4 u; } p;
+  p.h[0] = from_f<bf16>(a.x); p.h[1] = from_f<bf16>(a.y); p.h[2] = from_f<bf16>(a.z); p.h[3] = from_f<bf16>(a.w);
+  p.h[4] = from_f<bf16>(b.x); p.h[5] = from_f<bf16>(b.y); p.h[6] = from_f<bf16>(b.z); p.h[7] = from_f<bf16>(b.w);
+  return p.u;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+gemm_nt_bf16_direct_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K, int lda, int ldb, Epi e) {
+  constexpr int TM = BM / 32, TN = BN / 32;        // 16x16 tiles per wave along M / N (TN is even: tiles pair up)
+  constexpr int CA = BM / 32, CB = BN / 32;        // 16-byte chunks per thread per K tile
+  __shared__ __attribute__((aligned(16))) bf16 As[BM * BK];
+  __shared__ __attribute__((aligned(16))) bf16 Bs[BN * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const bool pair = !e.out_f32;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Two K tiles of global loads are kept in flight per thread in two NAMED register sets.  Every load is unconditional
+  // (host guarantees K % 64 == 0; row index clamped - rows past M / N only feed outputs that are never stored) and the
+  // last tiles run in a peeled tail without prefetch: a predicated load becomes an exec-mask branch and hipcc then waits
+  // vmcnt(0) before every LDS write, draining the other stage as well (measured: no gain from any prefetch depth);
+  // stage arrays indexed by a variable fall to scratch memory.
+  u32x4 ra0[CA], rb0[CB], ra1[CA], rb1[CB];
+  auto gload = [&](u32x4 (&ra)[CA], u32x4 (&rb)[CB], int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      int c = tid + i * 256, row = c >> 3, kc = (c & 7) * 8;
+      ra[i] = *reinterpret_cast<const u32x4*>(A + (size_t)min(m0 + row, M - 1) * lda + k0 + kc);
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      int c = tid + i * 256, row = c >> 3, kc = (c & 7) * 8;
+      rb[i] = *reinterpret_cast<const u32x4*>(B + (size_t)min(n0 + row, N - 1) * ldb + k0 + kc);
+    }
+  };
+  auto lstore = [&](const u32x4 (&ra)[CA], const u32x4 (&rb)[CB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      int c = tid + i * 256, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<u32x4*>(&As[row * BK + ((ch ^ (row & 7)) << 3)]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      int c = tid + i * 256, row = c >> 3, ch = c & 7;
+      // bf16 outputs: column j of a 32-column group sits at LDS row (j>>2 & 1)*16 + (j>>3)*4 + (j&3) of that group
+      int rho = pair ? (row & ~31) + (((row >> 2) & 1) << 4) + (((row >> 3) & 3) << 2) + (row & 3) : row;
+      *reinterpret_cast<u32x4*>(&Bs[rho * BK + ((ch ^ (rho & 7)) << 3)]) = rb[i];
+    }
+  };
+  auto mma = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; kk += 4) {             // kk: 16-byte chunk index of this 32-wide K step
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * (BM / 2) + i * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * (BN / 2) + j * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+  // one K tile: registers -> LDS, refill the register set with the tile two ahead (k_next >= 0), MFMAs
+  auto stage = [&](u32x4 (&ra)[CA], u32x4 (&rb)[CB], int k_next) __attribute__((always_inline)) {
+    lstore(ra, rb);
+    __syncthreads();
+    if (k_next >= 0) gload(ra, rb, k_next);              // compile-time after inlining: callers pass a constant -1 or a real k
+    mma();
+    __syncthreads();
+  };
+  const int nt = K / BK;
+  gload(ra0, rb0, 0);
+  if (nt > 1) gload(ra1, rb1, BK);
+  int t = 0;
+  for (; t + 3 < nt; t += 2) {
+    stage(ra0, rb0, (t + 2) * BK);
+    stage(ra1, rb1, (t + 3) * BK);
+  }
+  if (nt - t == 3) {
+    stage(ra0, rb0, (t + 2) * BK);
+    stage(ra1, rb1, -1);
+    stage(ra0, rb0, -1);
+  } else if (nt - t == 2) {
+    stage(ra0, rb0, -1);
+    stage(ra1, rb1, -1);
+  } else {
+    stage(ra0, rb0, -1);
+  }
+
+  // lane (fr, fq) holds, for row tile i and column tile j, row m = ... + fr and 4 consecutive columns
+  const bool vec = !(e.ldo & 7) && (!e.res || !(e.ldres & 3)) && (!e.out2 || !(e.ldo2 & 7)) && (!e.aux || !(e.ldaux & 7));
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 16 + fr;
+    if (m >= M) continue;
+    if (pair) {
+#pragma unroll
+      for (int c = 0; c < TN / 2; ++c) {
+        const int n = n0 + wn * (BN / 2) + 32 * c + 8 * fq;
+        const float4 a0 = make_float4(acc[i][2 * c][0], acc[i][2 * c][1], acc[i][2 * c][2], acc[i][2 * c][3]);
+        const float4 a1 = make_float4(acc[i][2 * c + 1][0], acc[i][2 * c + 1][1], acc[i][2 * c + 1][2], acc[i][2 * c + 1][3]);
+        if (vec && n + 7 < N) {
+          float4 p0, p1;
+          float4 v0 = epi_math4(e, m, n, a0, &p0);
+          float4 v1 = epi_math4(e, m, n + 4, a1, &p1);
+          if (e.act == LIDK_ACT_SWISH && e.out2) *reinterpret_cast<uint4*>((bf16*)e.out2 + (size_t)m * e.ldo2 + n) = pack8(p0, p1);
+          *reinterpret_cast<uint4*>((bf16*)e.out + (size_t)m * e.ldo + n) = pack8(v0, v1);
+        } else {
+          epi_store4<bf16>(e, m, n, N, a0);
+          epi_store4<bf16>(e, m, n + 4, N, a1);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + 16 * j + 4 * fq;
+        epi_store4<bf16>(e, m, n, N, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ f32 kernel (parity mode)
 __global__ void __launch_bounds__(256)
 gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, int M, int N, int K, int lda, int ldb,
@@ -249,6 +415,13 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
     // tile choice: measured on MI355X (tools/gemm_bench.py), the 64x64 tile wins on every shape of this model (K = 256..1024:
     // only 4..16 K-tiles, so many small workgroups per CU hide the load latency better than one big tile does); the 128x128
     // variant is kept for long-K problems and can be forced with LIDK_GEMM_TILE=128.
+    static const int direct = getenv("LIDK_GEMM_DIRECT") ? atoi(getenv("LIDK_GEMM_DIRECT")) : 1;
+    if (direct && splitk == 1 && !dbg && (g->K & 63) == 0) {
+      dim3 grid(cdiv(g->N, 64), cdiv(g->M, 64), 1);
+      gemm_nt_bf16_direct_kernel<64, 64><<<grid, 256, 0, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->K, g->lda,
+                                                             g->ldb, e);
+      return launch_status();
+    }
     long big = (long)cdiv(g->M, 128) * cdiv(g->N, 128) * splitk;
     static const int force_tile = getenv("LIDK_GEMM_TILE") ? atoi(getenv("LIDK_GEMM_TILE")) : 0;
     if (force_tile == 128 || (force_tile != 64 && big >= 384 && g->K >= 4096)) {

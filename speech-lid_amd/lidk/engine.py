@@ -10,6 +10,7 @@ torch provides memory and the current stream only; all arithmetic is lidk kernel
 Reference semantics followed: lid/conformer.py:252-259 (block), :445-466 (encoder, stochastic depth),
 lid/ConformerLangModel.py:272-294,352-356 (heads).
 """
+import contextlib
 import math
 from typing import Callable, Dict, List, Optional
 
@@ -19,6 +20,11 @@ from . import _lib as L
 from . import ops
 from ._lib import LidkError
 from .layout import ALIGN, ConformerCfg, Spec, init_values, model_specs
+
+
+def _os_env(k, d):
+    import os
+    return os.environ.get(k, d)
 
 
 def _ceil(a, b):
@@ -142,12 +148,17 @@ class _Work:
         cmax = max(ff, 2 * ci, 3 * cfg.heads * cfg.dim_head, 3 * cfg.last_heads * cfg.last_dim_head, 4 * d, 3 * cfg.n_mels,
                    self.v1p)
         self.cmax = cmax
-        self.dbig = e(M, cmax)                                # da / dy_pw1 / dqkv
+        # Each weight-gradient site of a block backward reads its own dY buffer, so the wgrad GEMMs can run on the side
+        # stream while the main stream continues down the dgrad chain without ever overwriting what they read.
+        self.da = [e(M, ff), e(M, ff)]                        # ff2 / ff1 hidden gradients
+        self.dy1 = e(M, 2 * ci)                               # conv pointwise-1 output gradient
+        self.dqkv = e(M, 3 * max(cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head))
+        self.dyTs = [e(M, d) for _ in range(4)]               # T-typed dx at: block output, x3, x2, x1
         self.dmid = e(M, max(ci, cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head, d))   # ds / do
         self.dmid2 = e(M, ci)
         self.dmid3 = e(M, ci)
         self.dh = e(M, d)
-        self.dyT = e(M, d)
+        self.dyT = self.dyTs[0]
         self.dxa, self.dxb = f(M, d), f(M, d)
         hmax = max(cfg.heads, cfg.last_heads)
         self.dsc = f(B, hmax, T, (T + 31) // 32 * 32)
@@ -188,6 +199,9 @@ class Engine:
         self.world_size = 1
         self.seed = 0
         self.step_count = 0
+        # Optional second HIP stream for the weight-gradient GEMMs (LIDK_SIDE_STREAM=1).  Off by default: measured on MI355X
+        # the fork/join edges inside the captured graphs cost more than the overlap wins (13.0 vs 11.85 ms/step, cfg2).
+        self.side = None
 
     # ------------------------------------------------------------------ parameters
     def reset_parameters(self):
@@ -211,6 +225,8 @@ class Engine:
         self.grad = torch.zeros_like(self.flat)
         self.buffers = {k: v.to(device) for k, v in self.buffers.items()}
         self._build_operands()
+        if self._hip and device.type == "cuda" and _os_env("LIDK_SIDE_STREAM", "0") == "1":
+            self.side = torch.cuda.Stream(device=device)
         return self
 
     def load_state(self, sd: Dict[str, torch.Tensor], strict: bool = True):
@@ -469,17 +485,33 @@ class Engine:
         tiles = -(-n // 64) * -(-k // 64)
         return max(1, min(16, round(512 / tiles)))
 
+    def _fork(self):
+        """Context for work that may overlap the main stream from here on: the side stream first waits for everything
+        issued so far (the producer of the wgrad's dY).  Inside a hipGraph capture this becomes a fork edge."""
+        if self.side is None:
+            return contextlib.nullcontext()
+        self.side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self.side)
+
+    def _join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+    def _wgrad_side(self, w: _Work, dyT, xT, dW, n, k, db=None):
+        with self._fork():
+            self._wgrad(w, dyT, xT, dW, n, k, db)
+
     def _wgrad(self, w: _Work, dyT, xT, dW, n, k, db=None):
         """dW [n,k] (f32) += dyT[M,n]^T @ xT[M,k] and db [n] += column sums of dyT, straight from the row-major activations."""
         self.k.gemm_tn(dyT, xT, dW, colsum=db, splitk=self._splitk(n, k), M=w.M, N1=n, N2=k)
 
-    def _ff_bwd(self, w: _Work, dx_res, dyT, x_in, P, h, a, u, mean, rstd, dx_out, dxT_out, dxT_scale):
+    def _ff_bwd(self, w: _Work, dx_res, dyT, x_in, P, h, a, u, mean, rstd, dx_out, dxT_out, dxT_scale, da_buf):
         """dyT = 0.5*dx_res (T).  Produces dx_out = dx_res + LN'(dh) and optional T copy for the next stage."""
         M, d, ff = w.M, self.cfg.d, a.shape[1]
-        self._wgrad(w, dyT, u, P["dw2"], d, ff, P["db2"])
-        da = w.dbig[:, :ff] if w.dbig.shape[1] == ff else w.dbig.view(-1)[:M * ff].view(M, ff)
+        self._wgrad_side(w, dyT, u, P["dw2"], d, ff, P["db2"])
+        da = da_buf if da_buf.shape[1] == ff else da_buf.view(-1)[:M * ff].view(M, ff)
         self.k.gemm_nt(dyT, P["w2"][1], da, act=L.ACT_SWISH_GRAD, aux=a, N=ff, K=d)
-        self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
+        self._wgrad_side(w, da, h, P["dw1"], ff, d, P["db1"])
         self.k.gemm_nt(da, P["w1"][1], w.dh, N=d, K=ff)
         self.k.layernorm_bwd(w.dh, x_in, mean, rstd, P["ln_w"], w.partial, dres=dx_res, dx=dx_out, dxT=dxT_out,
                           dxT_scale=dxT_scale, dgamma=P["dln_w"], dbeta=P["dln_b"], dtype=self.act_dtype)
@@ -494,44 +526,49 @@ class Engine:
         pad_left = K // 2
         ds = w.dmid.view(-1)[:M * ci].view(M, ci)
         dx3 = a
+        t1, t2, t3 = w.dyTs[1], w.dyTs[2], w.dyTs[3]
         if part in ("all", "a"):
             # ---- ff2: y = x3 + 0.5*ff(x3)
-            self._ff_bwd(w, dx4, dyT_half, bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.mean[3], bb.rstd[3], a, w.dyT, 1.0)
+            self._ff_bwd(w, dx4, dyT_half, bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.mean[3], bb.rstd[3], a, t1, 1.0, w.da[0])
             # ---- conv module: y = x2 + conv(x2)
-            self._wgrad(w, w.dyT, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
-            self.k.gemm_nt(w.dyT, C["w2"][1], ds, N=ci, K=d)
+            self._wgrad_side(w, t1, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
+            self.k.gemm_nt(t1, C["w2"][1], ds, N=ci, K=d)
             self.k.bn_swish_bwd_reduce(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial)
             self.k.reduce_partials_f64(w.partial, L.LN_PARTIAL_BLOCKS, 2 * ci, w.sums_local[:2 * ci])
             w.sums[:2 * ci].copy_(w.sums_local[:2 * ci])          # all-reduced in place by the SyncBN collective under DP
+            if part == "a":
+                self._join()
         if part in ("all", "b"):
             dc = w.dmid2
             self.k.bn_swish_bwd_apply(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.sums[:2 * ci],
                                       w.sums_local[:2 * ci], M * self.world_size, dc, C["dbn_w"], C["dbn_b"])
-            self.k.dwconv_bwd_weight(dc, bb.g, C["ddw"].view(ci, K), C["ddwb"], w.dw_partial, B, T, pad_left)
+            with self._fork():
+                self.k.dwconv_bwd_weight(dc, bb.g, C["ddw"].view(ci, K), C["ddwb"], w.dw_partial, B, T, pad_left)
             dg = w.dmid3
             self.k.dwconv_bwd_input(dc, C["dw"].view(ci, K), dg, B, T, pad_left)
-            dy1 = w.dbig.view(-1)[:M * 2 * ci].view(M, 2 * ci)
+            dy1 = w.dy1.view(-1)[:M * 2 * ci].view(M, 2 * ci)
             self.k.glu_bwd(bb.y, dg, dy1)
-            self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
+            self._wgrad_side(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
             self.k.gemm_nt(dy1, C["w1"][1], w.dh, N=d, K=2 * ci)
-            self.k.layernorm_bwd(w.dh, bb.x2, bb.mean[2], bb.rstd[2], C["ln_w"], w.partial, dres=dx3, dx=b, dxT=w.dyT,
+            self.k.layernorm_bwd(w.dh, bb.x2, bb.mean[2], bb.rstd[2], C["ln_w"], w.partial, dres=dx3, dx=b, dxT=t2,
                                  dxT_scale=1.0, dgamma=C["dln_w"], dbeta=C["dln_b"], dtype=self.act_dtype)
             dx2 = b
             # ---- attention: y = x1 + attn(x1)
             A = bp.attn
             inner = bp.heads * bp.dh
-            self._wgrad(w, w.dyT, bb.o, A["dwo"], d, inner, A["dbo"])
+            self._wgrad_side(w, t2, bb.o, A["dwo"], d, inner, A["dbo"])
             do = w.dmid.view(-1)[:M * inner].view(M, inner)
-            self.k.gemm_nt(w.dyT, A["wo"][1], do, N=inner, K=d)
-            dqkv = w.dbig.view(-1)[:M * 3 * inner].view(M, 3 * inner)
+            self.k.gemm_nt(t2, A["wo"][1], do, N=inner, K=d)
+            dqkv = w.dqkv.view(-1)[:M * 3 * inner].view(M, 3 * inner)
             self.k.attn_bwd(bb.qkv, A["emb"], bb.probs, do, dqkv, A["demb"], w.dsc, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
-            self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
+            self._wgrad_side(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
             self.k.gemm_nt(dqkv, A["wqkv"][1], w.dh, N=d, K=3 * inner)
-            self.k.layernorm_bwd(w.dh, bb.x1, bb.mean[1], bb.rstd[1], A["ln_w"], w.partial, dres=dx2, dx=a, dxT=w.dyT,
+            self.k.layernorm_bwd(w.dh, bb.x1, bb.mean[1], bb.rstd[1], A["ln_w"], w.partial, dres=dx2, dx=a, dxT=t3,
                                  dxT_scale=0.5, dgamma=A["dln_w"], dbeta=A["dln_b"], dtype=self.act_dtype)
             dx1 = a
             # ---- ff1
-            self._ff_bwd(w, dx1, w.dyT, x_in, bp.ff1, bb.h1, bb.a1, bb.u1, bb.mean[0], bb.rstd[0], dx_in_out, None, 1.0)
+            self._ff_bwd(w, dx1, t3, x_in, bp.ff1, bb.h1, bb.a1, bb.u1, bb.mean[0], bb.rstd[0], dx_in_out, None, 1.0, w.da[1])
+            self._join()
 
     def backward(self, dlogits: torch.Tensor):
         """dlogits (B, T, V+1) f32 for the language of the last training forward.  Accumulates into ``grad``."""

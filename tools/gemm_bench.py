@@ -40,18 +40,26 @@ def run(name, m, n, k, **kw):
 x = torch.empty(M * 1024, device=dev, dtype=torch.bfloat16); y = torch.empty_like(x)
 us = t(lambda: y.copy_(x)); print(f"copy 19.8MB bf16: {us:.1f} us -> {2*x.numel()*2/us/1e3:.0f} GB/s")
 run("ff up: bias+swish+pre", M, 1024, 256, act=L.ACT_SWISH)
-run("pw1: bias", M, 1024, 256)
-run("qkv: plain", M, 768, 256)
+run("pw1: bias (N=512)", M, 512, 256)
+run("qkv: plain (N=768)", M, 768, 256)
 run("ff down: bias,0.5,res f32", M, 256, 1024, alpha=0.5, res=True, out_f32=True)
-run("attn out / pw2 (K=256/512)", M, 256, 256, res=True, out_f32=True)
-run("pw2", M, 256, 512, res=True, out_f32=True)
-run("dgrad du: swish_grad", M, 1024, 256, act=L.ACT_SWISH_GRAD)
+run("attn out / pw2 (K=256)", M, 256, 256, res=True, out_f32=True)
+run("dgrad da: swish_grad", M, 1024, 256, act=L.ACT_SWISH_GRAD)
 run("dgrad dh (N=256,K=1024)", M, 256, 1024)
 run("dgrad dh (N=256,K=768)", M, 256, 768)
-run("wgrad dW1 [1024,256] splitk", 1024, 256, M, splitk=16, out_f32=True)
-run("wgrad dW2 [256,1024] splitk", 256, 1024, M, splitk=16, out_f32=True)
-run("wgrad dWo [256,256] splitk", 256, 256, M, splitk=48, out_f32=True)
-run("vocab", M, 41, 256, out_f32=True)
+run("dgrad dh (N=256,K=512)", M, 256, 512)
+run("dgrad (N=256,K=256)", M, 256, 256)
+if os.environ.get("BLAS_REF"):      # what the vendor library (hipBLASLt via torch) reaches on the same shapes, plain bf16 output
+    for (m, n, k) in ((M, 1024, 256), (M, 768, 256), (M, 512, 256), (M, 256, 256), (M, 256, 1024), (1024, 256, M), (256, 1024, M), (256, 256, M)):
+        A = torch.randn(m, k, device=dev).bfloat16(); B = torch.randn(n, k, device=dev).bfloat16(); out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+        us = t(lambda: torch.mm(A, B.t(), out=out))
+        print(f"torch.mm (hipBLASLt) NT             M={m:5d} N={n:5d} K={k:5d}  {us:8.1f} us  {2.0*m*n*k/us/1e6:7.1f} TF/s")
+        run("lidk plain", m, n, k) if k <= 1024 else None
+    for (m, n1, n2) in ((M, 1024, 256), (M, 256, 1024), (M, 256, 256)):
+        X = torch.randn(m, n1, device=dev).bfloat16(); Y = torch.randn(m, n2, device=dev).bfloat16(); out = torch.empty(n1, n2, device=dev, dtype=torch.bfloat16)
+        us = t(lambda: torch.mm(X.t(), Y, out=out))
+        print(f"torch.mm (hipBLASLt) TN             M={m:5d} N1={n1:4d} N2={n2:4d}  {us:8.1f} us  {2.0*m*n1*n2/us/1e6:7.1f} TF/s")
+if os.environ.get("NT_ONLY"): sys.exit(0)
 
 def run_tn(name, m, n1, n2, splitk):
     X = torch.randn(m, n1, device=dev).bfloat16(); Y = torch.randn(m, n2, device=dev).bfloat16()
