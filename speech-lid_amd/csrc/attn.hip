@@ -219,23 +219,23 @@ attn_bwd_cols_kernel(const T* __restrict__ qkv, const T* __restrict__ probs, con
 #define AF_NJ_MAX 16
 
 template <int DH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(640)
 attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT, bf16* __restrict__ out,
                      bf16* __restrict__ probs, AttGeom g, int ldp, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int KS = DH / 32, LDK = DH + 8;
   const int T_ = g.T, Tp = (T_ + 31) / 32 * 32, NJ = Tp / 16, LDV = Tp + 8, NE = 2 * Tp + 8;
   bf16* Ks = reinterpret_cast<bf16*>(smem);
-  bf16* Vt = Ks + Tp * LDK;
-  bf16* Es = Vt + DH * LDV;
+  bf16* Vs = Ks + Tp * LDK;                             // row-major; P.V reads it with transposed LDS reads (tr_frag)
+  bf16* Es = Vs + Tp * LDK;
   bf16* Ps = Es + NE * LDK;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, NW = nthr >> 6;
   const int b = blockIdx.x / g.H, h = blockIdx.x % g.H;
   const bf16* base = qkv + (size_t)b * T_ * g.ld + h * DH;
 
   // ---- stage K (row-major), V (transposed), E slice; 16-byte global loads
   constexpr int CH = DH / 8;
-  for (int c = tid; c < Tp * CH; c += 256) {
+  for (int c = tid; c < Tp * CH; c += nthr) {
     int j = c / CH, dc = (c % CH) * 8;
     uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
     if (j < T_) {
@@ -243,11 +243,9 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT
       vv = *reinterpret_cast<const uint4*>(base + (size_t)j * g.ld + 2 * g.inner + dc);
     }
     *reinterpret_cast<uint4*>(&Ks[j * LDK + dc]) = kv;
-    const bf16* ve = reinterpret_cast<const bf16*>(&vv);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) Vt[(dc + e) * LDV + j] = ve[e];
+    *reinterpret_cast<uint4*>(&Vs[j * LDK + dc]) = vv;
   }
-  for (int c = tid; c < NE * CH; c += 256) {
+  for (int c = tid; c < NE * CH; c += nthr) {
     int e = c / CH, dc = (c % CH) * 8;
     int r = max(-g.max_pos, min(g.max_pos, e - Tp)) + g.max_pos;
     *reinterpret_cast<uint4*>(&Es[e * LDK + dc]) = *reinterpret_cast<const uint4*>(embT + (size_t)r * DH + dc);
@@ -257,7 +255,7 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT
   const int fr = lane & 15, fq = lane >> 4;
   bf16* Pw = Ps + wave * 16 * LDV;
   const int nrb = (T_ + 15) / 16;
-  for (int rb = wave; rb < nrb; rb += 4) {
+  for (int rb = wave; rb < nrb; rb += NW) {          // wave-uniform
     const int i0 = rb * 16;
     // Q fragments straight from global: lane holds row i0+fr, k = 32*ks + 8*fq .. +8
     bf16x8 qf[KS];
@@ -314,7 +312,7 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) sum[r] += __shfl_xor(sum[r], o, 64);
-      sum[r] = 1.0f / sum[r];
+      sum[r] = __builtin_amdgcn_rcpf(sum[r]);
     }
 #pragma unroll
     for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
@@ -338,8 +336,7 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT
       bf16x8 pf = *reinterpret_cast<const bf16x8*>(&Pw[fr * LDV + k0 + fq * 8]);
 #pragma unroll
       for (int nt = 0; nt < DH / 16; ++nt) {
-        bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(nt * 16 + fr) * LDV + k0 + fq * 8]);
-        ao[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, ao[nt], 0, 0, 0);
+        ao[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, tr_frag(Vs, LDK, k0, nt * 16, fq, fr), ao[nt], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -353,9 +350,17 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT
   }
 }
 
-static size_t att_mfma_lds(int T_, int dh) {
+// waves per workgroup: one 16-row query block per wave where LDS allows (each wave owns a [16][Tp+8] P tile), at least 4
+#define ATT_NW_MAX 10
+static size_t att_mfma_lds(int T_, int dh, int nw = 4) {
   int Tp = (T_ + 31) / 32 * 32;
-  return (size_t)2 * ((size_t)Tp * (dh + 8) + (size_t)dh * (Tp + 8) + (size_t)(2 * Tp + 8) * (dh + 8) + (size_t)4 * 16 * (Tp + 8));
+  return (size_t)2 * ((size_t)2 * Tp * (dh + 8) + (size_t)(2 * Tp + 8) * (dh + 8) + (size_t)nw * 16 * (Tp + 8));
+}
+static int att_pick_nw(int T_, size_t (*lds)(int, int, int), int dh) {
+  int nw = (T_ + 15) / 16;
+  if (nw > ATT_NW_MAX) nw = ATT_NW_MAX;
+  while (nw > 4 && lds(T_, dh, nw) > 160 * 1024) --nw;
+  return nw < 4 ? 4 : nw;
 }
 
 extern "C" int lidk_attn_ldp(int T_, int dh, int dtype) {
@@ -374,7 +379,7 @@ extern "C" int lidk_attn_ldp(int T_, int dh, int dtype) {
 //   K2 (per b,h)   : dv = P^T.dO ; dk = scale * dS^T.Q ; dE[r] += scale * sum_i dS[i][i-r] q[i]
 // =====================================================================================================================
 template <int DH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(640)
 attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT, const bf16* __restrict__ probs,
                           const bf16* __restrict__ dout, bf16* __restrict__ dqkv, bf16* __restrict__ dsT, AttGeom g,
                           int ldp, float scale) {
@@ -384,12 +389,11 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
   bf16* Ks = reinterpret_cast<bf16*>(smem);
   bf16* Vs = Ks + Tp * LDK;
   bf16* Es = Vs + Tp * LDK;
-  bf16* Pall = Es + NE * LDK;
-  bf16* Sall = Pall + 4 * 16 * LDV;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bf16* Pall = Es + NE * LDK;                           // per wave: P rows, overwritten in place by dS
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, NW = nthr >> 6;
   const int b = blockIdx.x / g.H, h = blockIdx.x % g.H;
   const bf16* base = qkv + (size_t)b * T_ * g.ld + h * DH;
-  for (int c = tid; c < Tp * CH; c += 256) {
+  for (int c = tid; c < Tp * CH; c += nthr) {
     int j = c / CH, dc = (c % CH) * 8;
     uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
     if (j < T_) {
@@ -399,7 +403,7 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
     *reinterpret_cast<uint4*>(&Ks[j * LDK + dc]) = kv;
     *reinterpret_cast<uint4*>(&Vs[j * LDK + dc]) = vv;
   }
-  for (int c = tid; c < NE * CH; c += 256) {
+  for (int c = tid; c < NE * CH; c += nthr) {
     int e = c / CH, dc = (c % CH) * 8;
     int r = max(-g.max_pos, min(g.max_pos, e - Tp)) + g.max_pos;
     *reinterpret_cast<uint4*>(&Es[e * LDK + dc]) = *reinterpret_cast<const uint4*>(embT + (size_t)r * DH + dc);
@@ -408,10 +412,10 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
 
   const int fr = lane & 15, fq = lane >> 4;
   bf16* Pw = Pall + wave * 16 * LDV;
-  bf16* Sw = Sall + wave * 16 * LDV;
+  bf16* Sw = Pw;                                        // every element is read (P) and rewritten (dS) by the same lane
   const int nrb = (T_ + 15) / 16;
   const size_t bh = (size_t)(b * g.H + h) * T_;
-  for (int rb = wave; rb < nrb; rb += 4) {
+  for (int rb = wave; rb < nrb; rb += NW) {          // wave-uniform
     const int i0 = rb * 16;
     // P rows of this block -> LDS (16-byte chunks); rows >= T are zero
     for (int c = lane; c < 16 * (Tp / 8); c += 64) {
@@ -503,7 +507,7 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
 }
 
 template <int DH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ probs, const bf16* __restrict__ dout,
                           const bf16* __restrict__ dsT, bf16* __restrict__ dqkv, float* __restrict__ demb, AttGeom g, int ldp,
                           float scale) {
@@ -512,17 +516,17 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
   const int T_ = g.T, Tp = (T_ + 31) / 32 * 32, NJ = Tp / 16, LDV = Tp + 8;
   bf16* X = reinterpret_cast<bf16*>(smem);             // [Tp][LDV]: P, then dS
   bf16* Y = X + Tp * LDV;                               // [Tp][LDK]: dO, then Q
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4, nthr = blockDim.x, NW = nthr >> 6;
   const int b = blockIdx.x / g.H, h = blockIdx.x % g.H;
   const size_t bh = (size_t)(b * g.H + h) * T_;
   auto stage = [&](const bf16* sq, const bf16* rows, size_t row_stride) {
-    for (int c = tid; c < Tp * (Tp / 8); c += 256) {
+    for (int c = tid; c < Tp * (Tp / 8); c += nthr) {
       int i = c / (Tp / 8), col = (c % (Tp / 8)) * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (i < T_) v = *reinterpret_cast<const uint4*>(sq + (bh + i) * ldp + col);
       *reinterpret_cast<uint4*>(&X[i * LDV + col]) = v;
     }
-    for (int c = tid; c < Tp * CH; c += 256) {
+    for (int c = tid; c < Tp * CH; c += nthr) {
       int i = c / CH, dc = (c % CH) * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (i < T_) v = *reinterpret_cast<const uint4*>(rows + (size_t)i * row_stride + dc);
@@ -532,7 +536,7 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
   // ---- phase A: dv[j][d] = sum_i P[i][j] dO[i][d]
   stage(probs, dout + (size_t)b * T_ * g.inner + h * DH, g.inner);
   __syncthreads();
-  for (int jt = wave; jt < NJ; jt += 4) {
+  for (int jt = wave; jt < NJ; jt += NW) {
     f32x4 acc[DH / 16];
 #pragma unroll
     for (int nt = 0; nt < DH / 16; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -555,7 +559,7 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
   stage(dsT, qkv + (size_t)b * T_ * g.ld + h * DH, g.ld);
   __syncthreads();
   const int n_rt = 2 * Tp / 16;                          // offset tiles covering r in [-Tp, Tp)
-  for (int item = wave; item < NJ + n_rt; item += 4) {
+  for (int item = wave; item < NJ + n_rt; item += NW) {
     f32x4 acc[DH / 16];
 #pragma unroll
     for (int nt = 0; nt < DH / 16; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -603,9 +607,9 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
   }
 }
 
-static size_t att_bwd_rows_mfma_lds(int T_, int dh) {
+static size_t att_bwd_rows_mfma_lds(int T_, int dh, int nw = 4) {
   int Tp = (T_ + 31) / 32 * 32;
-  return (size_t)2 * ((size_t)2 * Tp * (dh + 8) + (size_t)(2 * Tp + 8) * (dh + 8) + (size_t)2 * 4 * 16 * (Tp + 8));
+  return (size_t)2 * ((size_t)2 * Tp * (dh + 8) + (size_t)(2 * Tp + 8) * (dh + 8) + (size_t)nw * 16 * (Tp + 8));
 }
 static size_t att_bwd_cols_mfma_lds(int T_, int dh) {
   int Tp = (T_ + 31) / 32 * 32;
@@ -616,12 +620,14 @@ template <int DH>
 static void att_bwd_mfma_launch(const void* qkv, const void* embT, const void* probs, int ldp, const void* dout, void* dqkv,
                                 float* demb, void* dsT, AttGeom g, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)DH);
-  size_t l1 = att_bwd_rows_mfma_lds(g.T, DH), l2 = att_bwd_cols_mfma_lds(g.T, DH);
+  const int nw = att_pick_nw(g.T, att_bwd_rows_mfma_lds, DH);
+  size_t l1 = att_bwd_rows_mfma_lds(g.T, DH, nw), l2 = att_bwd_cols_mfma_lds(g.T, DH);
   (void)hipFuncSetAttribute((const void*)attn_bwd_rows_mfma_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
-  attn_bwd_rows_mfma_kernel<DH><<<g.B * g.H, 256, l1, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)probs,
+  attn_bwd_rows_mfma_kernel<DH><<<g.B * g.H, 64 * nw, l1, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)probs,
                                                            (const bf16*)dout, (bf16*)dqkv, (bf16*)dsT, g, ldp, scale);
   (void)hipFuncSetAttribute((const void*)attn_bwd_cols_mfma_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-  attn_bwd_cols_mfma_kernel<DH><<<g.B * g.H, 256, l2, s>>>((const bf16*)qkv, (const bf16*)probs, (const bf16*)dout,
+  const int nwc = min(16, max(4, (g.T + 15) / 16 + 2 * ((g.T + 31) / 32 * 32) / 16) / 2);   // phase B has NJ + n_rt items: two rounds
+  attn_bwd_cols_mfma_kernel<DH><<<g.B * g.H, 64 * nwc, l2, s>>>((const bf16*)qkv, (const bf16*)probs, (const bf16*)dout,
                                                            (const bf16*)dsT, (bf16*)dqkv, demb, g, ldp, scale);
 }
 
@@ -642,13 +648,14 @@ extern "C" int lidk_attn_fwd(const void* qkv, const float* rel_emb, const void* 
   const float scale = 1.0f / sqrtf((float)dh);
   hipStream_t s = as_stream(stream);
   if (dtype == LIDK_BF16 && rel_emb_T && ldp == (T_ + 31) / 32 * 32 && lidk_attn_ldp(T_, dh, dtype) == ldp && (dh == 32 || dh == 64)) {
-    size_t lds = att_mfma_lds(T_, dh);
+    const int nw = att_pick_nw(T_, att_mfma_lds, dh);
+    size_t lds = att_mfma_lds(T_, dh, nw);
     if (dh == 64) {
       (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attn_fwd_mfma_kernel<64><<<B * heads, 256, lds, s>>>((const bf16*)qkv, (const bf16*)rel_emb_T, (bf16*)out, (bf16*)probs, g, ldp, scale);
+      attn_fwd_mfma_kernel<64><<<B * heads, 64 * nw, lds, s>>>((const bf16*)qkv, (const bf16*)rel_emb_T, (bf16*)out, (bf16*)probs, g, ldp, scale);
     } else {
       (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attn_fwd_mfma_kernel<32><<<B * heads, 256, lds, s>>>((const bf16*)qkv, (const bf16*)rel_emb_T, (bf16*)out, (bf16*)probs, g, ldp, scale);
+      attn_fwd_mfma_kernel<32><<<B * heads, 64 * nw, lds, s>>>((const bf16*)qkv, (const bf16*)rel_emb_T, (bf16*)out, (bf16*)probs, g, ldp, scale);
     }
     return launch_status();
   }

@@ -10,6 +10,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 struct Epi {
   int dbg;                 // tuning aid (LIDK_GEMM_DBG): 1 = skip the epilogue stores, 2 = skip the K loop
   const float* bias; int act; float alpha;
@@ -229,8 +231,6 @@ __device__ __forceinline__ uint4 pack8(float4 a, float4 b) {
   p.h[4] = from_f<bf16>(b.x); p.h[5] = from_f<bf16>(b.y); p.h[6] = from_f<bf16>(b.z); p.h[7] = from_f<bf16>(b.w);
   return p.u;
 }
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int BM, int BN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
@@ -455,7 +455,7 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
 // =====================================================================================================================
 #define BKM 64
 
-template <int BN1, int BN2>
+template <int BN1, int BN2, bool FULL>    // FULL: N1 % BN1 == 0, N2 % BN2 == 0, every row tile complete -> unpredicated loads
 __global__ void __launch_bounds__(256)
 gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict__ Y, int ldy, float* __restrict__ C, int ldc,
                     float* __restrict__ colsum, int M, int N1, int N2, int mchunk, float alpha) {
@@ -479,29 +479,32 @@ gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict_
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool want_cs = colsum != nullptr && blockIdx.x == 0;
 
-  constexpr int PD = 2;                                   // row-tiles of global loads in flight (see gemm_nt_bf16_kernel)
-  uint4 rx[PD][CX], ry[PD][CY];
-  auto gload = [&](int st, int m0) {
+  // Two row tiles of global loads in flight, in two named register sets (see gemm_nt_bf16_direct_kernel: predicated loads
+  // or stage arrays indexed by a variable make hipcc drain vmcnt(0) before every LDS write / fall to scratch).
+  u32x4 rx0[CX], ry0[CY], rx1[CX], ry1[CY];
+  auto gload = [&](u32x4 (&rx)[CX], u32x4 (&ry)[CY], int m0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < CX; ++i) {
       int c = tid + i * 256, row = c / PX, col = (c % PX) * 8;
-      rx[st][i] = (m0 + row < mend && n1_0 + col < N1p) ? *reinterpret_cast<const uint4*>(X + (size_t)(m0 + row) * ldx + n1_0 + col)
-                                                         : make_uint4(0, 0, 0, 0);
+      if (FULL) rx[i] = *reinterpret_cast<const u32x4*>(X + (size_t)(m0 + row) * ldx + n1_0 + col);
+      else rx[i] = (m0 + row < mend && n1_0 + col < N1p) ? *reinterpret_cast<const u32x4*>(X + (size_t)(m0 + row) * ldx + n1_0 + col)
+                                                          : (u32x4){0, 0, 0, 0};
     }
 #pragma unroll
     for (int i = 0; i < CY; ++i) {
       int c = tid + i * 256, row = c / PY, col = (c % PY) * 8;
-      ry[st][i] = (m0 + row < mend && n2_0 + col < N2p) ? *reinterpret_cast<const uint4*>(Y + (size_t)(m0 + row) * ldy + n2_0 + col)
-                                                         : make_uint4(0, 0, 0, 0);
+      if (FULL) ry[i] = *reinterpret_cast<const u32x4*>(Y + (size_t)(m0 + row) * ldy + n2_0 + col);
+      else ry[i] = (m0 + row < mend && n2_0 + col < N2p) ? *reinterpret_cast<const u32x4*>(Y + (size_t)(m0 + row) * ldy + n2_0 + col)
+                                                          : (u32x4){0, 0, 0, 0};
     }
   };
-  auto lstore = [&](int st) {
+  auto lstore = [&](const u32x4 (&rx)[CX], const u32x4 (&ry)[CY]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < CX; ++i) {
       int c = tid + i * 256, row = c / PX, col = (c % PX) * 8;
-      *reinterpret_cast<uint4*>(&Xs[row * LDX + col]) = rx[st][i];
+      *reinterpret_cast<u32x4*>(&Xs[row * LDX + col]) = rx[i];
       if (want_cs) {
-        const bf16* e = reinterpret_cast<const bf16*>(&rx[st][i]);
+        const bf16* e = reinterpret_cast<const bf16*>(&rx[i]);
 #pragma unroll
         for (int q = 0; q < 8; ++q) cs[q] += (float)e[q];
       }
@@ -509,35 +512,44 @@ gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict_
 #pragma unroll
     for (int i = 0; i < CY; ++i) {
       int c = tid + i * 256, row = c / PY, col = (c % PY) * 8;
-      *reinterpret_cast<uint4*>(&Ys[row * LDY + col]) = ry[st][i];
+      *reinterpret_cast<u32x4*>(&Ys[row * LDY + col]) = ry[i];
     }
   };
-
+  auto stage = [&](u32x4 (&rx)[CX], u32x4 (&ry)[CY], int m_next) __attribute__((always_inline)) {
+    lstore(rx, ry);
+    __syncthreads();
+    if (m_next >= 0) gload(rx, ry, m_next);
 #pragma unroll
-  for (int st = 0; st < PD; ++st) gload(st, mbeg + st * BKM);
-  for (int mt = mbeg; mt < mend; mt += PD * BKM) {
+    for (int kk = 0; kk < BKM; kk += 32) {
+      bf16x8 af[TM], bfr[TN];
 #pragma unroll
-    for (int st = 0; st < PD; ++st) {
-      const int m0 = mt + st * BKM;
-      if (m0 < mend) {                                    // block-uniform: every lane runs the transposed reads
-        lstore(st);
-        __syncthreads();
-        gload(st, m0 + PD * BKM);
+      for (int i = 0; i < TM; ++i) af[i] = tr_frag(Xs, LDX, kk, wm * WM + i * 16, fq, fr);
 #pragma unroll
-        for (int kk = 0; kk < BKM; kk += 32) {
-          bf16x8 af[TM], bfr[TN];
+      for (int j = 0; j < TN; ++j) bfr[j] = tr_frag(Ys, LDY, kk, wn * WN + j * 16, fq, fr);
 #pragma unroll
-          for (int i = 0; i < TM; ++i) af[i] = tr_frag(Xs, LDX, kk, wm * WM + i * 16, fq, fr);
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) bfr[j] = tr_frag(Ys, LDY, kk, wn * WN + j * 16, fq, fr);
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-      }
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
+    __syncthreads();
+  };
+  const int nt = (mend - mbeg + BKM - 1) / BKM;            // block-uniform; >= 1
+  gload(rx0, ry0, mbeg);
+  if (nt > 1) gload(rx1, ry1, mbeg + BKM);
+  int t = 0;
+  for (; t + 3 < nt; t += 2) {
+    stage(rx0, ry0, mbeg + (t + 2) * BKM);
+    stage(rx1, ry1, mbeg + (t + 3) * BKM);
+  }
+  if (nt - t == 3) {
+    stage(rx0, ry0, mbeg + (t + 2) * BKM);
+    stage(rx1, ry1, -1);
+    stage(rx0, ry0, -1);
+  } else if (nt - t == 2) {
+    stage(rx0, ry0, -1);
+    stage(rx1, ry1, -1);
+  } else {
+    stage(rx0, ry0, -1);
   }
   // bias gradient: threads with equal tid % PX hold partial sums of the same 8 columns
   if (colsum != nullptr && blockIdx.x == 0) {      // block-uniform
@@ -626,13 +638,19 @@ extern "C" int lidk_gemm_tn(const void* X, int ldx, const void* Y, int ldy, floa
   if (dtype == LIDK_BF16) {
     int mchunk = cdiv(cdiv(M, splitk), BKM) * BKM;
     splitk = cdiv(M, mchunk);
-    if (N1 >= 128 && N2 >= 128 && (long)cdiv(N1, 128) * cdiv(N2, 128) * splitk >= 256) {
-      dim3 grid(cdiv(N2, 128), cdiv(N1, 128), splitk);
-      gemm_tn_bf16_kernel<128, 128><<<grid, 256, 0, s>>>((const bf16*)X, ldx, (const bf16*)Y, ldy, C, ldc, colsum, M, N1, N2, mchunk, alpha);
-    } else {
-      dim3 grid(cdiv(N2, 64), cdiv(N1, 64), splitk);
-      gemm_tn_bf16_kernel<64, 64><<<grid, 256, 0, s>>>((const bf16*)X, ldx, (const bf16*)Y, ldy, C, ldc, colsum, M, N1, N2, mchunk, alpha);
-    }
+    static const int tn_tile = getenv("LIDK_TN_TILE") ? atoi(getenv("LIDK_TN_TILE")) : 0;
+    const bool big = tn_tile == 128 || (tn_tile != 64 && N1 >= 128 && N2 >= 128 && (long)cdiv(N1, 128) * cdiv(N2, 128) * splitk >= 256);
+    const int bn = big ? 128 : 64;
+    const bool full = !(N1 % bn) && !(N2 % bn) && !(M % BKM);        // mchunk is a multiple of BKM
+    dim3 grid(cdiv(N2, bn), cdiv(N1, bn), splitk);
+#define LIDK_TN_LAUNCH(BN_, FULL_)                                                                                          \
+  gemm_tn_bf16_kernel<BN_, BN_, FULL_><<<grid, 256, 0, s>>>((const bf16*)X, ldx, (const bf16*)Y, ldy, C, ldc, colsum, M, N1, \
+                                                           N2, mchunk, alpha)
+    if (big && full) LIDK_TN_LAUNCH(128, true);
+    else if (big) LIDK_TN_LAUNCH(128, false);
+    else if (full) LIDK_TN_LAUNCH(64, true);
+    else LIDK_TN_LAUNCH(64, false);
+#undef LIDK_TN_LAUNCH
   } else if (dtype == LIDK_F32) {
     int mchunk = cdiv(cdiv(M, splitk), 16) * 16;
     splitk = cdiv(M, mchunk);

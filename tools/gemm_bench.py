@@ -67,9 +67,11 @@ def run_tn(name, m, n1, n2, splitk):
     us = t(lambda: ops.gemm_tn(X, Y, C, colsum=cs, splitk=splitk))
     fl = 2.0 * m * n1 * n2
     print(f"{name:34s} M={m:5d} N1={n1:4d} N2={n2:4d} sk={splitk:2d} {us:8.1f} us  {fl/us/1e6:7.1f} TF/s")
-for sk in (4, 8, 16):
+for sk in (4, 8, 16, 32):
     run_tn("TN dW1 [1024,256]", M, 1024, 256, sk)
     run_tn("TN dW2 [256,1024]", M, 256, 1024, sk)
-run_tn("TN dWqkv [768,256]", M, 768, 256, 8)
-run_tn("TN dWo [256,256]", M, 256, 256, 16)
-run_tn("TN dWo [256,256]", M, 256, 256, 32)
+for sk in (8, 16):
+    run_tn("TN dWqkv [768,256]", M, 768, 256, sk)
+    run_tn("TN dWpw1 [512,256]", M, 512, 256, sk)
+for sk in (8, 16, 32):
+    run_tn("TN dWo [256,256]", M, 256, 256, sk)
