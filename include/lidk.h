@@ -66,8 +66,9 @@ int lidk_relu_bwd(const void* dy, const void* y, void* dx, long n, int dtype, vo
 int lidk_colsum(const void* x, int ldx, int x_dtype, float* out, float* partial, int M, int N, float scale, void* stream);
 /* out [C][R] = in [R][C]^T */
 int lidk_transpose(const void* in, int ldi, void* out, int ldo, int R, int C, int dtype, void* stream);
-/* out[c] = sum_p partial[p][c] in float64 (deterministic tree-free column sum of scratch partials). */
-int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double* out, void* stream);
+/* out[c] = sum_p partial[p][c] in float64 (deterministic column sum of scratch partials); out2 (may be NULL) gets a copy
+ * (the SyncBatchNorm backward keeps the local sums while `out` is all-reduced in place). */
+int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double* out, double* out2, void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm (nn.LayerNorm eps=1e-5, lid/conformer.py:85,190,250) */
 /* x [M][C] f32 -> yT (T, may be NULL) and/or y32 (f32, may be NULL); mean/rstd [M] saved for backward (may be NULL). */

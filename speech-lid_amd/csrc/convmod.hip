@@ -326,7 +326,14 @@ template <typename T>
 __global__ void bn_swish_bwd_apply_kernel(const T* __restrict__ ds, const T* __restrict__ c, const float* __restrict__ mean,
                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
                                           const float* __restrict__ beta, const double* __restrict__ sums, double count,
-                                          T* __restrict__ dc, long M, int C) {
+                                          T* __restrict__ dc, long M, int C, const double* __restrict__ sums_local,
+                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  if (blockIdx.x == 0) {        // parameter gradients from this rank's own sums (DDP averages them like any other gradient)
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+      if (dbeta) dbeta[ch] += (float)sums_local[ch];
+      if (dgamma) dgamma[ch] += (float)sums_local[C + ch];
+    }
+  }
   long n = M * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     int ch = (int)(i % C);
@@ -337,13 +344,6 @@ __global__ void bn_swish_bwd_apply_kernel(const T* __restrict__ ds, const T* __r
     dc[i] = from_f<T>(g * rs * (dz - m0 - xh * m1));
   }
 }
-__global__ void bn_param_grad_kernel(const double* __restrict__ sums_local, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int C) {
-  int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= C) return;
-  if (dbeta) dbeta[ch] += (float)sums_local[ch];
-  if (dgamma) dgamma[ch] += (float)sums_local[C + ch];
-}
 extern "C" int lidk_bn_swish_bwd_apply(const void* ds, const void* c, const float* mean, const float* rstd,
                                        const float* gamma, const float* beta, const double* sums,
                                        const double* sums_local, double count, void* dc, float* dgamma, float* dbeta,
@@ -351,7 +351,7 @@ extern "C" int lidk_bn_swish_bwd_apply(const void* ds, const void* c, const floa
   if (!ds || !c || !mean || !rstd || !gamma || !beta || !sums || !sums_local || !dc || count <= 0 || M <= 0 || C <= 0) return LIDK_ERR_ARG;
   hipStream_t s = as_stream(stream);
   LIDK_DISPATCH(dtype, bn_swish_bwd_apply_kernel<T><<<ew_blocks((long)M * C), 256, 0, s>>>(
-                           (const T*)ds, (const T*)c, mean, rstd, gamma, beta, sums, count, (T*)dc, M, C));
-  bn_param_grad_kernel<<<cdiv(C, 256), 256, 0, s>>>(sums_local, dgamma, dbeta, C);
+                           (const T*)ds, (const T*)c, mean, rstd, gamma, beta, sums, count, (T*)dc, M, C, sums_local, dgamma,
+                           dbeta));
   return launch_status();
 }

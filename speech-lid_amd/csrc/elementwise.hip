@@ -142,23 +142,28 @@ __global__ void colsum_partial_kernel(const T* __restrict__ x, int ldx, float* _
 template <typename ACC, typename TOUT, bool ACCUM>
 __global__ void __launch_bounds__(1024)
 colreduce_kernel(const float* __restrict__ partial, int nparts, int ncols, TOUT* __restrict__ out0, TOUT* __restrict__ out1,
-                 int split, float scale) {
+                 int split, float scale, TOUT* __restrict__ dup = nullptr) {
+  // 16 columns per workgroup (32 workgroups for the 512 LayerNorm columns instead of 8): a wave reads 4 partial rows x 16
+  // columns per instruction; fixed summation order -> deterministic
   __shared__ ACC red[16][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane >> 4;
+  const int c = blockIdx.x * 16 + (lane & 15);
   ACC acc = 0;
   if (c < ncols) {
 #pragma unroll 4
-    for (int p = w; p < nparts; p += 16) acc += (ACC)partial[(size_t)p * ncols + c];
+    for (int p = w * 4 + sub; p < nparts; p += 64) acc += (ACC)partial[(size_t)p * ncols + c];
   }
   red[w][lane] = acc;
   __syncthreads();
-  if (w == 0 && c < ncols) {
+  if (w == 0 && lane < 16 && c < ncols) {
     ACC s = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += red[i][lane];
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s += red[i][q * 16 + lane];
     TOUT* dst = (c < split) ? (out0 ? out0 + c : nullptr) : (out1 ? out1 + (c - split) : nullptr);
     if (dst) *dst = ACCUM ? (TOUT)(*dst + (TOUT)scale * (TOUT)s) : (TOUT)s;
+    if (dup) dup[c] = (TOUT)s;
   }
 }
 
@@ -168,14 +173,14 @@ extern "C" int lidk_colsum(const void* x, int ldx, int xd, float* out, float* pa
   hipStream_t s = as_stream(stream);
   int G = M < LIDK_LN_PARTIAL_BLOCKS ? M : LIDK_LN_PARTIAL_BLOCKS;
   LIDK_DISPATCH(xd, colsum_partial_kernel<T><<<G, 256, 0, s>>>((const T*)x, ldx, partial, M, N));
-  colreduce_kernel<float, float, true><<<cdiv(N, 64), 1024, 0, s>>>(partial, G, N, out, (float*)nullptr, N, scale);
+  colreduce_kernel<float, float, true><<<cdiv(N, 16), 1024, 0, s>>>(partial, G, N, out, (float*)nullptr, N, scale);
   return launch_status();
 }
 
-extern "C" int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double* out, void* stream) {
+extern "C" int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double* out, double* out2, void* stream) {
   if (!partial || !out || nparts <= 0 || ncols <= 0) return LIDK_ERR_ARG;
-  colreduce_kernel<double, double, false><<<cdiv(ncols, 64), 1024, 0, as_stream(stream)>>>(partial, nparts, ncols, out,
-                                                                                          (double*)nullptr, ncols, 1.0f);
+  colreduce_kernel<double, double, false><<<cdiv(ncols, 16), 1024, 0, as_stream(stream)>>>(partial, nparts, ncols, out,
+                                                                                          (double*)nullptr, ncols, 1.0f, out2);
   return launch_status();
 }
 
@@ -333,6 +338,6 @@ extern "C" int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, 
     LIDK_DISPATCH(dtype, ln_bwd_kernel<T, T><<<G, 256, 0, s>>>((const T*)dy, x, mean, rstd, gamma, dres, dx, (T*)dxT,
                                                               dxT_scale, partial, M, C));
   }
-  colreduce_kernel<float, float, true><<<cdiv(2 * C, 64), 1024, 0, s>>>(partial, G, 2 * C, dgamma, dbeta, C, 1.0f);
+  colreduce_kernel<float, float, true><<<cdiv(2 * C, 16), 1024, 0, s>>>(partial, G, 2 * C, dgamma, dbeta, C, 1.0f);
   return launch_status();
 }

@@ -81,6 +81,7 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
   else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
+#define LIDK_MEL_MAX 128
 // One wave per frame.  LDS per wave: re[512], im[512]; shared twiddle[256][2], window[512].
 __global__ void __launch_bounds__(256)
 stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ twiddle,
@@ -90,7 +91,16 @@ stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window,
   __shared__ float s_im[4][LIDK_N_FFT];
   __shared__ float s_tw[LIDK_N_FFT / 2][2];
   __shared__ float s_win[LIDK_N_FFT];
+  __shared__ short s_lo[LIDK_MEL_MAX], s_hi[LIDK_MEL_MAX];       // nonzero k-range of every (triangular) mel filter
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int m = threadIdx.x; m < n_mels; m += 256) {
+    int lo = LIDK_N_FFT / 2 + 1, hi = -1;
+    if (m < LIDK_MEL_MAX) {
+      for (int k = 0; k <= LIDK_N_FFT / 2; ++k)
+        if (melfb[(size_t)k * n_mels + m] != 0.f) { lo = min(lo, k); hi = k; }
+      s_lo[m] = (short)lo; s_hi[m] = (short)hi;
+    }
+  }
   for (int i = threadIdx.x; i < LIDK_N_FFT; i += 256) s_win[i] = window[i];
   for (int i = threadIdx.x; i < LIDK_N_FFT / 2; i += 256) { s_tw[i][0] = twiddle[2 * i]; s_tw[i][1] = twiddle[2 * i + 1]; }
   __syncthreads();
@@ -146,7 +156,8 @@ stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window,
     float vmax = -INFINITY;
     for (int m = lane; m < n_mels; m += 64) {
       float acc = 0.f;
-      for (int k = 0; k <= LIDK_N_FFT / 2; ++k) acc = fmaf(re[k], melfb[(size_t)k * n_mels + m], acc);
+      const int klo = m < LIDK_MEL_MAX ? s_lo[m] : 0, khi = m < LIDK_MEL_MAX ? s_hi[m] : LIDK_N_FFT / 2;
+      for (int k = klo; k <= khi; ++k) acc = fmaf(re[k], melfb[(size_t)k * n_mels + m], acc);
       float db = 10.0f * log10f(fmaxf(acc, 1e-10f));
       out[((size_t)b * F + f) * n_mels + m] = db;
       vmax = fmaxf(vmax, db);
@@ -182,7 +193,7 @@ extern "C" int lidk_logmel(const float* wav, const float* window, const float* t
   const int F = 1 + (L + 2 * pad) / hop;
   fill_kernel<<<cdiv(B, 256), 256, 0, s>>>(utt_max, B, -INFINITY);
   long nframes = (long)B * F;
-  int blocks = (int)((nframes + 3) / 4); if (blocks > 2048) blocks = 2048;
+  int blocks = (int)((nframes + 3) / 4); if (blocks > 512) blocks = 512;      // ~10 frames per wave: amortises the range scan
   stft_mel_kernel<<<blocks, 256, 0, s>>>(wav, window, twiddle, melfb, out, utt_max, B, L, pad, hop, F, n_mels);
   long n = nframes * n_mels;
   int eb = (int)((n + 255) / 256); if (eb > 8192) eb = 8192;

@@ -534,8 +534,8 @@ class Engine:
             self._wgrad_side(w, t1, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
             self.k.gemm_nt(t1, C["w2"][1], ds, N=ci, K=d)
             self.k.bn_swish_bwd_reduce(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial)
-            self.k.reduce_partials_f64(w.partial, L.LN_PARTIAL_BLOCKS, 2 * ci, w.sums_local[:2 * ci])
-            w.sums[:2 * ci].copy_(w.sums_local[:2 * ci])          # all-reduced in place by the SyncBN collective under DP
+            # sums is all-reduced in place by the SyncBN collective under DP; sums_local keeps this rank's share
+            self.k.reduce_partials_f64(w.partial, L.LN_PARTIAL_BLOCKS, 2 * ci, w.sums[:2 * ci], w.sums_local[:2 * ci])
             if part == "a":
                 self._join()
         if part in ("all", "b"):

@@ -141,8 +141,8 @@ def transpose(x, out):
     return out
 
 
-def reduce_partials_f64(partial, nparts, ncols, out):
-    check(lib().lidk_reduce_partials_f64(_p(partial), nparts, ncols, _p(out), _stream()), "reduce_partials_f64")
+def reduce_partials_f64(partial, nparts, ncols, out, out2=None):
+    check(lib().lidk_reduce_partials_f64(_p(partial), nparts, ncols, _p(out), _p(out2), _stream()), "reduce_partials_f64")
     return out
 
 

@@ -53,8 +53,10 @@ def transpose(x, out):
     return out
 
 
-def reduce_partials_f64(partial, nparts, ncols, out):
+def reduce_partials_f64(partial, nparts, ncols, out, out2=None):
     out.copy_(partial[:nparts * ncols].view(nparts, ncols).double().sum(0))
+    if out2 is not None:
+        out2.copy_(out)
     return out
 
 
