@@ -54,8 +54,14 @@ dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float
               float* __restrict__ stat_partial, int B, int T_, int C, int K, int pad_left, int flip) {
   __shared__ __attribute__((aligned(16))) T tile[DW_ROWS][64];
   __shared__ float red[4][2][64];
+  __shared__ float wsh[64 * DW_KMAX];     // this block's 64 x K taps: one coalesced load; a lane's K taps are then a stride-K
+                                          // LDS walk (K odd -> conflict free) instead of K global gathers of 64 cache lines each
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * 64, b = blockIdx.z;
+  {
+    const int nw = min(64, C - c0) * K;
+    for (int i = threadIdx.x; i < nw; i += 256) wsh[i] = w[(size_t)c0 * K + i];
+  }
   const int ch = c0 + lane;
   const bool chok = ch < C;
   // stage [rows][64 channels] with 16-byte loads (8 bf16 / 4 f32 channels per lane) when the channel chunk is full
@@ -75,11 +81,11 @@ dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float
       tile[r][lane] = v;
     }
   }
-  float wr[DW_KMAX];
-#pragma unroll
-  for (int k = 0; k < DW_KMAX; ++k) wr[k] = (chok && k < K) ? w[(size_t)ch * K + (flip ? K - 1 - k : k)] : 0.f;
   const float bv = (bias && chok) ? bias[ch] : 0.f;
   __syncthreads();
+  float wr[DW_KMAX];
+#pragma unroll
+  for (int k = 0; k < DW_KMAX; ++k) wr[k] = (chok && k < K) ? wsh[lane * K + (flip ? K - 1 - k : k)] : 0.f;
   float x[8 + DW_KMAX - 1];
 #pragma unroll
   for (int r = 0; r < 8 + DW_KMAX - 1; ++r) x[r] = to_f(tile[wave * 8 + r][lane]);
@@ -189,15 +195,26 @@ dwconv_wgrad_kernel(const T* __restrict__ dc, const T* __restrict__ g, float* __
   }
 }
 
-__global__ void dwconv_wgrad_finalize_kernel(const float* __restrict__ partial, int B, int C, int K, float* __restrict__ dw,
-                                             float* __restrict__ db) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= C * (K + 1)) return;
-  int ch = idx / (K + 1), k = idx - ch * (K + 1);
+// dw[ch][k] += sum_b partial[b][ch][k], db[ch] += sum_b partial[b][ch][K]: 64 outputs per workgroup, 16 waves split the batch,
+// fixed summation order
+__global__ void __launch_bounds__(1024)
+dwconv_wgrad_finalize_kernel(const float* __restrict__ partial, int B, int C, int K, float* __restrict__ dw,
+                             float* __restrict__ db) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + lane, n = C * (K + 1);
   float acc = 0.f;
-  for (int b = 0; b < B; ++b) acc += partial[((size_t)b * C + ch) * (K + 1) + k];
-  if (k < K) dw[(size_t)ch * K + k] += acc;
-  else if (db) db[ch] += acc;
+  if (idx < n)
+    for (int b = wv; b < B; b += 16) acc += partial[(size_t)b * n + idx];
+  red[wv][lane] = acc;
+  __syncthreads();
+  if (wv != 0 || idx >= n) return;
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += red[i][lane];
+  const int ch = idx / (K + 1), k = idx - ch * (K + 1);
+  if (k < K) dw[(size_t)ch * K + k] += t;
+  else if (db) db[ch] += t;
 }
 
 extern "C" int lidk_dwconv_bwd_weight(const void* dc, const void* g, float* dw, float* db, float* partial, int B, int T_,
@@ -206,7 +223,7 @@ extern "C" int lidk_dwconv_bwd_weight(const void* dc, const void* g, float* dw, 
   hipStream_t s = as_stream(stream);
   dim3 grid(cdiv(C, 64), B);
   LIDK_DISPATCH(dtype, dwconv_wgrad_kernel<T><<<grid, 256, 0, s>>>((const T*)dc, (const T*)g, partial, B, T_, C, K, pad_left));
-  dwconv_wgrad_finalize_kernel<<<cdiv(C * (K + 1), 256), 256, 0, s>>>(partial, B, C, K, dw, db);
+  dwconv_wgrad_finalize_kernel<<<cdiv(C * (K + 1), 64), 1024, 0, s>>>(partial, B, C, K, dw, db);
   return launch_status();
 }
 
