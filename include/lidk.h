@@ -29,7 +29,8 @@ enum { LIDK_ACT_NONE = 0, LIDK_ACT_SWISH = 1, LIDK_ACT_RELU = 2, LIDK_ACT_SWISH_
 #define LIDK_N_FFT 512
 #define LIDK_N_FREQ 257
 #define LIDK_LN_PARTIAL_BLOCKS 256   /* rows of the column-reduction scratch used by *_bwd kernels */
-#define LIDK_LN_BWD_BLOCKS 1024      /* rows of scratch used by lidk_layernorm_bwd */
+#define LIDK_LN_BWD_BLOCKS 1024
+#define LIDK_BN_PARTIAL_BLOCKS 1024   /* partial rows written by lidk_bn_swish_bwd_reduce */      /* rows of scratch used by lidk_layernorm_bwd */
 
 int lidk_version(void);
 
@@ -150,7 +151,7 @@ int lidk_bn_eval_stats(const float* running_mean, const float* running_var, floa
 /* s = swish(gamma*(c-mean)*rstd + beta) */
 int lidk_bn_swish_fwd(const void* c, const float* mean, const float* rstd, const float* gamma, const float* beta,
                       void* s, int M, int C, int dtype, void* stream);
-/* backward pass 1: partial [LIDK_LN_PARTIAL_BLOCKS][2][C] of (sum dz, sum dz*xhat), dz = ds*swish'(z) */
+/* backward pass 1: partial [LIDK_BN_PARTIAL_BLOCKS][2][C] of (sum dz, sum dz*xhat), dz = ds*swish'(z) */
 int lidk_bn_swish_bwd_reduce(const void* ds, const void* c, const float* mean, const float* rstd, const float* gamma,
                              const float* beta, float* partial, int M, int C, int dtype, void* stream);
 /* backward pass 2: dc = gamma*rstd*(dz - sums[0]/count - xhat*sums[1]/count); dgamma += sums_local[1]; dbeta += sums_local[0].

@@ -305,14 +305,21 @@ bn_swish_bwd_reduce_kernel(const T* __restrict__ ds, const T* __restrict__ c, co
   if (rl < rl_n) {
     const int ch = cg * 4;
     const float4 mu = load4(mean + ch), rs = load4(rstd + ch), g = load4(gamma + ch), b = load4(beta + ch);
-    for (int m = blockIdx.x * rl_n + rl; m < M; m += gridDim.x * rl_n) {
-      float4 x = load4(c + (size_t)m * C + ch), d = load4(ds + (size_t)m * C + ch);
+    auto row = [&](float4 x, float4 d) __attribute__((always_inline)) {
       float xh, dz;
       xh = (x.x - mu.x) * rs.x; dz = d.x * swish_grad(xh * g.x + b.x); a0[0] += dz; a1[0] = fmaf(dz, xh, a1[0]);
       xh = (x.y - mu.y) * rs.y; dz = d.y * swish_grad(xh * g.y + b.y); a0[1] += dz; a1[1] = fmaf(dz, xh, a1[1]);
       xh = (x.z - mu.z) * rs.z; dz = d.z * swish_grad(xh * g.z + b.z); a0[2] += dz; a1[2] = fmaf(dz, xh, a1[2]);
       xh = (x.w - mu.w) * rs.w; dz = d.w * swish_grad(xh * g.w + b.w); a0[3] += dz; a1[3] = fmaf(dz, xh, a1[3]);
+    };
+    const int step = gridDim.x * rl_n;
+    int m = blockIdx.x * rl_n + rl;
+    for (; m + step < M; m += 2 * step) {               // two rows per iteration: four independent loads in flight
+      float4 x0 = load4(c + (size_t)m * C + ch), d0 = load4(ds + (size_t)m * C + ch);
+      float4 x1 = load4(c + (size_t)(m + step) * C + ch), d1 = load4(ds + (size_t)(m + step) * C + ch);
+      row(x0, d0); row(x1, d1);
     }
+    if (m < M) row(load4(c + (size_t)m * C + ch), load4(ds + (size_t)m * C + ch));
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) { red[threadIdx.x][q] = a0[q]; red[threadIdx.x][4 + q] = a1[q]; }
@@ -333,8 +340,8 @@ extern "C" int lidk_bn_swish_bwd_reduce(const void* ds, const void* c, const flo
                                         const float* gamma, const float* beta, float* partial, int M, int C, int dtype,
                                         void* stream) {
   if (!ds || !c || !mean || !rstd || !gamma || !beta || !partial || M <= 0 || C <= 0 || (C & 3) || C > 1024) return LIDK_ERR_ARG;
-  // always LIDK_LN_PARTIAL_BLOCKS partial rows; blocks beyond M write zeros
-  LIDK_DISPATCH(dtype, bn_swish_bwd_reduce_kernel<T><<<LIDK_LN_PARTIAL_BLOCKS, 256, 0, as_stream(stream)>>>(
+  // always LIDK_BN_PARTIAL_BLOCKS partial rows; blocks beyond M write zeros
+  LIDK_DISPATCH(dtype, bn_swish_bwd_reduce_kernel<T><<<LIDK_BN_PARTIAL_BLOCKS, 256, 0, as_stream(stream)>>>(
                            (const T*)ds, (const T*)c, mean, rstd, gamma, beta, partial, M, C));
   return launch_status();
 }
@@ -351,23 +358,39 @@ __global__ void bn_swish_bwd_apply_kernel(const T* __restrict__ ds, const T* __r
       if (dgamma) dgamma[ch] += (float)sums_local[C + ch];
     }
   }
-  long n = M * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    int ch = (int)(i % C);
-    float mu = mean[ch], rs = rstd[ch], g = gamma[ch];
-    float xh = (to_f(c[i]) - mu) * rs;
-    float dz = to_f(ds[i]) * swish_grad(xh * g + beta[ch]);
-    float m0 = (float)(sums[ch] / count), m1 = (float)(sums[C + ch] / count);
-    dc[i] = from_f<T>(g * rs * (dz - m0 - xh * m1));
+  // 4 channels per thread (8/16-byte accesses).  When C/4 divides the block size a thread keeps the same channels for
+  // its whole grid-stride walk, so the per-channel constants (two f64 divisions each) are computed once.
+  const int groups = C / 4;
+  const long n4 = M * (long)groups, stride = (long)gridDim.x * blockDim.x;
+  const bool fixed = (blockDim.x % groups) == 0;
+  float4 mu, rs, g, b, m0, m1;
+  auto consts = [&](int ch) __attribute__((always_inline)) {
+    mu = load4(mean + ch); rs = load4(rstd + ch); g = load4(gamma + ch); b = load4(beta + ch);
+    m0 = make_float4((float)(sums[ch] / count), (float)(sums[ch + 1] / count), (float)(sums[ch + 2] / count),
+                     (float)(sums[ch + 3] / count));
+    m1 = make_float4((float)(sums[C + ch] / count), (float)(sums[C + ch + 1] / count), (float)(sums[C + ch + 2] / count),
+                     (float)(sums[C + ch + 3] / count));
+  };
+  if (fixed) consts((int)(threadIdx.x % groups) * 4);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    if (!fixed) consts((int)(i % groups) * 4);
+    const long e = i * 4;
+    float4 x = load4(c + e), d = load4(ds + e), o;
+    float xh, dz;
+    xh = (x.x - mu.x) * rs.x; dz = d.x * swish_grad(xh * g.x + b.x); o.x = g.x * rs.x * (dz - m0.x - xh * m1.x);
+    xh = (x.y - mu.y) * rs.y; dz = d.y * swish_grad(xh * g.y + b.y); o.y = g.y * rs.y * (dz - m0.y - xh * m1.y);
+    xh = (x.z - mu.z) * rs.z; dz = d.z * swish_grad(xh * g.z + b.z); o.z = g.z * rs.z * (dz - m0.z - xh * m1.z);
+    xh = (x.w - mu.w) * rs.w; dz = d.w * swish_grad(xh * g.w + b.w); o.w = g.w * rs.w * (dz - m0.w - xh * m1.w);
+    store4(dc + e, o);
   }
 }
 extern "C" int lidk_bn_swish_bwd_apply(const void* ds, const void* c, const float* mean, const float* rstd,
                                        const float* gamma, const float* beta, const double* sums,
                                        const double* sums_local, double count, void* dc, float* dgamma, float* dbeta,
                                        int M, int C, int dtype, void* stream) {
-  if (!ds || !c || !mean || !rstd || !gamma || !beta || !sums || !sums_local || !dc || count <= 0 || M <= 0 || C <= 0) return LIDK_ERR_ARG;
+  if (!ds || !c || !mean || !rstd || !gamma || !beta || !sums || !sums_local || !dc || count <= 0 || M <= 0 || C <= 0 || (C & 3)) return LIDK_ERR_ARG;
   hipStream_t s = as_stream(stream);
-  LIDK_DISPATCH(dtype, bn_swish_bwd_apply_kernel<T><<<ew_blocks((long)M * C), 256, 0, s>>>(
+  LIDK_DISPATCH(dtype, bn_swish_bwd_apply_kernel<T><<<ew_blocks((long)M * C / 4), 256, 0, s>>>(
                            (const T*)ds, (const T*)c, mean, rstd, gamma, beta, sums, count, (T*)dc, M, C, sums_local, dgamma,
                            dbeta));
   return launch_status();

@@ -8,6 +8,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_SWISH, ACT_RELU, ACT_SWISH_GRAD = 0, 1, 2, 3
 LN_PARTIAL_BLOCKS = 256
 LN_BWD_BLOCKS = 1024
+BN_PARTIAL_BLOCKS = 1024
 OPT_CHUNK = 8192
 
 

@@ -162,7 +162,7 @@ class _Work:
         self.dxa, self.dxb = f(M, d), f(M, d)
         hmax = max(cfg.heads, cfg.last_heads)
         self.dsc = f(B, hmax, T, (T + 31) // 32 * 32)
-        self.partial = f(max(L.LN_PARTIAL_BLOCKS * 2 * cmax, L.LN_BWD_BLOCKS * 2 * d))
+        self.partial = f(max(L.LN_PARTIAL_BLOCKS * 2 * cmax, L.LN_BWD_BLOCKS * 2 * d, L.BN_PARTIAL_BLOCKS * 2 * ci))
         self.stat_parts = eng.k.dwconv_stat_parts(B, T)
         self.stat_partial = f(self.stat_parts * 2 * ci)
         self.dw_partial = f(B * ci * (max(cfg.conv_kernel_size, 31) + 1))
@@ -535,7 +535,7 @@ class Engine:
             self.k.gemm_nt(t1, C["w2"][1], ds, N=ci, K=d)
             self.k.bn_swish_bwd_reduce(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial)
             # sums is all-reduced in place by the SyncBN collective under DP; sums_local keeps this rank's share
-            self.k.reduce_partials_f64(w.partial, L.LN_PARTIAL_BLOCKS, 2 * ci, w.sums[:2 * ci], w.sums_local[:2 * ci])
+            self.k.reduce_partials_f64(w.partial, L.BN_PARTIAL_BLOCKS, 2 * ci, w.sums[:2 * ci], w.sums_local[:2 * ci])
             if part == "a":
                 self._join()
         if part in ("all", "b"):

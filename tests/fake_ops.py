@@ -9,6 +9,7 @@ import torch.nn.functional as F
 
 ACT_NONE, ACT_SWISH, ACT_RELU, ACT_SWISH_GRAD = 0, 1, 2, 3
 LN_PARTIAL_BLOCKS = 256
+BN_PARTIAL_BLOCKS = 1024
 
 
 def _f(t):
@@ -249,7 +250,7 @@ def _dz(ds, c, mean, rstd, gamma, beta):
 def bn_swish_bwd_reduce(ds, c, mean, rstd, gamma, beta, partial):
     dz, xh = _dz(ds, c, mean, rstd, gamma, beta)
     C = c.shape[1]
-    partial[:LN_PARTIAL_BLOCKS * 2 * C].zero_()
+    partial[:BN_PARTIAL_BLOCKS * 2 * C].zero_()
     partial[:C] = dz.sum(0)
     partial[C:2 * C] = (dz * xh).sum(0)
 

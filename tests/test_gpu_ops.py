@@ -341,10 +341,10 @@ def test_batchnorm_swish_train_and_eval(dt):
     gd, bd = dev(gamma.detach()), dev(beta.detach())
     ops.bn_swish_fwd(cd, mean, rstd, gd, bd, so)
     check("bn_swish_fwd", so, s, tol(dt, 2e-5, 3e-2))
-    partial = torch.empty(L.LN_PARTIAL_BLOCKS * 2 * C, device=DEV)
+    partial = torch.empty(L.BN_PARTIAL_BLOCKS * 2 * C, device=DEV)
     ops.bn_swish_bwd_reduce(dev(ds, dt), cd, mean, rstd, gd, bd, partial)
     bs = torch.empty(2 * C, device=DEV, dtype=torch.float64)
-    ops.reduce_partials_f64(partial, L.LN_PARTIAL_BLOCKS, 2 * C, bs)
+    ops.reduce_partials_f64(partial, L.BN_PARTIAL_BLOCKS, 2 * C, bs)
     dc = torch.empty(M, C, device=DEV, dtype=dt)
     dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     ops.bn_swish_bwd_apply(dev(ds, dt), cd, mean, rstd, gd, bd, bs, bs, M, dc, dgam, dbet)
