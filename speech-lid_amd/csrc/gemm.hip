@@ -12,6 +12,15 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Workgroups are dispatched round-robin over the 8 XCDs (each with a private L2) in launch order.  Map launch index L to a
+// logical tile index so that every XCD works through ONE contiguous range of tiles: tiles that share an operand panel
+// (same row block, neighbouring column tiles) then hit the same L2 instead of fetching the panel once per XCD
+// (rocprofv3 FETCH_SIZE on the ff-up GEMM: 39 MB with the plain grid for 5.5 MB of operands).  Bijective for any count.
+__device__ __forceinline__ int xcd_tile(int L, int total) {
+  const int xcd = L & 7, slot = L >> 3, q = total >> 3, r = total & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 struct Epi {
   int dbg;                 // tuning aid (LIDK_GEMM_DBG): 1 = skip the epilogue stores, 2 = skip the K loop
   const float* bias; int act; float alpha;
@@ -225,6 +234,12 @@ __device__ __forceinline__ float4 epi_math4(const Epi& e, int m, int n, float4 v
   if (e.res) { float4 r = load4(e.res + (size_t)m * e.ldres + n); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
   return v;
 }
+__device__ __forceinline__ void st16(const Epi& e, void* p, uint4 v) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  u4 w = {v.x, v.y, v.z, v.w};
+  if (e.dbg & 8) __builtin_nontemporal_store(w, reinterpret_cast<u4*>(p));
+  else *reinterpret_cast<u4*>(p) = w;
+}
 __device__ __forceinline__ uint4 pack8(float4 a, float4 b) {
   union { bf16 h[8]; uint4 u; } p;
   p.h[0] = from_f<bf16>(a.x); p.h[1] = from_f<bf16>(a.y); p.h[2] = from_f<bf16>(a.z); p.h[3] = from_f<bf16>(a.w);
@@ -235,13 +250,15 @@ __device__ __forceinline__ uint4 pack8(float4 a, float4 b) {
 template <int BM, int BN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 gemm_nt_bf16_direct_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K, int lda, int ldb, Epi e) {
+  const int n_tiles = (N + BN - 1) / BN;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);               // column tile fastest inside a row block
   constexpr int TM = BM / 32, TN = BN / 32;        // 16x16 tiles per wave along M / N (TN is even: tiles pair up)
   constexpr int CA = BM / 32, CB = BN / 32;        // 16-byte chunks per thread per K tile
   __shared__ __attribute__((aligned(16))) bf16 As[BM * BK];
   __shared__ __attribute__((aligned(16))) bf16 Bs[BN * BK];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fq = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
   const bool pair = !e.out_f32;
 
   f32x4 acc[TM][TN];
@@ -300,12 +317,12 @@ gemm_nt_bf16_direct_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
     }
   };
   // one K tile: registers -> LDS, refill the register set with the tile two ahead (k_next >= 0), MFMAs
+  // e.dbg (LIDK_GEMM_DBG, tuning aid): 1 = no epilogue stores, 2 = no operand reloads inside the loop, 4 = no LDS/MFMA work
   auto stage = [&](u32x4 (&ra)[CA], u32x4 (&rb)[CB], int k_next) __attribute__((always_inline)) {
-    lstore(ra, rb);
-    __syncthreads();
-    if (k_next >= 0) gload(ra, rb, k_next);              // compile-time after inlining: callers pass a constant -1 or a real k
-    mma();
-    __syncthreads();
+    if (!(e.dbg & 4)) { lstore(ra, rb); __syncthreads(); }
+    else { acc[0][0][0] += __uint_as_float((ra[0][0] ^ rb[0][0]) & 1u); }
+    if (k_next >= 0 && !(e.dbg & 2)) gload(ra, rb, k_next);   // compile-time after inlining: callers pass -1 or a real k
+    if (!(e.dbg & 4)) { mma(); __syncthreads(); }
   };
   const int nt = K / BK;
   gload(ra0, rb0, 0);
@@ -331,7 +348,7 @@ gemm_nt_bf16_direct_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * (BM / 2) + i * 16 + fr;
-    if (m >= M) continue;
+    if (m >= M || ((e.dbg & 1) && acc[i][0][0] != 12345.f)) continue;
     if (pair) {
 #pragma unroll
       for (int c = 0; c < TN / 2; ++c) {
@@ -342,8 +359,8 @@ gemm_nt_bf16_direct_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
           float4 p0, p1;
           float4 v0 = epi_math4(e, m, n, a0, &p0);
           float4 v1 = epi_math4(e, m, n + 4, a1, &p1);
-          if (e.act == LIDK_ACT_SWISH && e.out2) *reinterpret_cast<uint4*>((bf16*)e.out2 + (size_t)m * e.ldo2 + n) = pack8(p0, p1);
-          *reinterpret_cast<uint4*>((bf16*)e.out + (size_t)m * e.ldo + n) = pack8(v0, v1);
+          if (e.act == LIDK_ACT_SWISH && e.out2) st16(e, (bf16*)e.out2 + (size_t)m * e.ldo2 + n, pack8(p0, p1));
+          st16(e, (bf16*)e.out + (size_t)m * e.ldo + n, pack8(v0, v1));
         } else {
           epi_store4<bf16>(e, m, n, N, a0);
           epi_store4<bf16>(e, m, n + 4, N, a1);
@@ -416,8 +433,8 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
     // only 4..16 K-tiles, so many small workgroups per CU hide the load latency better than one big tile does); the 128x128
     // variant is kept for long-K problems and can be forced with LIDK_GEMM_TILE=128.
     static const int direct = getenv("LIDK_GEMM_DIRECT") ? atoi(getenv("LIDK_GEMM_DIRECT")) : 1;
-    if (direct && splitk == 1 && !dbg && (g->K & 63) == 0) {
-      dim3 grid(cdiv(g->N, 64), cdiv(g->M, 64), 1);
+    if (direct && splitk == 1 && (g->K & 63) == 0) {
+      const int grid = cdiv(g->N, 64) * cdiv(g->M, 64);
       gemm_nt_bf16_direct_kernel<64, 64><<<grid, 256, 0, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->K, g->lda,
                                                              g->ldb, e);
       return launch_status();
@@ -467,8 +484,12 @@ gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict_
   bf16* Xs = reinterpret_cast<bf16*>(smem);
   bf16* Ys = Xs + BKM * LDX;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1, fr = lane & 15, fq = lane >> 4;
-  const int n1_0 = blockIdx.y * BN1, n2_0 = blockIdx.x * BN2;
-  const int mbeg = blockIdx.z * mchunk, mend = min(M, mbeg + mchunk);
+  // 1-D launch, XCD-aware: all tiles of one row chunk (they share its X and Y rows) run on the same XCD back to back
+  const int t1 = (N1 + BN1 - 1) / BN1, t2 = (N2 + BN2 - 1) / BN2;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int bz = tile / (t1 * t2), by = (tile / t2) % t1, bx = tile % t2;
+  const int n1_0 = by * BN1, n2_0 = bx * BN2;
+  const int mbeg = bz * mchunk, mend = min(M, mbeg + mchunk);
   const int N1p = (N1 + 7) & ~7, N2p = (N2 + 7) & ~7;           // operands are readable (zero padded) up to a multiple of 8
 
   f32x4 acc[TM][TN];
@@ -477,7 +498,7 @@ gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict_
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const bool want_cs = colsum != nullptr && blockIdx.x == 0;
+  const bool want_cs = colsum != nullptr && bx == 0;
 
   // Two row tiles of global loads in flight, in two named register sets (see gemm_nt_bf16_direct_kernel: predicated loads
   // or stage arrays indexed by a variable make hipcc drain vmcnt(0) before every LDS write / fall to scratch).
@@ -552,7 +573,7 @@ gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict_
     stage(rx0, ry0, -1);
   }
   // bias gradient: threads with equal tid % PX hold partial sums of the same 8 columns
-  if (colsum != nullptr && blockIdx.x == 0) {      // block-uniform
+  if (want_cs) {      // block-uniform
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int q = 0; q < 8; ++q) red[tid * 8 + q] = cs[q];
@@ -642,7 +663,7 @@ extern "C" int lidk_gemm_tn(const void* X, int ldx, const void* Y, int ldy, floa
     const bool big = tn_tile == 128 || (tn_tile != 64 && N1 >= 128 && N2 >= 128 && (long)cdiv(N1, 128) * cdiv(N2, 128) * splitk >= 256);
     const int bn = big ? 128 : 64;
     const bool full = !(N1 % bn) && !(N2 % bn) && !(M % BKM);        // mchunk is a multiple of BKM
-    dim3 grid(cdiv(N2, bn), cdiv(N1, bn), splitk);
+    const int grid = cdiv(N2, bn) * cdiv(N1, bn) * splitk;
 #define LIDK_TN_LAUNCH(BN_, FULL_)                                                                                          \
   gemm_tn_bf16_kernel<BN_, BN_, FULL_><<<grid, 256, 0, s>>>((const bf16*)X, ldx, (const bf16*)Y, ldy, C, ldc, colsum, M, N1, \
                                                            N2, mchunk, alpha)

@@ -39,6 +39,9 @@ def run(name, m, n, k, **kw):
 
 x = torch.empty(M * 1024, device=dev, dtype=torch.bfloat16); y = torch.empty_like(x)
 us = t(lambda: y.copy_(x)); print(f"copy 19.8MB bf16: {us:.1f} us -> {2*x.numel()*2/us/1e3:.0f} GB/s")
+z = torch.empty(2 * M * 1024, device=dev, dtype=torch.bfloat16)
+us = t(lambda: z.fill_(1.0)); print(f"fill 39.6MB bf16: {us:.1f} us -> {z.numel()*2/us/1e3:.0f} GB/s")
+us = t(lambda: y.fill_(1.0)); print(f"fill 19.8MB bf16: {us:.1f} us -> {y.numel()*2/us/1e3:.0f} GB/s")
 run("ff up: bias+swish+pre", M, 1024, 256, act=L.ACT_SWISH)
 run("pw1: bias (N=512)", M, 512, 256)
 run("qkv: plain (N=768)", M, 768, 256)
