@@ -13,8 +13,10 @@ number (every layer runs every step, matching the 21.67 GFLOP/utterance accounti
 --stochastic-depth to time the reference default (p=0.7, ~16 % fewer executed blocks on average).
 
 Prints ONE JSON line (rank 0) with the contract's fields plus:
-  roofline     : the MFMA GEMM kernel (gemm_nt_bf16_kernel, both tile shapes): algorithmic 2*M*N*K FLOPs of every launch of
-                 one training step / their summed durations, each launch bracketed by HIP events on its own stream
+  roofline     : the dominant kernel (gemm_nt_bf16_direct_kernel, every Linear / 1x1 conv forward and data gradient):
+                 algorithmic bytes of every launch of one training step / their summed durations, each launch bracketed by
+                 HIP events on its own stream (HBM roofline: these K <= 1024 GEMMs are below the machine balance); the MFMA
+                 rate of the same launches and the weight-gradient kernel are reported in the same object
   cpu_baseline : the CPU oracle (oracle/, torch fp32) running the same step on this host's cores, bounded sample
 """
 import argparse
@@ -30,6 +32,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0               # HBM3E peak, same guide ("HBM": 8 TB/s spec, ~6.3 TB/s achievable)
 SECONDS = 3.0
 BATCH = 64
 N_LANGS = 14
@@ -122,30 +125,60 @@ def cpu_baseline(module, ds, steps, batch, threads):
             "sample": f"{steps} steps of batch {batch} (3 s utterances) after 1 warm-up step, {t:.2f} s/step, fp32 torch-CPU oracle"}
 
 
+def _pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/r01/pmc_traffic.json, produced by
+    tools/gpu_pmc_bench.sh on this same command): FETCH_SIZE and WRITE_SIZE are in KB; FETCH_SIZE counts 64 B per 128-B
+    request on gfx950 and is doubled, as MI355X_MICROARCH.md (HBM) prescribes; WRITE_SIZE is exact for 16-byte stores."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    raw = json.load(open(path))
+    hits = [v for name, v in raw.items() if kernel_prefix in name and "FETCH_SIZE_KB_per_launch_raw" in v
+            and "WRITE_SIZE_KB_per_launch_raw" in v]
+    if not hits:
+        return None
+    v = max(hits, key=lambda h: h.get("launches_fetch", 0))          # the instantiation that dominates the step
+    return round((2.0 * v["FETCH_SIZE_KB_per_launch_raw"] + v["WRITE_SIZE_KB_per_launch_raw"]) * 1024.0)
+
+
 def gemm_roofline(trainer, batches, step_fn):
-    """Bracket every MFMA GEMM launch (gemm_nt forward/dgrad, gemm_tn wgrad) of ONE training step with HIP events on the
-    launch stream; algorithmic FLOPs are 2*M*N*K per launch.  The step runs through the eager launch path (graph replay
-    bypasses the Python wrappers and events cannot be recorded inside a capture); the kernels and shapes are identical."""
+    """Bracket every launch of the dominant kernel (gemm_nt: every Linear / 1x1 conv forward and its data gradient) of ONE
+    training step with HIP events on the launch stream, and the weight-gradient GEMM (gemm_tn) likewise.  With K = 256..1024
+    these GEMMs sit below the machine balance (about 150 FLOP per algorithmic byte against 2500 TF/s / 8 TB/s = 312), so the
+    roofline that bounds them is HBM: achieved = algorithmic bytes (operands read once, outputs written once; DESIGN.md
+    section 5) / measured time.  The MFMA rate of the same launches is reported beside it.  The step runs through the eager
+    launch path (events cannot be recorded inside a hipGraph capture); kernels and shapes are those of the timed steps.  The
+    cost of an empty event bracket is measured and subtracted."""
     eng = trainer.engine
     k = eng.k
     orig_nt, orig_tn = k.gemm_nt, k.gemm_tn
-    rec = []
+    rec = {"nt": [], "tn": []}
 
-    def bracket(fn, flops, *a, **kw):
+    def esz(t):
+        return t.element_size()
+
+    def bracket(kind, fn, flops, nbytes, *a, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = fn(*a, **kw)
         e1.record()
-        rec.append((e0, e1, flops))
+        rec[kind].append((e0, e1, flops, nbytes))
         return r
 
     def timed_nt(A, B, out, *a, M=None, N=None, K=None, **kw):
         m, kk, n = (A.shape[0] if M is None else M), (A.shape[1] if K is None else K), (B.shape[0] if N is None else N)
-        return bracket(orig_nt, 2.0 * m * n * kk, A, B, out, *a, M=M, N=N, K=K, **kw)
+        nbytes = m * kk * esz(A) + n * kk * esz(B) + m * n * esz(out)
+        for key in ("out2", "aux", "res"):
+            if kw.get(key) is not None:
+                nbytes += m * n * esz(kw[key])
+        if kw.get("bias") is not None:
+            nbytes += n * 4
+        return bracket("nt", orig_nt, 2.0 * m * n * kk, nbytes, A, B, out, *a, M=M, N=N, K=K, **kw)
 
     def timed_tn(X, Y, C, *a, M=None, N1=None, N2=None, **kw):
         m, n1, n2 = (X.shape[0] if M is None else M), (X.shape[1] if N1 is None else N1), (Y.shape[1] if N2 is None else N2)
-        return bracket(orig_tn, 2.0 * m * n1 * n2, X, Y, C, *a, M=M, N1=N1, N2=N2, **kw)
+        nbytes = m * n1 * esz(X) + m * n2 * esz(Y) + n1 * n2 * 4
+        return bracket("tn", orig_tn, 2.0 * m * n1 * n2, nbytes, X, Y, C, *a, M=M, N1=N1, N2=N2, **kw)
 
     graphs_on = eng.graphs.enabled
     eng.graphs.enabled = False
@@ -156,13 +189,30 @@ def gemm_roofline(trainer, batches, step_fn):
     finally:
         k.gemm_nt, k.gemm_tn = orig_nt, orig_tn
         eng.graphs.enabled = graphs_on
-    ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-    flops = sum(f for _, _, f in rec)
-    return {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": "gemm_nt_bf16_kernel + gemm_tn_bf16_kernel", "launches_per_step": len(rec),
-            "gemm_ms_per_step": round(ms, 3), "gemm_gflop_per_step": round(flops / 1e9, 1),
-            "avg_launch_us": round(ms * 1e3 / len(rec), 2)}
+    empty = []
+    for _ in range(200):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()
+        empty.append((e0, e1))
+    torch.cuda.synchronize()
+    ovh = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]          # median, ms
+
+    def tot(kind):
+        ms = sum(max(a.elapsed_time(b) - ovh, 0.0) for a, b, _, _ in rec[kind])
+        return ms, sum(f for _, _, f, _ in rec[kind]), sum(n for _, _, _, n in rec[kind]), len(rec[kind])
+
+    ms, fl, by, n = tot("nt")
+    ms2, fl2, by2, n2 = tot("tn")
+    gbs = by / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": _pmc_traffic("gemm_nt_bf16_direct_kernel"), "kernel": "gemm_nt_bf16_direct_kernel<64,64>",
+            "launches_per_step": n, "avg_launch_us": round(ms * 1e3 / n, 2), "kernel_ms_per_step": round(ms, 3),
+            "algorithmic_bytes_per_launch": round(by / n), "event_bracket_overhead_us": round(ovh * 1e3, 2),
+            "mfma": {"achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
+            "wgrad_kernel": {"kernel": "gemm_tn_bf16_kernel<64,64>", "launches_per_step": n2,
+                             "avg_launch_us": round(ms2 * 1e3 / n2, 2), "GB/s": round(by2 / (ms2 * 1e-3) / 1e9, 1),
+                             "TFLOP/s": round(fl2 / (ms2 * 1e-3) / 1e12, 1), "traffic": _pmc_traffic("gemm_tn_bf16_kernel")}}
 
 
 def main():
