@@ -35,6 +35,7 @@ class Novograd(Optimizer):
             self._exp_avg = None
             self._exp_avg_sq = None
             self._work_cache: Dict[tuple, torch.Tensor] = {}
+            self._head_cache: Dict[tuple, Optional[str]] = {}
             self._scratch = None
             self.total_norm = None          # device scalar: gradient norm before clipping, from the last step
         elif None not in engines:
@@ -70,7 +71,10 @@ class Novograd(Optimizer):
         eng.k.novograd_step(eng.flat, eng.grad, self._exp_avg, self._exp_avg_sq, work, len(eng.specs), float(grp["lr"]),
                             grp["betas"], grp["eps"], grp["weight_decay"], grp["grad_averaging"],
                             float(max_norm) if max_norm else 0.0, self._scratch, self.total_norm)
-        eng.refresh_weights()
+        lang = self._head_cache.get(tids)
+        if tids not in self._head_cache:
+            lang = self._head_cache[tids] = eng.single_active_head(tids)
+        eng.refresh_weights(lang)
 
     # ------------------------------------------------------------------ generic path
     @torch.no_grad()

@@ -148,17 +148,24 @@ class _Work:
         cmax = max(ff, 2 * ci, 3 * cfg.heads * cfg.dim_head, 3 * cfg.last_heads * cfg.last_dim_head, 4 * d, 3 * cfg.n_mels,
                    self.v1p)
         self.cmax = cmax
-        # Each weight-gradient site of a block backward reads its own dY buffer, so the wgrad GEMMs can run on the side
-        # stream while the main stream continues down the dgrad chain without ever overwriting what they read.
-        self.da = [e(M, ff), e(M, ff)]                        # ff2 / ff1 hidden gradients
-        self.dy1 = e(M, 2 * ci)                               # conv pointwise-1 output gradient
-        self.dqkv = e(M, 3 * max(cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head))
-        self.dyTs = [e(M, d) for _ in range(4)]               # T-typed dx at: block output, x3, x2, x1
+        # Each weight-gradient site of a block backward reads its own dY buffer, and consecutive blocks alternate between two
+        # such sets: the weight-gradient GEMMs of a block can then run beside the NEXT block's dgrad chain (deferred mode,
+        # Engine.backward) without either side overwriting what the other still reads.
+        class _Set:
+            pass
+        self.sets = []
+        for _ in range(2):
+            S = _Set()
+            S.da = [e(M, ff), e(M, ff)]                       # ff2 / ff1 hidden gradients
+            S.dy1 = e(M, 2 * ci)                              # conv pointwise-1 output gradient
+            S.dqkv = e(M, 3 * max(cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head))
+            S.dyTs = [e(M, d) for _ in range(4)]              # T-typed dx at: block output (x0.5), x3, x2, x1
+            S.dc = e(M, ci)                                   # depthwise-conv output gradient
+            self.sets.append(S)
         self.dmid = e(M, max(ci, cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head, d))   # ds / do
-        self.dmid2 = e(M, ci)
         self.dmid3 = e(M, ci)
         self.dh = e(M, d)
-        self.dyT = self.dyTs[0]
+        self.dyT = self.sets[0].dyTs[0]                       # the head block (first in backward) uses set 0
         self.dxa, self.dxb = f(M, d), f(M, d)
         hmax = max(cfg.heads, cfg.last_heads)
         self.dsc = f(B, hmax, T, (T + 31) // 32 * 32)
@@ -199,8 +206,9 @@ class Engine:
         self.world_size = 1
         self.seed = 0
         self.step_count = 0
-        # Optional second HIP stream for the weight-gradient GEMMs (LIDK_SIDE_STREAM=1).  Off by default: measured on MI355X
-        # the fork/join edges inside the captured graphs cost more than the overlap wins (13.0 vs 11.85 ms/step, cfg2).
+        # Second HIP stream for the weight-gradient GEMMs (LIDK_SIDE_STREAM=0 turns it off): a block's wgrads are deferred and
+        # run beside the next block's dgrad chain, one fork/join per captured block graph: 9.75 vs 10.01 ms/step.  (Forking
+        # at every wgrad site cost more in graph edges than the overlap won: 13.0 vs 11.85 ms/step at the time.)
         self.side = None
 
     # ------------------------------------------------------------------ parameters
@@ -225,7 +233,7 @@ class Engine:
         self.grad = torch.zeros_like(self.flat)
         self.buffers = {k: v.to(device) for k, v in self.buffers.items()}
         self._build_operands()
-        if self._hip and device.type == "cuda" and _os_env("LIDK_SIDE_STREAM", "0") == "1":
+        if self._hip and device.type == "cuda" and _os_env("LIDK_SIDE_STREAM", "1") != "0":
             self.side = torch.cuda.Stream(device=device)
         return self
 
@@ -308,6 +316,7 @@ class Engine:
         self._c3_off, off = off, off + _ceil(c3.shape[0] * 3 * c3.shape[1], ALIGN)
         self.wT = torch.zeros(off, device=self.device, dtype=self.act_dtype)
         self.mats, self.mat_tiles = self.k.build_cast_table(mats, self.device)
+        self._mat_rows, self._lang_tables = mats, {}
         self._wviews = {}
         for key, (w_off, t_off, n, k, ldt) in views.items():
             self._wviews[key] = (self.wT[w_off:w_off + n * k].view(n, k),
@@ -323,9 +332,19 @@ class Engine:
         self.graphs.clear()
         self.refresh_weights()
 
-    def refresh_weights(self):
-        """f32 master -> T operands (after an optimizer step, load_state_dict or reset)."""
-        self.k.cast_weights(self.flat, self.wT, self.mats, self.mat_tiles)
+    def refresh_weights(self, lang: Optional[str] = None):
+        """f32 master -> T operands (after an optimizer step, load_state_dict or reset).  With ``lang`` only the tensors a
+        training step for that language can have changed are converted (encoder, front end, that language's head): the
+        other 13 heads are half of the arena."""
+        if lang is None:
+            self.k.cast_weights(self.flat, self.wT, self.mats, self.mat_tiles)
+        else:
+            if lang not in self._lang_tables:
+                other = [self.stage_range(f"head.{l}") for l in self.cfg.lang2vocab if l != lang]
+                rows = [r for r in self._mat_rows if not any(lo <= r[0] < hi for lo, hi in other)]
+                self._lang_tables[lang] = self.k.build_cast_table(rows, self.device)
+            mats, tiles = self._lang_tables[lang]
+            self.k.cast_weights(self.flat, self.wT, mats, tiles)
         c3 = self.pview("model.featurizer.sub_sampling.sub_sampling.0.weight")       # [Co][Ci][3] -> [Co][k*Ci+ci]
         self.w_conv3.copy_(c3.permute(0, 2, 1).reshape(c3.shape[0], -1))             # 19 K elements: layout glue, not math
 
@@ -412,12 +431,12 @@ class Engine:
             self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
                                  dtype=self.act_dtype)
 
-    def _enc_block_bwd(self, dy, x_in, i, w: _Work, dfeat, part: str):
+    def _enc_block_bwd(self, dy, x_in, i, w: _Work, dfeat, part: str, S, wg: bool):
         bp, bb = self.enc_params[i], w.enc[i]
         if part in ("all", "a"):
-            self.k.layernorm_bwd(dy, bb.x4, bb.mean[4], bb.rstd[4], bp.post["w"], w.partial, dx=w.dxa, dxT=w.dyT,
+            self.k.layernorm_bwd(dy, bb.x4, bb.mean[4], bb.rstd[4], bp.post["w"], w.partial, dx=w.dxa, dxT=S.dyTs[0],
                                  dxT_scale=0.5, dgamma=bp.post["dw"], dbeta=bp.post["db"], dtype=self.act_dtype)
-        self._block_bwd(w, x_in, bp, bb, w.dxa, w.dyT, dfeat, part)
+        self._block_bwd(w, x_in, bp, bb, w.dxa, S, dfeat, part, wg)
 
     def _head_fwd(self, w: _Work, feat, lang, training, seed, logits):
         cfg = self.cfg
@@ -497,28 +516,28 @@ class Engine:
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
 
-    def _wgrad_side(self, w: _Work, dyT, xT, dW, n, k, db=None):
-        with self._fork():
-            self._wgrad(w, dyT, xT, dW, n, k, db)
-
     def _wgrad(self, w: _Work, dyT, xT, dW, n, k, db=None):
         """dW [n,k] (f32) += dyT[M,n]^T @ xT[M,k] and db [n] += column sums of dyT, straight from the row-major activations."""
         self.k.gemm_tn(dyT, xT, dW, colsum=db, splitk=self._splitk(n, k), M=w.M, N1=n, N2=k)
 
-    def _ff_bwd(self, w: _Work, dx_res, dyT, x_in, P, h, a, u, mean, rstd, dx_out, dxT_out, dxT_scale, da_buf):
+    def _ff_bwd(self, w: _Work, dx_res, dyT, x_in, P, h, a, u, mean, rstd, dx_out, dxT_out, dxT_scale, da_buf, wg: bool):
         """dyT = 0.5*dx_res (T).  Produces dx_out = dx_res + LN'(dh) and optional T copy for the next stage."""
         M, d, ff = w.M, self.cfg.d, a.shape[1]
-        self._wgrad_side(w, dyT, u, P["dw2"], d, ff, P["db2"])
+        if wg:
+            self._wgrad(w, dyT, u, P["dw2"], d, ff, P["db2"])
         da = da_buf if da_buf.shape[1] == ff else da_buf.view(-1)[:M * ff].view(M, ff)
         self.k.gemm_nt(dyT, P["w2"][1], da, act=L.ACT_SWISH_GRAD, aux=a, N=ff, K=d)
-        self._wgrad_side(w, da, h, P["dw1"], ff, d, P["db1"])
+        if wg:
+            self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
         self.k.gemm_nt(da, P["w1"][1], w.dh, N=d, K=ff)
         self.k.layernorm_bwd(w.dh, x_in, mean, rstd, P["ln_w"], w.partial, dres=dx_res, dx=dx_out, dxT=dxT_out,
                           dxT_scale=dxT_scale, dgamma=P["dln_w"], dbeta=P["dln_b"], dtype=self.act_dtype)
 
-    def _block_bwd(self, w: _Work, x_in, bp: _BlockParams, bb: _BlockBuf, dx4, dyT_half, dx_in_out, part: str = "all"):
-        """dx4: f32 gradient at x4 (after post_norm backward); dyT_half = 0.5*dx4 in T.  Writes the gradient w.r.t. the
-        block input into dx_in_out (f32).  ``part`` cuts the sequence at the SyncBatchNorm backward all-reduce."""
+    def _block_bwd(self, w: _Work, x_in, bp: _BlockParams, bb: _BlockBuf, dx4, S, dx_in_out, part: str = "all",
+                   wg: bool = True):
+        """dx4: f32 gradient at x4 (after post_norm backward); S.dyTs[0] = 0.5*dx4 in T.  Writes the gradient w.r.t. the
+        block input into dx_in_out (f32) and every weight-gradient operand (dY) into the scratch set S.  ``part`` cuts the
+        sequence at the SyncBatchNorm backward all-reduce.  wg=False leaves the weight gradients to _block_wgrads."""
         B, T, M, d = w.B, w.T, w.M, self.cfg.d
         a, b = (w.dxa, w.dxb) if dx4 is w.dxb else (w.dxb, w.dxa)     # two f32 ping-pong buffers
         C = bp.conv
@@ -526,29 +545,29 @@ class Engine:
         pad_left = K // 2
         ds = w.dmid.view(-1)[:M * ci].view(M, ci)
         dx3 = a
-        t1, t2, t3 = w.dyTs[1], w.dyTs[2], w.dyTs[3]
+        t0, t1, t2, t3 = S.dyTs
         if part in ("all", "a"):
             # ---- ff2: y = x3 + 0.5*ff(x3)
-            self._ff_bwd(w, dx4, dyT_half, bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.mean[3], bb.rstd[3], a, t1, 1.0, w.da[0])
+            self._ff_bwd(w, dx4, t0, bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.mean[3], bb.rstd[3], a, t1, 1.0, S.da[0], wg)
             # ---- conv module: y = x2 + conv(x2)
-            self._wgrad_side(w, t1, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
+            if wg:
+                self._wgrad(w, t1, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
             self.k.gemm_nt(t1, C["w2"][1], ds, N=ci, K=d)
             self.k.bn_swish_bwd_reduce(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial)
             # sums is all-reduced in place by the SyncBN collective under DP; sums_local keeps this rank's share
             self.k.reduce_partials_f64(w.partial, L.BN_PARTIAL_BLOCKS, 2 * ci, w.sums[:2 * ci], w.sums_local[:2 * ci])
-            if part == "a":
-                self._join()
         if part in ("all", "b"):
-            dc = w.dmid2
+            dc = S.dc.view(-1)[:M * ci].view(M, ci)
             self.k.bn_swish_bwd_apply(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.sums[:2 * ci],
                                       w.sums_local[:2 * ci], M * self.world_size, dc, C["dbn_w"], C["dbn_b"])
-            with self._fork():
+            if wg:
                 self.k.dwconv_bwd_weight(dc, bb.g, C["ddw"].view(ci, K), C["ddwb"], w.dw_partial, B, T, pad_left)
             dg = w.dmid3
             self.k.dwconv_bwd_input(dc, C["dw"].view(ci, K), dg, B, T, pad_left)
-            dy1 = w.dy1.view(-1)[:M * 2 * ci].view(M, 2 * ci)
+            dy1 = S.dy1.view(-1)[:M * 2 * ci].view(M, 2 * ci)
             self.k.glu_bwd(bb.y, dg, dy1)
-            self._wgrad_side(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
+            if wg:
+                self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
             self.k.gemm_nt(dy1, C["w1"][1], w.dh, N=d, K=2 * ci)
             self.k.layernorm_bwd(w.dh, bb.x2, bb.mean[2], bb.rstd[2], C["ln_w"], w.partial, dres=dx3, dx=b, dxT=t2,
                                  dxT_scale=1.0, dgamma=C["dln_w"], dbeta=C["dln_b"], dtype=self.act_dtype)
@@ -556,19 +575,41 @@ class Engine:
             # ---- attention: y = x1 + attn(x1)
             A = bp.attn
             inner = bp.heads * bp.dh
-            self._wgrad_side(w, t2, bb.o, A["dwo"], d, inner, A["dbo"])
+            if wg:
+                self._wgrad(w, t2, bb.o, A["dwo"], d, inner, A["dbo"])
             do = w.dmid.view(-1)[:M * inner].view(M, inner)
             self.k.gemm_nt(t2, A["wo"][1], do, N=inner, K=d)
-            dqkv = w.dqkv.view(-1)[:M * 3 * inner].view(M, 3 * inner)
+            dqkv = S.dqkv.view(-1)[:M * 3 * inner].view(M, 3 * inner)
             self.k.attn_bwd(bb.qkv, A["emb"], bb.probs, do, dqkv, A["demb"], w.dsc, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
-            self._wgrad_side(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
+            if wg:
+                self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
             self.k.gemm_nt(dqkv, A["wqkv"][1], w.dh, N=d, K=3 * inner)
             self.k.layernorm_bwd(w.dh, bb.x1, bb.mean[1], bb.rstd[1], A["ln_w"], w.partial, dres=dx2, dx=a, dxT=t3,
                                  dxT_scale=0.5, dgamma=A["dln_w"], dbeta=A["dln_b"], dtype=self.act_dtype)
             dx1 = a
             # ---- ff1
-            self._ff_bwd(w, dx1, t3, x_in, bp.ff1, bb.h1, bb.a1, bb.u1, bb.mean[0], bb.rstd[0], dx_in_out, None, 1.0, w.da[1])
-            self._join()
+            self._ff_bwd(w, dx1, t3, x_in, bp.ff1, bb.h1, bb.a1, bb.u1, bb.mean[0], bb.rstd[0], dx_in_out, None, 1.0, S.da[1], wg)
+
+    def _block_wgrads(self, w: _Work, bp: _BlockParams, bb: _BlockBuf, S):
+        """The ten weight-gradient launches of one block, reading the dY operands its dgrad chain left in scratch set S."""
+        B, T, M, d = w.B, w.T, w.M, self.cfg.d
+        C, A = bp.conv, bp.attn
+        ci, K = C["dw"].shape[0], C["dw"].shape[2]
+        inner = bp.heads * bp.dh
+        t0, t1, t2, t3 = S.dyTs
+        for P, dyT, da_buf, h, u in ((bp.ff2, t0, S.da[0], bb.h4, bb.u4), (bp.ff1, t3, S.da[1], bb.h1, bb.u1)):
+            ff = u.shape[1]
+            da = da_buf if da_buf.shape[1] == ff else da_buf.view(-1)[:M * ff].view(M, ff)
+            self._wgrad(w, dyT, u, P["dw2"], d, ff, P["db2"])
+            self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
+        self._wgrad(w, t1, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
+        dc = S.dc.view(-1)[:M * ci].view(M, ci)
+        self.k.dwconv_bwd_weight(dc, bb.g, C["ddw"].view(ci, K), C["ddwb"], w.dw_partial, B, T, K // 2)
+        dy1 = S.dy1.view(-1)[:M * 2 * ci].view(M, 2 * ci)
+        self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
+        self._wgrad(w, t2, bb.o, A["dwo"], d, inner, A["dbo"])
+        dqkv = S.dqkv.view(-1)[:M * 3 * inner].view(M, 3 * inner)
+        self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
 
     def backward(self, dlogits: torch.Tensor):
         """dlogits (B, T, V+1) f32 for the language of the last training forward.  Accumulates into ``grad``."""
@@ -601,20 +642,44 @@ class Engine:
         dfeat = torch.empty_like(w.dxa) if not hasattr(w, "dfeat") else w.dfeat
         w.dfeat = dfeat
         feat = ctx["feat"]
-        self._run_split(("hb", id(w), lang, feat.data_ptr()), lambda part: self._block_bwd(w, feat, bp, bb, w.dxa, w.dyT, dfeat, part),
-                        self._bn_collective(w, bp.conv["dw"].shape[0]))
-        if self.on_stage_grads_ready:
-            self.on_stage_grads_ready(f"head.{lang}")
-        # encoder blocks in reverse
-        dy = dfeat                                   # f32 gradient at the block output (after post_norm)
+        # Blocks in backward order: the head block, then the kept encoder blocks in reverse.  In deferred mode (side stream)
+        # a block's graph holds its dgrad chain on the main stream and, forked beside it, the weight gradients of the
+        # PREVIOUS block (whose dY operands sit in the other scratch set); the last block's weight gradients run at the end.
+        defer = self.side is not None
         kept = [i for i in range(cfg.n_blocks) if ctx["keep"][i]]
+        blocks = [("head", lang, bp, bb, feat, f"head.{lang}")]
         for idx in reversed(range(len(kept))):
             i = kept[idx]
             x_in = w.enc[kept[idx - 1]].out if idx > 0 else (w.x0d if (cfg.pos_dropout > 0) else w.x0)
-            self._run_split(("eb", id(w), i, x_in.data_ptr()), lambda part: self._enc_block_bwd(dfeat, x_in, i, w, dfeat, part),
-                            self._bn_collective(w, self.enc_params[i].conv["dw"].shape[0]))
+            blocks.append(("enc", i, self.enc_params[i], w.enc[i], x_in, f"enc.{i}"))
+        prev = None                                  # (tag, bp, bb, S, stage)
+        for n, (kind, tag, bpk, bbk, x_in, stage) in enumerate(blocks):
+            S = w.sets[n & 1]
+
+            def fn(part, kind=kind, tag=tag, bpk=bpk, bbk=bbk, x_in=x_in, S=S, prev=prev):
+                if prev is not None and part in ("all", "a"):
+                    with self._fork():
+                        self._block_wgrads(w, prev[1], prev[2], prev[3])
+                if kind == "head":
+                    self._block_bwd(w, x_in, bpk, bbk, w.dxa, S, dfeat, part, not defer)
+                else:
+                    self._enc_block_bwd(dfeat, x_in, tag, w, dfeat, part, S, not defer)
+                if prev is not None and part in ("all", "a"):
+                    self._join()
+
+            key = ("bb", id(w), kind, tag, x_in.data_ptr(), n & 1, prev[0] if prev else None)
+            self._run_split(key, fn, self._bn_collective(w, bpk.conv["dw"].shape[0]))
+            if defer:
+                if prev is not None and self.on_stage_grads_ready:
+                    self.on_stage_grads_ready(prev[4])
+                prev = ((kind, tag), bpk, bbk, S, stage)
+            elif self.on_stage_grads_ready:
+                self.on_stage_grads_ready(stage)
+        if prev is not None:
+            self._block_wgrads(w, prev[1], prev[2], prev[3])
             if self.on_stage_grads_ready:
-                self.on_stage_grads_ready(f"enc.{i}")
+                self.on_stage_grads_ready(prev[4])
+        dy = dfeat                                   # f32 gradient at the first block's input (after pos-enc dropout)
         # front end: x0 = sqrt(d) * (r @ Wl^T + b) [dropout]; r = relu(col @ Wc^T + bc)
         fz = "model.featurizer.sub_sampling"
         if cfg.pos_dropout > 0:
@@ -645,6 +710,15 @@ class Engine:
         a, b = self.stages[f"head.{lang}"]
         ids += list(range(a, b))
         return ids
+
+    def single_active_head(self, tids) -> Optional[str]:
+        """The one language whose head holds gradients among tensor ids ``tids``; None if several (or no) heads do."""
+        langs = []
+        for l in self.cfg.lang2vocab:
+            a, b = self.stages[f"head.{l}"]
+            if any(a <= t < b for t in tids):
+                langs.append(l)
+        return langs[0] if len(langs) == 1 else None
 
     def stage_range(self, stage: str):
         a, b = self.stages[stage]

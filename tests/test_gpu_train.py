@@ -59,5 +59,7 @@ def test_bench_contract_small():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
-    assert line["value"] > 0 and line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+    roof = line["roofline"]
+    assert line["value"] > 0 and roof["bound"] == "hbm" and roof["unit"] == "GB/s" and 0 < roof["frac"] < 1
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0 < roof["mfma"]["frac"] < 1
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
