@@ -4,6 +4,7 @@
 // stage, 9 stages); power, mel projection and log are fused behind it so a frame's samples are read once and
 // only its 80 mel values are written (algorithmic bytes: 4*L in + 4*80*F out per utterance).
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------ normalize_wav
 __global__ void __launch_bounds__(1024) normalize_wav_kernel(const float* __restrict__ wav, float* __restrict__ out, int L) {
@@ -82,34 +83,65 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
 }
 
 #define LIDK_MEL_MAX 128
+#define LIDK_MEL_TAPS 64
+// One wave per frame, 16 waves per workgroup (the per-workgroup set-up - window, twiddles, the compact filterbank - is paid
+// once per 16 waves); every wave walks a CONTIGUOUS run of frames, so it crosses an utterance boundary at most once or twice
+// and the utterance maximum costs one atomic per run (a per-frame atomic on 64 addresses was 40 % of the kernel).
 // One wave per frame.  LDS per wave: re[512], im[512]; shared twiddle[256][2], window[512].
-__global__ void __launch_bounds__(256)
+#define STFT_WAVES 16
+__global__ void __launch_bounds__(64 * STFT_WAVES)
 stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ twiddle,
                 const float* __restrict__ melfb, float* __restrict__ out, float* __restrict__ utt_max, int B, int L,
-                int pad, int hop, int F, int n_mels) {
-  __shared__ float s_re[4][LIDK_N_FFT];
-  __shared__ float s_im[4][LIDK_N_FFT];
+                int pad, int hop, int F, int n_mels, int dbg) {
+  __shared__ float s_re[STFT_WAVES][LIDK_N_FFT];
+  __shared__ float s_im[STFT_WAVES][LIDK_N_FFT];
   __shared__ float s_tw[LIDK_N_FFT / 2][2];
   __shared__ float s_win[LIDK_N_FFT];
-  __shared__ short s_lo[LIDK_MEL_MAX], s_hi[LIDK_MEL_MAX];       // nonzero k-range of every (triangular) mel filter
+  __shared__ int s_lo[LIDK_MEL_MAX], s_hi[LIDK_MEL_MAX];         // nonzero k-range of every (triangular) mel filter
+  __shared__ float s_coef[LIDK_MEL_MAX * LIDK_MEL_TAPS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int m = threadIdx.x; m < n_mels; m += 256) {
-    int lo = LIDK_N_FFT / 2 + 1, hi = -1;
-    if (m < LIDK_MEL_MAX) {
-      for (int k = 0; k <= LIDK_N_FFT / 2; ++k)
-        if (melfb[(size_t)k * n_mels + m] != 0.f) { lo = min(lo, k); hi = k; }
-      s_lo[m] = (short)lo; s_hi[m] = (short)hi;
+  // range scan, one filterbank row per thread (all loads independent; a per-filter serial scan costs 257 dependent L2
+  // round trips per workgroup)
+  for (int m = threadIdx.x; m < LIDK_MEL_MAX; m += 64 * STFT_WAVES) { s_lo[m] = LIDK_N_FFT / 2 + 1; s_hi[m] = -1; }
+  __syncthreads();
+  for (int k = threadIdx.x; k <= LIDK_N_FFT / 2; k += 64 * STFT_WAVES) {
+    const float* row = melfb + (size_t)k * n_mels;
+    const int nm = min(n_mels, LIDK_MEL_MAX);
+    for (int m0 = 0; m0 < nm; m0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = row[min(m0 + j, nm - 1)];        // 16 loads in flight
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (m0 + j < nm && v[j] != 0.f) { atomicMin(&s_lo[m0 + j], k); atomicMax(&s_hi[m0 + j], k); }
     }
   }
-  for (int i = threadIdx.x; i < LIDK_N_FFT; i += 256) s_win[i] = window[i];
-  for (int i = threadIdx.x; i < LIDK_N_FFT / 2; i += 256) { s_tw[i][0] = twiddle[2 * i]; s_tw[i][1] = twiddle[2 * i + 1]; }
+  for (int i = threadIdx.x; i < LIDK_N_FFT; i += 64 * STFT_WAVES) s_win[i] = window[i];
+  for (int i = threadIdx.x; i < LIDK_N_FFT / 2; i += 64 * STFT_WAVES) { s_tw[i][0] = twiddle[2 * i]; s_tw[i][1] = twiddle[2 * i + 1]; }
+  __syncthreads();
+  // the nonzero taps of every filter (about two per FFT bin in total) -> LDS, LIDK_MEL_TAPS slots per filter; the per-frame
+  // projection then never touches global memory (it was a chain of dependent L2 loads, 30 deep for the widest filter)
+  for (int i = threadIdx.x; i < LIDK_MEL_MAX * LIDK_MEL_TAPS; i += 64 * STFT_WAVES) {
+    const int m = i / LIDK_MEL_TAPS, j = i - m * LIDK_MEL_TAPS;
+    float c = 0.f;
+    if (m < n_mels && s_lo[m] + j <= s_hi[m]) c = melfb[(size_t)(s_lo[m] + j) * n_mels + m];
+    s_coef[i] = c;
+  }
   __syncthreads();
   float* re = s_re[wave];
   float* im = s_im[wave];
   const int Lp = L + 2 * pad;
   const long nframes = (long)B * F;
-  for (long fr = (long)blockIdx.x * 4 + wave; fr < nframes; fr += (long)gridDim.x * 4) {
+  const long per_wave = (nframes + (long)gridDim.x * STFT_WAVES - 1) / ((long)gridDim.x * STFT_WAVES);
+  const long fr0 = ((long)blockIdx.x * STFT_WAVES + wave) * per_wave, fr1 = min(nframes, fr0 + per_wave);
+  int run_b = -1;
+  float run_max = -INFINITY;
+  for (long fr = fr0; fr < fr1; ++fr) {
     const int b = (int)(fr / F), f = (int)(fr - (long)b * F);
+    if (b != run_b) {                                    // wave-uniform
+      if (run_b >= 0 && lane == 0 && !(dbg & 4)) atomic_max_float(&utt_max[run_b], run_max);
+      run_b = b; run_max = -INFINITY;
+    }
     const float* x = wav + (size_t)b * L;
     // windowed frame, bit-reversed placement
 #pragma unroll
@@ -127,6 +159,7 @@ stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window,
     // 9 radix-2 DIT stages
 #pragma unroll
     for (int st = 1; st <= 9; ++st) {
+      if (dbg & 1) break;
       const int half = 1 << (st - 1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -154,18 +187,23 @@ stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window,
     __builtin_amdgcn_wave_barrier();
     // mel projection + dB; lanes over mel bins (coalesced filterbank reads and output writes)
     float vmax = -INFINITY;
-    for (int m = lane; m < n_mels; m += 64) {
+    for (int m = lane; m < n_mels && !(dbg & 2); m += 64) {
       float acc = 0.f;
       const int klo = m < LIDK_MEL_MAX ? s_lo[m] : 0, khi = m < LIDK_MEL_MAX ? s_hi[m] : LIDK_N_FFT / 2;
-      for (int k = klo; k <= khi; ++k) acc = fmaf(re[k], melfb[(size_t)k * n_mels + m], acc);
+      if (m < LIDK_MEL_MAX && khi - klo < LIDK_MEL_TAPS) {
+        const float* cf = s_coef + m * LIDK_MEL_TAPS;
+        for (int k = klo; k <= khi; ++k) acc = fmaf(re[k], cf[k - klo], acc);
+      } else {
+        for (int k = klo; k <= khi; ++k) acc = fmaf(re[k], melfb[(size_t)k * n_mels + m], acc);
+      }
       float db = 10.0f * log10f(fmaxf(acc, 1e-10f));
       out[((size_t)b * F + f) * n_mels + m] = db;
       vmax = fmaxf(vmax, db);
     }
-    vmax = wave_max(vmax);
-    if (lane == 0) atomic_max_float(&utt_max[b], vmax);
+    run_max = fmaxf(run_max, wave_max(vmax));
     __builtin_amdgcn_wave_barrier();
   }
+  if (run_b >= 0 && lane == 0 && !(dbg & 4)) atomic_max_float(&utt_max[run_b], run_max);
 }
 
 __global__ void db_floor_mask_kernel(float* __restrict__ out, const float* __restrict__ utt_max, const int32_t* __restrict__ spans,
@@ -193,8 +231,9 @@ extern "C" int lidk_logmel(const float* wav, const float* window, const float* t
   const int F = 1 + (L + 2 * pad) / hop;
   fill_kernel<<<cdiv(B, 256), 256, 0, s>>>(utt_max, B, -INFINITY);
   long nframes = (long)B * F;
-  int blocks = (int)((nframes + 3) / 4); if (blocks > 512) blocks = 512;      // ~10 frames per wave: amortises the range scan
-  stft_mel_kernel<<<blocks, 256, 0, s>>>(wav, window, twiddle, melfb, out, utt_max, B, L, pad, hop, F, n_mels);
+  int blocks = (int)((nframes + STFT_WAVES - 1) / STFT_WAVES); if (blocks > 256) blocks = 256;      // one workgroup per CU
+  static const int dbg = getenv("LIDK_STFT_DBG") ? atoi(getenv("LIDK_STFT_DBG")) : 0;     // tuning aid: 1 no FFT, 2 no mel, 4 no max
+  stft_mel_kernel<<<blocks, 64 * STFT_WAVES, 0, s>>>(wav, window, twiddle, melfb, out, utt_max, B, L, pad, hop, F, n_mels, dbg);
   long n = nframes * n_mels;
   int eb = (int)((n + 255) / 256); if (eb > 8192) eb = 8192;
   db_floor_mask_kernel<<<eb, 256, 0, s>>>(out, utt_max, spans, mask_times > 0 ? mask_times : 0, F, n_mels, n, top_db);

@@ -54,3 +54,8 @@ show("bn+swish fwd", t(lambda: ops.bn_swish_fwd(c_, bm, br, gam, bet, s_)), 2 * 
 show("bn+swish bwd reduce", t(lambda: ops.bn_swish_bwd_reduce(dc_, c_, bm, br, gam, bet, partial)), 2 * M * ci * 2 / 1e6)
 sums, sl = torch.zeros(2 * ci, device=dev, dtype=torch.float64), torch.zeros(2 * ci, device=dev, dtype=torch.float64)
 show("bn+swish bwd apply", t(lambda: ops.bn_swish_bwd_apply(dc_, c_, bm, br, gam, bet, sums, sl, M, dg_, dga, dbe)), 3 * M * ci * 2 / 1e6)
+wav = f32(B, 48000) * 0.1
+show("normalize_wav", t(lambda: ops.normalize_wav(wav)), 2 * B * 48000 * 4 / 1e6)
+nw = ops.normalize_wav(wav)
+show("dither + pre-emphasis", t(lambda: ops.dither_preemph(nw, coef=0.97, dither=1e-5, seed=7)), 2 * B * 48000 * 4 / 1e6)
+show("logmel (stft+mel+dB+floor)", t(lambda: ops.logmel(nw, pad=16, n_mels=80, spans=None)), (B * 48000 * 4 + B * 301 * 80 * 4) / 1e6)
