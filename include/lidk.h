@@ -29,8 +29,8 @@ enum { LIDK_ACT_NONE = 0, LIDK_ACT_SWISH = 1, LIDK_ACT_RELU = 2, LIDK_ACT_SWISH_
 #define LIDK_N_FFT 512
 #define LIDK_N_FREQ 257
 #define LIDK_LN_PARTIAL_BLOCKS 256   /* rows of the column-reduction scratch used by *_bwd kernels */
-#define LIDK_LN_BWD_BLOCKS 1024
-#define LIDK_BN_PARTIAL_BLOCKS 1024   /* partial rows written by lidk_bn_swish_bwd_reduce */      /* rows of scratch used by lidk_layernorm_bwd */
+#define LIDK_LN_BWD_BLOCKS 1024      /* rows of scratch used by lidk_layernorm_bwd */
+#define LIDK_BN_PARTIAL_BLOCKS 1024   /* partial rows written by lidk_bn_swish_bwd_reduce */
 
 int lidk_version(void);
 
@@ -76,10 +76,12 @@ int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double
 int lidk_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* yT, float* y32, float* mean,
                        float* rstd, int M, int C, float eps, int dtype, void* stream);
 /* dx = dres + LN'(dy);  dxT = dxT_scale*dx (T, optional);  dgamma/dbeta += column sums.  dy is T or f32 (dy_dtype).
- * partial: >= LIDK_LN_BWD_BLOCKS*2*C floats. */
+ * partial: >= LIDK_LN_BWD_BLOCKS*2*C floats.  With dgamma == dbeta == NULL only the partial rows are written and the
+ * parameter gradients are finished later (off the critical path) by lidk_layernorm_param_grads on the same partial, M, C. */
 int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
                        const float* gamma, const float* dres, float* dx, void* dxT, float dxT_scale, float* dgamma,
                        float* dbeta, float* partial, int M, int C, int dtype, void* stream);
+int lidk_layernorm_param_grads(const float* partial, int M, int C, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------ GEMM  C[M][N] = A[M][K] * B[N][K]^T  (+ fused epilogue)
  * Replaces every nn.Linear / 1x1 nn.Conv1d on the path (lid/conformer.py:98-100,163-166,192,199,334; lid/ConformerLangModel.py:350)

@@ -338,6 +338,14 @@ extern "C" int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, 
     LIDK_DISPATCH(dtype, ln_bwd_kernel<T, T><<<G, 256, 0, s>>>((const T*)dy, x, mean, rstd, gamma, dres, dx, (T*)dxT,
                                                               dxT_scale, partial, M, C));
   }
-  colreduce_kernel<float, float, true><<<cdiv(2 * C, 16), 1024, 0, s>>>(partial, G, 2 * C, dgamma, dbeta, C, 1.0f);
+  if (dgamma || dbeta)      // both NULL: the caller finishes the parameter gradients later with lidk_layernorm_param_grads
+    colreduce_kernel<float, float, true><<<cdiv(2 * C, 16), 1024, 0, s>>>(partial, G, 2 * C, dgamma, dbeta, C, 1.0f);
+  return launch_status();
+}
+
+extern "C" int lidk_layernorm_param_grads(const float* partial, int M, int C, float* dgamma, float* dbeta, void* stream) {
+  if (!partial || M <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAX_VEC || (!dgamma && !dbeta)) return LIDK_ERR_ARG;
+  int G = cdiv(M, 4) < LIDK_LN_BWD_BLOCKS ? cdiv(M, 4) : LIDK_LN_BWD_BLOCKS;     // the partial rows lidk_layernorm_bwd(M) wrote
+  colreduce_kernel<float, float, true><<<cdiv(2 * C, 16), 1024, 0, as_stream(stream)>>>(partial, G, 2 * C, dgamma, dbeta, C, 1.0f);
   return launch_status();
 }

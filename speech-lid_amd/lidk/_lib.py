@@ -48,6 +48,7 @@ SIGNATURES = {
     "lidk_reduce_partials_f64": (_I, [_P, _I, _I, _P, _P, _P]),
     "lidk_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "lidk_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
+    "lidk_layernorm_param_grads": (_I, [_P, _I, _I, _P, _P, _P]),
     "lidk_gemm_nt": (_I, [C.POINTER(GemmArgs), _I, _P]),
     "lidk_gemm_tn": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _I, _I, _P]),
     "lidk_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

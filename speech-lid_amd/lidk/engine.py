@@ -161,6 +161,7 @@ class _Work:
             S.dqkv = e(M, 3 * max(cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head))
             S.dyTs = [e(M, d) for _ in range(4)]              # T-typed dx at: block output (x0.5), x3, x2, x1
             S.dc = e(M, ci)                                   # depthwise-conv output gradient
+            S.lnp = [f(L.LN_BWD_BLOCKS * 2 * d) for _ in range(5)]   # LayerNorm dgamma/dbeta partial rows: post, ff2, conv, attn, ff1
             self.sets.append(S)
         self.dmid = e(M, max(ci, cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head, d))   # ds / do
         self.dmid3 = e(M, ci)
@@ -434,8 +435,8 @@ class Engine:
     def _enc_block_bwd(self, dy, x_in, i, w: _Work, dfeat, part: str, S, wg: bool):
         bp, bb = self.enc_params[i], w.enc[i]
         if part in ("all", "a"):
-            self.k.layernorm_bwd(dy, bb.x4, bb.mean[4], bb.rstd[4], bp.post["w"], w.partial, dx=w.dxa, dxT=S.dyTs[0],
-                                 dxT_scale=0.5, dgamma=bp.post["dw"], dbeta=bp.post["db"], dtype=self.act_dtype)
+            post = dict(ln_w=bp.post["w"], dln_w=bp.post["dw"], dln_b=bp.post["db"])
+            self._ln_bwd(w, dy, bb.x4, bb.mean[4], bb.rstd[4], post, S.lnp[0], wg, dx=w.dxa, dxT=S.dyTs[0], dxT_scale=0.5)
         self._block_bwd(w, x_in, bp, bb, w.dxa, S, dfeat, part, wg)
 
     def _head_fwd(self, w: _Work, feat, lang, training, seed, logits):
@@ -520,7 +521,16 @@ class Engine:
         """dW [n,k] (f32) += dyT[M,n]^T @ xT[M,k] and db [n] += column sums of dyT, straight from the row-major activations."""
         self.k.gemm_tn(dyT, xT, dW, colsum=db, splitk=self._splitk(n, k), M=w.M, N1=n, N2=k)
 
-    def _ff_bwd(self, w: _Work, dx_res, dyT, x_in, P, h, a, u, mean, rstd, dx_out, dxT_out, dxT_scale, da_buf, wg: bool):
+    def _ln_bwd(self, w: _Work, dy, x, mean, rstd, P, lnp, wg: bool, **kw):
+        """LayerNorm backward.  wg=True finishes dgamma/dbeta at once (shared scratch); otherwise only the partial rows are
+        written, into this site's own buffer, and _block_wgrads finishes them beside the next block's chain."""
+        if wg:
+            self.k.layernorm_bwd(dy, x, mean, rstd, P["ln_w"], w.partial, dgamma=P["dln_w"], dbeta=P["dln_b"],
+                                 dtype=self.act_dtype, **kw)
+        else:
+            self.k.layernorm_bwd(dy, x, mean, rstd, P["ln_w"], lnp, dtype=self.act_dtype, **kw)
+
+    def _ff_bwd(self, w: _Work, dx_res, dyT, x_in, P, h, a, u, mean, rstd, dx_out, dxT_out, dxT_scale, da_buf, wg: bool, lnp):
         """dyT = 0.5*dx_res (T).  Produces dx_out = dx_res + LN'(dh) and optional T copy for the next stage."""
         M, d, ff = w.M, self.cfg.d, a.shape[1]
         if wg:
@@ -530,8 +540,7 @@ class Engine:
         if wg:
             self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
         self.k.gemm_nt(da, P["w1"][1], w.dh, N=d, K=ff)
-        self.k.layernorm_bwd(w.dh, x_in, mean, rstd, P["ln_w"], w.partial, dres=dx_res, dx=dx_out, dxT=dxT_out,
-                          dxT_scale=dxT_scale, dgamma=P["dln_w"], dbeta=P["dln_b"], dtype=self.act_dtype)
+        self._ln_bwd(w, w.dh, x_in, mean, rstd, P, lnp, wg, dres=dx_res, dx=dx_out, dxT=dxT_out, dxT_scale=dxT_scale)
 
     def _block_bwd(self, w: _Work, x_in, bp: _BlockParams, bb: _BlockBuf, dx4, S, dx_in_out, part: str = "all",
                    wg: bool = True):
@@ -548,7 +557,7 @@ class Engine:
         t0, t1, t2, t3 = S.dyTs
         if part in ("all", "a"):
             # ---- ff2: y = x3 + 0.5*ff(x3)
-            self._ff_bwd(w, dx4, t0, bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.mean[3], bb.rstd[3], a, t1, 1.0, S.da[0], wg)
+            self._ff_bwd(w, dx4, t0, bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.mean[3], bb.rstd[3], a, t1, 1.0, S.da[0], wg, S.lnp[1])
             # ---- conv module: y = x2 + conv(x2)
             if wg:
                 self._wgrad(w, t1, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
@@ -569,8 +578,7 @@ class Engine:
             if wg:
                 self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
             self.k.gemm_nt(dy1, C["w1"][1], w.dh, N=d, K=2 * ci)
-            self.k.layernorm_bwd(w.dh, bb.x2, bb.mean[2], bb.rstd[2], C["ln_w"], w.partial, dres=dx3, dx=b, dxT=t2,
-                                 dxT_scale=1.0, dgamma=C["dln_w"], dbeta=C["dln_b"], dtype=self.act_dtype)
+            self._ln_bwd(w, w.dh, bb.x2, bb.mean[2], bb.rstd[2], C, S.lnp[2], wg, dres=dx3, dx=b, dxT=t2, dxT_scale=1.0)
             dx2 = b
             # ---- attention: y = x1 + attn(x1)
             A = bp.attn
@@ -584,15 +592,21 @@ class Engine:
             if wg:
                 self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
             self.k.gemm_nt(dqkv, A["wqkv"][1], w.dh, N=d, K=3 * inner)
-            self.k.layernorm_bwd(w.dh, bb.x1, bb.mean[1], bb.rstd[1], A["ln_w"], w.partial, dres=dx2, dx=a, dxT=t3,
-                                 dxT_scale=0.5, dgamma=A["dln_w"], dbeta=A["dln_b"], dtype=self.act_dtype)
+            self._ln_bwd(w, w.dh, bb.x1, bb.mean[1], bb.rstd[1], A, S.lnp[3], wg, dres=dx2, dx=a, dxT=t3, dxT_scale=0.5)
             dx1 = a
             # ---- ff1
-            self._ff_bwd(w, dx1, t3, x_in, bp.ff1, bb.h1, bb.a1, bb.u1, bb.mean[0], bb.rstd[0], dx_in_out, None, 1.0, S.da[1], wg)
+            self._ff_bwd(w, dx1, t3, x_in, bp.ff1, bb.h1, bb.a1, bb.u1, bb.mean[0], bb.rstd[0], dx_in_out, None, 1.0, S.da[1], wg,
+                         S.lnp[4])
 
-    def _block_wgrads(self, w: _Work, bp: _BlockParams, bb: _BlockBuf, S):
-        """The ten weight-gradient launches of one block, reading the dY operands its dgrad chain left in scratch set S."""
+    def _block_wgrads(self, w: _Work, bp: _BlockParams, bb: _BlockBuf, S, post_norm: bool):
+        """The ten weight-gradient launches of one block, reading the dY operands its dgrad chain left in scratch set S, and the
+        LayerNorm dgamma/dbeta finalizers of its sites (post_norm: the block's own post_norm went through this path too)."""
         B, T, M, d = w.B, w.T, w.M, self.cfg.d
+        sites = [(1, bp.ff2), (2, bp.conv), (3, bp.attn), (4, bp.ff1)]
+        if post_norm:
+            sites.append((0, dict(dln_w=bp.post["dw"], dln_b=bp.post["db"])))
+        for i, P in sites:
+            self.k.layernorm_param_grads(S.lnp[i], M, d, P["dln_w"], P["dln_b"])
         C, A = bp.conv, bp.attn
         ci, K = C["dw"].shape[0], C["dw"].shape[2]
         inner = bp.heads * bp.dh
@@ -659,7 +673,7 @@ class Engine:
             def fn(part, kind=kind, tag=tag, bpk=bpk, bbk=bbk, x_in=x_in, S=S, prev=prev):
                 if prev is not None and part in ("all", "a"):
                     with self._fork():
-                        self._block_wgrads(w, prev[1], prev[2], prev[3])
+                        self._block_wgrads(w, prev[1], prev[2], prev[3], prev[0][0] == "enc")
                 if kind == "head":
                     self._block_bwd(w, x_in, bpk, bbk, w.dxa, S, dfeat, part, not defer)
                 else:
@@ -676,7 +690,7 @@ class Engine:
             elif self.on_stage_grads_ready:
                 self.on_stage_grads_ready(stage)
         if prev is not None:
-            self._block_wgrads(w, prev[1], prev[2], prev[3])
+            self._block_wgrads(w, prev[1], prev[2], prev[3], prev[0][0] == "enc")
             if self.on_stage_grads_ready:
                 self.on_stage_grads_ready(prev[4])
         dy = dfeat                                   # f32 gradient at the first block's input (after pos-enc dropout)

@@ -162,6 +162,11 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, partial, dres=None, dx=None, dxT=Non
                                    dxT_scale, _p(dgamma), _p(dbeta), _p(partial), M, Cc, code, _stream()), "layernorm_bwd")
 
 
+def layernorm_param_grads(partial, M, C, dgamma, dbeta):
+    """Finish dgamma/dbeta from the partial rows a ``layernorm_bwd(..., dgamma=None, dbeta=None)`` call left behind."""
+    check(lib().lidk_layernorm_param_grads(_p(partial), M, C, _p(dgamma), _p(dbeta), _stream()), "layernorm_param_grads")
+
+
 # ----------------------------------------------------------------------------------------------- GEMM
 def gemm_nt(A, B, out, bias=None, act=L.ACT_NONE, alpha=1.0, res=None, out2=None, aux=None, splitk=1, M=None, N=None,
             K=None):

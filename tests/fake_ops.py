@@ -84,14 +84,23 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, partial, dres=None, dx=None, dxT=Non
     d = rstd[:, None] * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
     if dres is not None:
         d = d + dres
+    C = x.shape[1]
+    partial[:2 * C] = torch.cat([(dyf * xh).sum(0), dyf.sum(0)])          # "row 0" of the partial sums; the rest unused
     if dgamma is not None:
-        dgamma += (dyf * xh).sum(0)
+        dgamma += partial[:C]
     if dbeta is not None:
-        dbeta += dyf.sum(0)
+        dbeta += partial[C:2 * C]
     if dx is not None:
         dx.copy_(d)
     if dxT is not None:
         dxT.copy_((d * dxT_scale).to(dxT.dtype))
+
+
+def layernorm_param_grads(partial, M, C, dgamma, dbeta):
+    if dgamma is not None:
+        dgamma += partial[:C]
+    if dbeta is not None:
+        dbeta += partial[C:2 * C]
 
 
 def gemm_nt(A, B, out, bias=None, act=ACT_NONE, alpha=1.0, res=None, out2=None, aux=None, splitk=1, M=None, N=None, K=None):

@@ -125,6 +125,12 @@ def test_layernorm_fwd_bwd(dt, M, C):
     dx2 = torch.empty(M, C, device=DEV)
     ops.layernorm_bwd(dev(rt(dy, dt)), xd, mean, rstd, gd, partial, dx=dx2, dtype=dt)
     check("ln_bwd_dx_f32dy", dx2, x.grad, 5e-5, 1e-5)
+    # split form: partial rows now, parameter gradients later (the engine finishes them on the weight-gradient stream)
+    dgam2 = torch.full((C,), 1.0, device=DEV)
+    dbet2 = torch.full((C,), -1.0, device=DEV)
+    ops.layernorm_bwd(dev(dy, dt), xd, mean, rstd, gd, partial, dres=dev(dres), dx=dx, dxT=dxT, dxT_scale=0.5)
+    ops.layernorm_param_grads(partial, M, C, dgam2, dbet2)
+    assert torch.equal(dgam2, dgam) and torch.equal(dbet2, dbet)
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
