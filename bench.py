@@ -272,7 +272,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
-    roof = gemm_roofline(trainer, batches, step_fn) if rank == 0 else None
+    roof = gemm_roofline(trainer, batches, step_fn)      # every rank runs the instrumented step (it contains collectives)
     if world > 1:
         dist.barrier()
     cpu = None

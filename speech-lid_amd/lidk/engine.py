@@ -53,7 +53,9 @@ class _GraphCache:
             return fn()
         if st[0] is None:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread-local capture mode: other threads (e.g. the RCCL process group's watchdog polling its events) must
+            # not invalidate a capture in progress
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
             st[0] = g
         st[0].replay()

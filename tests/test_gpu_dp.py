@@ -14,7 +14,7 @@ from conftest import PKG, ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir, amp):
+def _worker(rank, world, port, out_dir, amp, backend="gloo", force_ddp=False, tag=""):
     sys.path[:0] = [ROOT, PKG]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from ccml import seed_everything
@@ -24,8 +24,8 @@ def _worker(rank, world, port, out_dir, amp):
     seed_everything(0)
     ov = ["trainer.gpu_id=0", f"trainer.use_amp={'true' if amp else 'false'}", "trainer.total_epoch=1", "model.dropout=0.0",
           "data.feature.mask_times=0", f"data.sampler_common.train_batch_size={4 // world}", "data.synthetic.items_per_lang=8",
-          "data.synthetic.val_items_per_lang=2", "data.synthetic.seconds=0.5", f"trainer.ddp={'true' if world > 1 else 'false'}",
-          f"trainer.world_size={world}", f"trainer.local_rank={rank}", "trainer.backend=gloo", f"trainer.master_port={port}",
+          "data.synthetic.val_items_per_lang=2", "data.synthetic.seconds=0.5", f"trainer.ddp={'true' if (world > 1 or force_ddp) else 'false'}",
+          f"trainer.world_size={world}", f"trainer.local_rank={rank}", f"trainer.backend={backend}", f"trainer.master_port={port}",
           "module.interval=1000", "trainer.log_interval=1000"]
     cfg = hydra_lite.load_config(os.path.join(PKG, "lid", "conf"), "synthetic_cfg1", ov)
     module, sets, params = launcher.build(cfg, rank, world)
@@ -37,7 +37,7 @@ def _worker(rank, world, port, out_dir, amp):
     trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
     trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=params)
     torch.save({k: v.detach().cpu().clone() for k, v in module.model.state_dict().items()},
-               os.path.join(out_dir, f"w{world}_r{rank}.pt"))
+               os.path.join(out_dir, f"w{world}_r{rank}{tag}.pt"))
 
 
 @pytest.mark.parametrize("amp", [False])
@@ -59,3 +59,20 @@ def test_two_ranks_match_one_process_on_gpu(tmp_path, amp):
             worst = max(worst, float((r0[k] - one[k]).abs().max()))
             np.testing.assert_allclose(r0[k].numpy(), one[k].numpy(), rtol=5e-3, atol=5e-5, err_msg=k)
     print(f"[dp 2x2 vs 1x4] max |param diff| = {worst:.3e}")
+
+
+def test_single_rank_rccl_process_group_with_graph_capture(tmp_path):
+    """One rank over the real 'nccl' (= RCCL) backend: the SyncBN and gradient all-reduces become single-rank RCCL launches on
+    the side stream, with the process group's watchdog thread alive while block sequences are captured into hipGraphs (the
+    captures use thread-local error mode for exactly that reason).  Must reproduce the plain single-process run."""
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_worker, args=(0, 1, 29717, str(tmp_path), False))
+    p.start(); p.join(400)
+    assert p.exitcode == 0
+    q = ctx.Process(target=_worker, args=(0, 1, 29719, str(tmp_path), False, "nccl", True, "_rccl"))
+    q.start(); q.join(400)
+    assert q.exitcode == 0
+    a, b = torch.load(tmp_path / "w1_r0.pt"), torch.load(tmp_path / "w1_r0_rccl.pt")
+    for k in a:
+        if a[k].is_floating_point() and not k.endswith(("conv.net.4.conv.bias", "conv.net.5.running_mean")):
+            np.testing.assert_allclose(b[k].numpy(), a[k].numpy(), rtol=5e-3, atol=5e-5, err_msg=k)
