@@ -376,6 +376,143 @@ gemm_nt_bf16_direct_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------ bf16 MFMA kernel, pipelined tiles
+// For the wide K = 256 GEMMs (ff up-projection, its data gradient, QKV, pointwise conv 1) the output stores are half of a
+// launch (ablation in DESIGN.md section 5) and, in gemm_nt_bf16_direct_kernel, purely additive: a wave keeps its slot until
+// its stores have drained, so stores never overlap the next tile's operand fetch.  Here every workgroup walks TPB tiles and
+// the work of consecutive tiles is interleaved in straight-line code:
+//   * the epilogue of tile j-1 (its accumulators are kept in 16 spare registers) is issued in two slices inside the first
+//     two K stages of tile j;
+//   * the last two K stages of tile j issue the operand loads of tile j+1's first two K tiles.
+// Everything in the steady state is unconditional (M % 64 == 0, N % 64 == 0, K == 256, epilogue chosen at compile time,
+// tile indices past the end are clamped to the last tile, which is then simply computed twice with identical stores), so
+// hipcc can keep counted vmcnt waits instead of draining the stores.
+enum { PIPE_PLAIN = 0, PIPE_BIAS = 1, PIPE_BIAS_SWISH_PRE = 2, PIPE_SWISH_GRAD = 3 };
+
+template <int MODE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
+gemm_nt_bf16_pipe_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int lda, int ldb, int tiles,
+                         int G, int TPB, Epi e) {
+  constexpr int K = 256;
+  __shared__ __attribute__((aligned(16))) bf16 As[64 * BK];
+  __shared__ __attribute__((aligned(16))) bf16 Bs[64 * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int n_tiles = N / 64, span = G * TPB;
+
+  auto coords = [&](int j, int& m0, int& n0) __attribute__((always_inline)) {
+    int t = xcd_tile(blockIdx.x + j * G, span);          // G % 8 == 0: the XCD of launch index b + j*G is that of b
+    t = min(t, tiles - 1);
+    m0 = (t / n_tiles) * 64; n0 = (t % n_tiles) * 64;
+  };
+  u32x4 ra0[2], rb0[2], ra1[2], rb1[2];
+  auto gload = [&](u32x4 (&ra)[2], u32x4 (&rb)[2], int m0, int n0, int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int c = tid + i * 256, row = c >> 3, kc = (c & 7) * 8;
+      ra[i] = *reinterpret_cast<const u32x4*>(A + (size_t)(m0 + row) * lda + k0 + kc);
+      rb[i] = *reinterpret_cast<const u32x4*>(B + (size_t)(n0 + row) * ldb + k0 + kc);
+    }
+  };
+  auto lstore = [&](const u32x4 (&ra)[2], const u32x4 (&rb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int c = tid + i * 256, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<u32x4*>(&As[row * BK + ((ch ^ (row & 7)) << 3)]) = ra[i];
+      int rho = (row & ~31) + (((row >> 2) & 1) << 4) + (((row >> 3) & 3) << 2) + (row & 3);     // bf16 outputs: pair layout
+      *reinterpret_cast<u32x4*>(&Bs[rho * BK + ((ch ^ (rho & 7)) << 3)]) = rb[i];
+    }
+  };
+  f32x4 acc[2][2], prv[2][2];
+  auto mma = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; kk += 4) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * 32 + i * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * 32 + j * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+  // rows i*16 + fr of this wave's 32x32 block of the tile at (m0, n0): 8 consecutive columns per lane
+  auto epi = [&](const f32x4 (&a)[2][2], int i, int m0, int n0) __attribute__((always_inline)) {
+    const int m = m0 + wm * 32 + i * 16 + fr, n = n0 + wn * 32 + 8 * fq;
+    float4 v0 = make_float4(a[i][0][0], a[i][0][1], a[i][0][2], a[i][0][3]);
+    float4 v1 = make_float4(a[i][1][0], a[i][1][1], a[i][1][2], a[i][1][3]);
+    if (MODE == PIPE_BIAS || MODE == PIPE_BIAS_SWISH_PRE) {
+      float4 b0 = load4(e.bias + n), b1 = load4(e.bias + n + 4);
+      v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w; v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
+    }
+    if (MODE == PIPE_BIAS_SWISH_PRE) {
+      *reinterpret_cast<uint4*>((bf16*)e.out2 + (size_t)m * e.ldo2 + n) = pack8(v0, v1);
+      v0.x *= sigmoidf_(v0.x); v0.y *= sigmoidf_(v0.y); v0.z *= sigmoidf_(v0.z); v0.w *= sigmoidf_(v0.w);
+      v1.x *= sigmoidf_(v1.x); v1.y *= sigmoidf_(v1.y); v1.z *= sigmoidf_(v1.z); v1.w *= sigmoidf_(v1.w);
+    }
+    if (MODE == PIPE_SWISH_GRAD) {
+      const bf16* ap = (const bf16*)e.aux + (size_t)m * e.ldaux + n;
+      float4 a0 = load4(ap), a1 = load4(ap + 4);
+      float s;
+      s = sigmoidf_(a0.x); v0.x *= s * (1.f + a0.x * (1.f - s)); s = sigmoidf_(a0.y); v0.y *= s * (1.f + a0.y * (1.f - s));
+      s = sigmoidf_(a0.z); v0.z *= s * (1.f + a0.z * (1.f - s)); s = sigmoidf_(a0.w); v0.w *= s * (1.f + a0.w * (1.f - s));
+      s = sigmoidf_(a1.x); v1.x *= s * (1.f + a1.x * (1.f - s)); s = sigmoidf_(a1.y); v1.y *= s * (1.f + a1.y * (1.f - s));
+      s = sigmoidf_(a1.z); v1.z *= s * (1.f + a1.z * (1.f - s)); s = sigmoidf_(a1.w); v1.w *= s * (1.f + a1.w * (1.f - s));
+    }
+    *reinterpret_cast<uint4*>((bf16*)e.out + (size_t)m * e.ldo + n) = pack8(v0, v1);
+  };
+  auto zero = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto keep = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) prv[i][j] = acc[i][j];
+  };
+#define PIPE_STAGE(RA, RB, LOADS, EPI)   \
+  do { lstore(RA, RB); __syncthreads(); LOADS; mma(); EPI; __syncthreads(); } while (0)
+
+  int m0, n0, mn, nn, mp = 0, np = 0;
+  coords(0, m0, n0);
+  gload(ra0, rb0, m0, n0, 0);
+  gload(ra1, rb1, m0, n0, BK);
+  // ---- first tile: nothing to store yet
+  coords(1, mn, nn);
+  zero();
+  PIPE_STAGE(ra0, rb0, gload(ra0, rb0, m0, n0, 2 * BK), (void)0);
+  PIPE_STAGE(ra1, rb1, gload(ra1, rb1, m0, n0, 3 * BK), (void)0);
+  PIPE_STAGE(ra0, rb0, gload(ra0, rb0, mn, nn, 0), (void)0);
+  PIPE_STAGE(ra1, rb1, gload(ra1, rb1, mn, nn, BK), (void)0);
+  keep(); mp = m0; np = n0; m0 = mn; n0 = nn;
+  // ---- middle tiles
+  for (int j = 1; j + 1 < TPB; ++j) {
+    coords(j + 1, mn, nn);
+    zero();
+    PIPE_STAGE(ra0, rb0, gload(ra0, rb0, m0, n0, 2 * BK), epi(prv, 0, mp, np));
+    PIPE_STAGE(ra1, rb1, gload(ra1, rb1, m0, n0, 3 * BK), epi(prv, 1, mp, np));
+    PIPE_STAGE(ra0, rb0, gload(ra0, rb0, mn, nn, 0), (void)0);
+    PIPE_STAGE(ra1, rb1, gload(ra1, rb1, mn, nn, BK), (void)0);
+    keep(); mp = m0; np = n0; m0 = mn; n0 = nn;
+  }
+  // ---- last tile (TPB >= 2): no further prefetch, then its own epilogue
+  zero();
+  PIPE_STAGE(ra0, rb0, gload(ra0, rb0, m0, n0, 2 * BK), epi(prv, 0, mp, np));
+  PIPE_STAGE(ra1, rb1, gload(ra1, rb1, m0, n0, 3 * BK), epi(prv, 1, mp, np));
+  PIPE_STAGE(ra0, rb0, (void)0, (void)0);
+  PIPE_STAGE(ra1, rb1, (void)0, (void)0);
+  epi(acc, 0, m0, n0);
+  epi(acc, 1, m0, n0);
+#undef PIPE_STAGE
+}
+
 // ------------------------------------------------------------------------------------ f32 kernel (parity mode)
 __global__ void __launch_bounds__(256)
 gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, int M, int N, int K, int lda, int ldb,
@@ -433,6 +570,28 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
     // only 4..16 K-tiles, so many small workgroups per CU hide the load latency better than one big tile does); the 128x128
     // variant is kept for long-K problems and can be forced with LIDK_GEMM_TILE=128.
     static const int direct = getenv("LIDK_GEMM_DIRECT") ? atoi(getenv("LIDK_GEMM_DIRECT")) : 1;
+    static const int pipe = getenv("LIDK_GEMM_PIPE") ? atoi(getenv("LIDK_GEMM_PIPE")) : 1;
+    if (pipe && splitk == 1 && !dbg && g->K == 256 && !(g->M & 63) && !(g->N & 63) && !g->out_f32 && !g->res && g->alpha == 1.0f &&
+        !(g->ldo & 7) && (!g->out2 || !(g->ldo2 & 7)) && (!g->aux || !(g->ldaux & 7))) {
+      int mode = -1;
+      if (g->act == LIDK_ACT_NONE) mode = g->bias ? PIPE_BIAS : PIPE_PLAIN;
+      else if (g->act == LIDK_ACT_SWISH && g->bias && g->out2) mode = PIPE_BIAS_SWISH_PRE;
+      else if (g->act == LIDK_ACT_SWISH_GRAD && !g->bias) mode = PIPE_SWISH_GRAD;
+      const int tiles = (g->M / 64) * (g->N / 64);
+      const int tpb = pipe > 1 ? pipe : (tiles > 1024 ? 2 : 1);     // tiles per workgroup (measured: 2 beats 3 and 4 on every shape)
+      if (mode >= 0 && tpb >= 2) {
+        const int G = cdiv(cdiv(tiles, tpb), 8) * 8;
+#define LIDK_PIPE_LAUNCH(MODE_)                                                                                              \
+  gemm_nt_bf16_pipe_kernel<MODE_><<<G, 256, 0, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->lda, g->ldb, tiles, \
+                                                    G, tpb, e)
+        if (mode == PIPE_PLAIN) LIDK_PIPE_LAUNCH(PIPE_PLAIN);
+        else if (mode == PIPE_BIAS) LIDK_PIPE_LAUNCH(PIPE_BIAS);
+        else if (mode == PIPE_BIAS_SWISH_PRE) LIDK_PIPE_LAUNCH(PIPE_BIAS_SWISH_PRE);
+        else LIDK_PIPE_LAUNCH(PIPE_SWISH_GRAD);
+#undef LIDK_PIPE_LAUNCH
+        return launch_status();
+      }
+    }
     if (direct && splitk == 1 && (g->K & 63) == 0) {
       const int grid = cdiv(g->N, 64) * cdiv(g->M, 64);
       gemm_nt_bf16_direct_kernel<64, 64><<<grid, 256, 0, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->K, g->lda,

@@ -192,6 +192,32 @@ def test_gemm_epilogues(dt):
     check("gemm_splitk", o, base + _gemm_ref(A2, B2, dt).float(), 5e-4)
 
 
+@pytest.mark.parametrize("M,N", [(9664, 1024), (6400, 512), (4160, 768), (3136, 1024)])
+def test_gemm_pipelined_tiles(M, N):
+    """Wide K = 256 shapes take the tile-pipelined kernel (several tiles per workgroup, epilogue of tile j-1 issued inside
+    tile j's K loop, clamped duplicate tiles at the end of the range): all four compiled epilogues against the reference."""
+    dt, K = torch.bfloat16, 256
+    A = torch.randn(M, K, generator=g(30)) * 0.3
+    B = torch.randn(N, K, generator=g(31)) * 0.3
+    bias = torch.randn(N, generator=g(32))
+    aux = torch.randn(M, N, generator=g(33))
+    acc = _gemm_ref(A, B, dt).float()
+    Ad, Bd = dev(A, dt), dev(B, dt)
+    out = torch.full((M, N), 5.0, device=DEV, dtype=dt)
+    pre = torch.full((M, N), 5.0, device=DEV, dtype=dt)
+    ops.gemm_nt(Ad, Bd, out)
+    check("pipe_plain", out, acc, 4e-2)
+    ops.gemm_nt(Ad, Bd, out, bias=dev(bias))
+    check("pipe_bias", out, acc + bias, 4e-2)
+    ops.gemm_nt(Ad, Bd, out, bias=dev(bias), act=L.ACT_SWISH, out2=pre)
+    a = acc + bias
+    check("pipe_swish_pre", pre, a, 4e-2)
+    check("pipe_swish", out, a * torch.sigmoid(a), 4e-2)
+    s_ = torch.sigmoid(rt(aux, dt))
+    ops.gemm_nt(Ad, Bd, out, act=L.ACT_SWISH_GRAD, aux=dev(aux, dt))
+    check("pipe_swish_grad", out, acc * s_ * (1 + rt(aux, dt) * (1 - s_)), 4e-2)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N1,N2,splitk", [(9664, 1024, 256, 8), (9664, 256, 1024, 8), (204, 256, 64, 4), (1000, 41, 256, 16),
                                             (333, 80, 240, 3), (4100, 768, 256, 5), (130, 64, 64, 1), (2048, 256, 256, 16)])
