@@ -506,7 +506,7 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
   }
 }
 
-template <int DH>
+template <int DH, bool DUAL>     // DUAL: LDS holds both phases' operands at once
 __global__ void __launch_bounds__(1024)
 attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ probs, const bf16* __restrict__ dout,
                           const bf16* __restrict__ dsT, bf16* __restrict__ dqkv, float* __restrict__ demb, AttGeom g, int ldp,
@@ -514,12 +514,16 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LDK = DH + 8, CH = DH / 8;
   const int T_ = g.T, Tp = (T_ + 31) / 32 * 32, NJ = Tp / 16, LDV = Tp + 8;
-  bf16* X = reinterpret_cast<bf16*>(smem);             // [Tp][LDV]: P, then dS
-  bf16* Y = X + Tp * LDV;                               // [Tp][LDK]: dO, then Q
+  // both phases' operands are staged up front (P, dO | dS, Q in separate buffers) so their global loads overlap and the
+  // second phase starts without another load round trip
+  bf16* X = reinterpret_cast<bf16*>(smem);             // [Tp][LDV]: P
+  bf16* Y = X + Tp * LDV;                               // [Tp][LDK]: dO
+  bf16* X2 = DUAL ? Y + Tp * LDK : X;                   // [Tp][LDV]: dS
+  bf16* Y2 = DUAL ? X2 + Tp * LDV : Y;                  // [Tp][LDK]: Q
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4, nthr = blockDim.x, NW = nthr >> 6;
   const int b = blockIdx.x / g.H, h = blockIdx.x % g.H;
   const size_t bh = (size_t)(b * g.H + h) * T_;
-  auto stage = [&](const bf16* sq, const bf16* rows, size_t row_stride) {
+  auto stage = [&](bf16* X, bf16* Y, const bf16* sq, const bf16* rows, size_t row_stride) {
     for (int c = tid; c < Tp * (Tp / 8); c += nthr) {
       int i = c / (Tp / 8), col = (c % (Tp / 8)) * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -534,7 +538,8 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
     }
   };
   // ---- phase A: dv[j][d] = sum_i P[i][j] dO[i][d]
-  stage(probs, dout + (size_t)b * T_ * g.inner + h * DH, g.inner);
+  stage(X, Y, probs, dout + (size_t)b * T_ * g.inner + h * DH, g.inner);
+  if (DUAL) stage(X2, Y2, dsT, qkv + (size_t)b * T_ * g.ld + h * DH, g.ld);
   __syncthreads();
   for (int jt = wave; jt < NJ; jt += NW) {
     f32x4 acc[DH / 16];
@@ -554,10 +559,12 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
         if (j < T_) dqkv[(size_t)(b * T_ + j) * g.ld + 2 * g.inner + h * DH + nt * 16 + fr] = (bf16)acc[nt][r];
       }
   }
-  __syncthreads();
   // ---- phase B: dk[j][d] = scale * sum_i dS[i][j] q[i][d] ; dE[r][d] += scale * sum_i dS[i][i-r] q[i][d]
-  stage(dsT, qkv + (size_t)b * T_ * g.ld + h * DH, g.ld);
-  __syncthreads();
+  if (!DUAL) {
+    __syncthreads();
+    stage(X2, Y2, dsT, qkv + (size_t)b * T_ * g.ld + h * DH, g.ld);
+    __syncthreads();
+  }
   const int n_rt = 2 * Tp / 16;                          // offset tiles covering r in [-Tp, Tp)
   for (int item = wave; item < NJ + n_rt; item += NW) {
     f32x4 acc[DH / 16];
@@ -566,10 +573,10 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
     if (item < NJ) {
       const int jt = item;
       for (int k0 = 0; k0 < Tp; k0 += 32) {
-        bf16x8 af = tr_frag(X, LDV, k0, jt * 16, fq, fr);
+        bf16x8 af = tr_frag(X2, LDV, k0, jt * 16, fq, fr);
 #pragma unroll
         for (int nt = 0; nt < DH / 16; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, tr_frag(Y, LDK, k0, nt * 16, fq, fr), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, tr_frag(Y2, LDK, k0, nt * 16, fq, fr), acc[nt], 0, 0, 0);
       }
 #pragma unroll
       for (int nt = 0; nt < DH / 16; ++nt)
@@ -587,12 +594,12 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
         for (int jj = 0; jj < 8; ++jj) {
           const int i = k0 + 8 * fq + jj, col = i - rt - fr;    // dS[i][i - r], r = rt + fr
           const bool ok = col >= 0 && col < Tp;
-          const bf16 val = X[i * LDV + (ok ? col : 0)];
+          const bf16 val = X2[i * LDV + (ok ? col : 0)];
           ga.e[jj] = ok ? val : (bf16)0.f;
         }
 #pragma unroll
         for (int nt = 0; nt < DH / 16; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga.v, tr_frag(Y, LDK, k0, nt * 16, fq, fr), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga.v, tr_frag(Y2, LDK, k0, nt * 16, fq, fr), acc[nt], 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -611,9 +618,9 @@ static size_t att_bwd_rows_mfma_lds(int T_, int dh, int nw = 4) {
   int Tp = (T_ + 31) / 32 * 32;
   return (size_t)2 * ((size_t)2 * Tp * (dh + 8) + (size_t)(2 * Tp + 8) * (dh + 8) + (size_t)nw * 16 * (Tp + 8));
 }
-static size_t att_bwd_cols_mfma_lds(int T_, int dh) {
+static size_t att_bwd_cols_mfma_lds(int T_, int dh, bool dual = false) {
   int Tp = (T_ + 31) / 32 * 32;
-  return (size_t)2 * ((size_t)Tp * (Tp + 8) + (size_t)Tp * (dh + 8));
+  return (size_t)2 * (dual ? 2 : 1) * ((size_t)Tp * (Tp + 8) + (size_t)Tp * (dh + 8));
 }
 
 template <int DH>
@@ -625,10 +632,18 @@ static void att_bwd_mfma_launch(const void* qkv, const void* embT, const void* p
   (void)hipFuncSetAttribute((const void*)attn_bwd_rows_mfma_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
   attn_bwd_rows_mfma_kernel<DH><<<g.B * g.H, 64 * nw, l1, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)probs,
                                                            (const bf16*)dout, (bf16*)dqkv, (bf16*)dsT, g, ldp, scale);
-  (void)hipFuncSetAttribute((const void*)attn_bwd_cols_mfma_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
   const int nwc = min(16, max(4, (g.T + 15) / 16 + 2 * ((g.T + 31) / 32 * 32) / 16) / 2);   // phase B has NJ + n_rt items: two rounds
-  attn_bwd_cols_mfma_kernel<DH><<<g.B * g.H, 64 * nwc, l2, s>>>((const bf16*)qkv, (const bf16*)probs, (const bf16*)dout,
-                                                           (const bf16*)dsT, (bf16*)dqkv, demb, g, ldp, scale);
+  const bool dual = att_bwd_cols_mfma_lds(g.T, DH, true) <= 160 * 1024;
+  if (dual) {
+    l2 = att_bwd_cols_mfma_lds(g.T, DH, true);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_cols_mfma_kernel<DH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+    attn_bwd_cols_mfma_kernel<DH, true><<<g.B * g.H, 64 * nwc, l2, s>>>((const bf16*)qkv, (const bf16*)probs, (const bf16*)dout,
+                                                                       (const bf16*)dsT, (bf16*)dqkv, demb, g, ldp, scale);
+  } else {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_cols_mfma_kernel<DH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+    attn_bwd_cols_mfma_kernel<DH, false><<<g.B * g.H, 64 * nwc, l2, s>>>((const bf16*)qkv, (const bf16*)probs, (const bf16*)dout,
+                                                                        (const bf16*)dsT, (bf16*)dqkv, demb, g, ldp, scale);
+  }
 }
 
 // ------------------------------------------------------------------------------------ host side

@@ -250,10 +250,13 @@ def _attn_ref(qkv, emb, B, T, H, dh):
 @pytest.mark.parametrize("path", ["v1", "mfma"])
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("B,T,H,dh,maxpos", [(2, 51, 4, 16, 512), (2, 151, 4, 64, 512), (1, 70, 8, 32, 512),
-                                             (2, 51, 8, 8, 512), (2, 60, 2, 16, 20), (2, 100, 2, 64, 30), (3, 33, 2, 32, 512)])
+                                             (2, 51, 8, 8, 512), (2, 60, 2, 16, 20), (2, 100, 2, 64, 30), (3, 33, 2, 32, 512),
+                                             (1, 200, 2, 64, 512)])     # T = 200: backward column kernel stages its two phases in turn
 def test_attention_fwd_bwd(dt, B, T, H, dh, maxpos, path):
     if path == "mfma" and (dt != torch.bfloat16 or dh not in (32, 64)):
         pytest.skip("MFMA attention kernels are bf16, dh in {32, 64}")
+    if path == "v1" and dt == torch.float32 and T * dh > 10000:
+        pytest.skip("the f32 (parity-mode) kernels keep K, V and the rel-pos slice in LDS as f32: T = 200 x dh = 64 does not fit")
     inner = H * dh
     qkv = (0.7 * torch.randn(B * T, 3 * inner, generator=g(20)))
     emb = (0.5 * torch.randn(2 * maxpos + 1, dh, generator=g(21)))
