@@ -55,8 +55,16 @@ class _GraphCache:
             g = torch.cuda.CUDAGraph()
             # thread-local capture mode: other threads (e.g. the RCCL process group's watchdog polling its events) must
             # not invalidate a capture in progress
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                fn()
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    fn()
+            except RuntimeError as err:                 # capture refused (nothing was executed): run this and all later
+                import logging                          # sequences through the eager launch path instead
+                logging.warning("lidk: hipGraph capture failed (%s); continuing without graphs", str(err).splitlines()[0])
+                self.enabled = False
+                self.state.clear()
+                torch.cuda.synchronize()
+                return fn()
             st[0] = g
         st[0].replay()
 
