@@ -137,10 +137,17 @@ int lidk_glu_bwd(const void* y, const void* dg, void* dy, int M, int C, int dtyp
  * stat_partial (optional) [B*ceil(T/32)][2][C]: per-block (sum, sum of squares) of c for the BatchNorm batch statistics. */
 int lidk_dwconv_fwd(const void* g, const float* w, const float* bias, void* c, float* stat_partial, int B, int T, int C,
                     int K, int pad_left, int dtype, void* stream);
+/* The same forward with the GLU of lid/conformer.py:47-54 fused in front: y [B*T][2C] -> c; g (may be NULL) receives
+ * a*sigmoid(gate) [B*T][C] for the weight gradient.  C % 4 == 0. */
+int lidk_glu_dwconv_fwd(const void* y, const float* w, const float* bias, void* g, void* c, float* stat_partial, int B, int T,
+                        int C, int K, int pad_left, int dtype, void* stream);
 int lidk_dwconv_stat_parts(int B, int T);
 int lidk_dwconv_bwd_input(const void* dc, const float* w, void* dg, int B, int T, int C, int K, int pad_left, int dtype,
                           void* stream);
 /* dw [C][K] += , db [C] += ;  partial: >= B*C*(K+1) floats */
+/* Input gradient with the GLU backward fused behind it: dy [B*T][2C] = (dg*sigmoid(gate) | dg*a*sigmoid'(gate)), a/gate from y. */
+int lidk_dwconv_bwd_input_glu(const void* dc, const float* w, const void* y, void* dy, int B, int T, int C, int K, int pad_left,
+                              int dtype, void* stream);
 int lidk_dwconv_bwd_weight(const void* dc, const void* g, float* dw, float* db, float* partial, int B, int T, int C,
                            int K, int pad_left, int dtype, void* stream);
 /* BatchNorm1d training statistics (lid/conformer.py:197): sums [2][C] f64 = (sum x, sum x^2) over `count` rows (already

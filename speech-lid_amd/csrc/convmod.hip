@@ -48,10 +48,15 @@ extern "C" int lidk_glu_bwd(const void* y, const void* dg, void* dy, int M, int 
 
 // ------------------------------------------------------------------------------------ depthwise conv (fwd and dgrad)
 // out[b][t][ch] = bias[ch] + sum_k w[ch][k] * in[b][t + k - pad_left][ch]   (flip=1: w[ch][K-1-k], used for dgrad)
-template <typename T>
+// MODE 1 (forward, GLU fused in front): `in` is the pre-GLU tensor y [.][2C]; the tile is filled with y_a * sigmoid(y_gate)
+//         and the workgroup's own rows of that product are also written to gout (the weight gradient reads it later).
+// MODE 2 (dgrad, GLU backward fused behind): the result dg is not stored; out is dy [.][2C] with
+//         dy_a = dg * sigmoid(gate), dy_gate = dg * a * sigmoid(gate) * (1 - sigmoid(gate)), a/gate read from yglu.
+template <typename T, int MODE>
 __global__ void __launch_bounds__(256)
 dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
-              float* __restrict__ stat_partial, int B, int T_, int C, int K, int pad_left, int flip) {
+              float* __restrict__ stat_partial, int B, int T_, int C, int K, int pad_left, int flip,
+              const T* __restrict__ yglu, T* __restrict__ gout) {
   __shared__ __attribute__((aligned(16))) T tile[DW_ROWS][64];
   __shared__ float red[4][2][64];
   __shared__ float wsh[64 * DW_KMAX];     // this block's 64 x K taps: one coalesced load; a lane's K taps are then a stride-K
@@ -66,7 +71,21 @@ dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float
   const bool chok = ch < C;
   // stage [rows][64 channels] with 16-byte loads (8 bf16 / 4 f32 channels per lane) when the channel chunk is full
   constexpr int VE = 16 / sizeof(T), CPR = 64 / VE;
-  if (c0 + 64 <= C && (C % VE) == 0) {
+  if (MODE == 1) {
+    // GLU on the way in: 4 channels per thread (8/16-byte accesses of both halves of y); requires C % 4 == 0 (host check)
+    for (int q = threadIdx.x; q < DW_ROWS * 16; q += 256) {
+      int r = q >> 4, cc = (q & 15) * 4, t = t0 - pad_left + r;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool live = t >= 0 && t < T_ && r < DW_TT + K - 1 && c0 + cc < C;
+      if (live) {
+        const T* yr = in + ((size_t)b * T_ + t) * 2 * C + c0 + cc;
+        float4 a = load4(yr), gt = load4(yr + C);
+        o.x = a.x * sigmoidf_(gt.x); o.y = a.y * sigmoidf_(gt.y); o.z = a.z * sigmoidf_(gt.z); o.w = a.w * sigmoidf_(gt.w);
+        if (gout && r >= pad_left && r < pad_left + DW_TT) store4(gout + ((size_t)b * T_ + t) * C + c0 + cc, o);
+      }
+      store4(&tile[r][cc], o);
+    }
+  } else if (c0 + 64 <= C && (C % VE) == 0) {
     for (int q = threadIdx.x; q < DW_ROWS * CPR; q += 256) {
       int r = q / CPR, cc = (q % CPR) * VE, t = t0 - pad_left + r;
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -97,7 +116,15 @@ dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float
     for (int k = 0; k < DW_KMAX; ++k) acc = fmaf(wr[k], x[o + k], acc);
     int t = t0 + wave * 8 + o;
     if (chok && t < T_) {
-      out[((size_t)b * T_ + t) * C + ch] = from_f<T>(acc);
+      if (MODE == 2) {
+        const T* yr = yglu + ((size_t)b * T_ + t) * 2 * C + ch;
+        const float a = to_f(yr[0]), sg = sigmoidf_(to_f(yr[C]));
+        T* dr = out + ((size_t)b * T_ + t) * 2 * C + ch;
+        dr[0] = from_f<T>(acc * sg);
+        dr[C] = from_f<T>(acc * a * sg * (1.f - sg));
+      } else {
+        out[((size_t)b * T_ + t) * C + ch] = from_f<T>(acc);
+      }
       s1 += acc; s2 = fmaf(acc, acc, s2);
     }
   }
@@ -118,8 +145,18 @@ extern "C" int lidk_dwconv_fwd(const void* g, const float* w, const float* bias,
                                int T_, int C, int K, int pad_left, int dtype, void* stream) {
   if (!g || !w || !c || B <= 0 || T_ <= 0 || C <= 0 || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K) return LIDK_ERR_ARG;
   dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
-  LIDK_DISPATCH(dtype, dwconv_kernel<T><<<grid, 256, 0, as_stream(stream)>>>((const T*)g, w, bias, (T*)c, stat_partial, B,
-                                                                            T_, C, K, pad_left, 0));
+  LIDK_DISPATCH(dtype, (dwconv_kernel<T, 0><<<grid, 256, 0, as_stream(stream)>>>((const T*)g, w, bias, (T*)c, stat_partial, B,
+                                                                                T_, C, K, pad_left, 0, nullptr, nullptr)));
+  return launch_status();
+}
+
+extern "C" int lidk_glu_dwconv_fwd(const void* y, const float* w, const float* bias, void* g, void* c, float* stat_partial,
+                                   int B, int T_, int C, int K, int pad_left, int dtype, void* stream) {
+  if (!y || !w || !c || B <= 0 || T_ <= 0 || C <= 0 || (C & 3) || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K)
+    return LIDK_ERR_ARG;
+  dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
+  LIDK_DISPATCH(dtype, (dwconv_kernel<T, 1><<<grid, 256, 0, as_stream(stream)>>>((const T*)y, w, bias, (T*)c, stat_partial, B,
+                                                                                T_, C, K, pad_left, 0, nullptr, (T*)g)));
   return launch_status();
 }
 
@@ -127,8 +164,17 @@ extern "C" int lidk_dwconv_bwd_input(const void* dc, const float* w, void* dg, i
                                      int dtype, void* stream) {
   if (!dc || !w || !dg || B <= 0 || T_ <= 0 || C <= 0 || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K) return LIDK_ERR_ARG;
   dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
-  LIDK_DISPATCH(dtype, dwconv_kernel<T><<<grid, 256, 0, as_stream(stream)>>>((const T*)dc, w, nullptr, (T*)dg, nullptr, B,
-                                                                            T_, C, K, K - 1 - pad_left, 1));
+  LIDK_DISPATCH(dtype, (dwconv_kernel<T, 0><<<grid, 256, 0, as_stream(stream)>>>((const T*)dc, w, nullptr, (T*)dg, nullptr, B,
+                                                                                T_, C, K, K - 1 - pad_left, 1, nullptr, nullptr)));
+  return launch_status();
+}
+
+extern "C" int lidk_dwconv_bwd_input_glu(const void* dc, const float* w, const void* y, void* dy, int B, int T_, int C, int K,
+                                         int pad_left, int dtype, void* stream) {
+  if (!dc || !w || !y || !dy || B <= 0 || T_ <= 0 || C <= 0 || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K) return LIDK_ERR_ARG;
+  dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
+  LIDK_DISPATCH(dtype, (dwconv_kernel<T, 2><<<grid, 256, 0, as_stream(stream)>>>((const T*)dc, w, nullptr, (T*)dy, nullptr, B,
+                                                                                T_, C, K, K - 1 - pad_left, 1, (const T*)y, nullptr)));
   return launch_status();
 }
 

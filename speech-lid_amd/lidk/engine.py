@@ -174,7 +174,6 @@ class _Work:
             S.lnp = [f(L.LN_BWD_BLOCKS * 2 * d) for _ in range(5)]   # LayerNorm dgamma/dbeta partial rows: post, ff2, conv, attn, ff1
             self.sets.append(S)
         self.dmid = e(M, max(ci, cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head, d))   # ds / do
-        self.dmid3 = e(M, ci)
         self.dh = e(M, d)
         self.dyT = self.sets[0].dyTs[0]                       # the head block (first in backward) uses set 0
         self.dxa, self.dxb = f(M, d), f(M, d)
@@ -402,14 +401,13 @@ class Engine:
             self.k.gemm_nt(bb.o, A["wo"][0], bb.x2, bias=A["bo"], res=bb.x1)
             self.k.layernorm_fwd(bb.x2, C["ln_w"], C["ln_b"], yT=bb.h3, mean=bb.mean[2], rstd=bb.rstd[2])
             self.k.gemm_nt(bb.h3, C["w1"][0], bb.y, bias=C["b1"])
-            self.k.glu_fwd(bb.y, bb.g)
             dw2d = C["dw"].view(ci, K)
             pad_left = K // 2
-            if training:
-                self.k.dwconv_fwd(bb.g, dw2d, C["dwb"], bb.c, w.stat_partial, B, T, pad_left)
+            if training:                   # GLU fused into the depthwise conv's tile load; g is kept for the weight gradient
+                self.k.glu_dwconv_fwd(bb.y, dw2d, C["dwb"], bb.g, bb.c, w.stat_partial, B, T, pad_left)
                 self.k.reduce_partials_f64(w.stat_partial, w.stat_parts, 2 * ci, w.sums[:2 * ci])
             else:
-                self.k.dwconv_fwd(bb.g, dw2d, C["dwb"], bb.c, None, B, T, pad_left)
+                self.k.glu_dwconv_fwd(bb.y, dw2d, C["dwb"], None, bb.c, None, B, T, pad_left)
         if part in ("all", "b"):
             if training:
                 self.k.bn_train_stats(w.sums[:2 * ci], M * self.world_size, bb.bn_mean, bb.bn_rstd, C["rm"], C["rv"], C["nbt"])
@@ -581,10 +579,8 @@ class Engine:
                                       w.sums_local[:2 * ci], M * self.world_size, dc, C["dbn_w"], C["dbn_b"])
             if wg:
                 self.k.dwconv_bwd_weight(dc, bb.g, C["ddw"].view(ci, K), C["ddwb"], w.dw_partial, B, T, pad_left)
-            dg = w.dmid3
-            self.k.dwconv_bwd_input(dc, C["dw"].view(ci, K), dg, B, T, pad_left)
             dy1 = S.dy1.view(-1)[:M * 2 * ci].view(M, 2 * ci)
-            self.k.glu_bwd(bb.y, dg, dy1)
+            self.k.dwconv_bwd_input_glu(dc, C["dw"].view(ci, K), bb.y, dy1, B, T, pad_left)     # conv dgrad + GLU backward
             if wg:
                 self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
             self.k.gemm_nt(dy1, C["w1"][1], w.dh, N=d, K=2 * ci)

@@ -249,6 +249,20 @@ def dwconv_bwd_input(dc, w, dg, B, T, pad_left):
     check(lib().lidk_dwconv_bwd_input(_p(dc), _p(w), _p(dg), B, T, Cc, K, pad_left, _code(dc), _stream()), "dwconv_bwd_input")
 
 
+def glu_dwconv_fwd(y, w, bias, g, c, stat_partial, B, T, pad_left):
+    """GLU + depthwise conv in one launch: y [M, 2C] -> c [M, C]; g [M, C] (optional) keeps the GLU output for the wgrad."""
+    Cc, K = w.shape
+    check(lib().lidk_glu_dwconv_fwd(_p(y), _p(w), _p(bias), _p(g), _p(c), _p(stat_partial), B, T, Cc, K, pad_left, _code(y),
+                                    _stream()), "glu_dwconv_fwd")
+
+
+def dwconv_bwd_input_glu(dc, w, y, dy, B, T, pad_left):
+    """Depthwise-conv input gradient + GLU backward in one launch: dc [M, C], y [M, 2C] -> dy [M, 2C]."""
+    Cc, K = w.shape
+    check(lib().lidk_dwconv_bwd_input_glu(_p(dc), _p(w), _p(y), _p(dy), B, T, Cc, K, pad_left, _code(dc), _stream()),
+          "dwconv_bwd_input_glu")
+
+
 def dwconv_bwd_weight(dc, g, dw, db, partial, B, T, pad_left):
     Cc, K = dw.shape
     check(lib().lidk_dwconv_bwd_weight(_p(dc), _p(g), _p(dw), _p(db), _p(partial), B, T, Cc, K, pad_left, _code(dc),

@@ -215,6 +215,18 @@ def dwconv_bwd_input(dc, w, dg, B, T, pad_left):
     dg.view(B * T, -1).copy_(x.grad.to(dg.dtype))
 
 
+def glu_dwconv_fwd(y, w, bias, g, c, stat_partial, B, T, pad_left):
+    gg = g if g is not None else torch.empty(y.shape[0], y.shape[1] // 2, dtype=y.dtype)
+    glu_fwd(y, gg)
+    dwconv_fwd(gg, w, bias, c, stat_partial, B, T, pad_left)
+
+
+def dwconv_bwd_input_glu(dc, w, y, dy, B, T, pad_left):
+    dg = torch.empty(y.shape[0], y.shape[1] // 2, dtype=torch.float32)
+    dwconv_bwd_input(dc, w, dg, B, T, pad_left)
+    glu_bwd(y, dg, dy)
+
+
 @torch.enable_grad()
 def dwconv_bwd_weight(dc, g, dw, db, partial, B, T, pad_left):
     w = torch.zeros_like(dw).requires_grad_()

@@ -351,6 +351,39 @@ def test_dwconv_fwd_bwd_and_stats(dt, B, T, C, K):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,T,C,K", [(3, 70, 128, 31), (2, 151, 256, 31), (2, 40, 68, 7)])
+def test_glu_dwconv_fused_matches_separate_kernels(dt, B, T, C, K):
+    """GLU fused in front of the depthwise conv (forward) and behind its input gradient (backward) against the two-kernel
+    sequences: the forward tile holds the same T-rounded GLU output, so c, g and the BatchNorm sums are bit-identical; the
+    backward skips the T rounding of dg, so it is compared with the tolerance of one bf16 rounding."""
+    M, pad = B * T, K // 2
+    y = torch.randn(M, 2 * C, generator=g(130))
+    w = 0.3 * torch.randn(C, K, generator=g(131))
+    b = 0.1 * torch.randn(C, generator=g(132))
+    dc = torch.randn(M, C, generator=g(133))
+    yd, wd, bd, dcd = dev(y, dt), dev(w), dev(b), dev(dc, dt)
+    nparts = ops.dwconv_stat_parts(B, T)
+    g_sep, c_sep = torch.empty(M, C, device=DEV, dtype=dt), torch.empty(M, C, device=DEV, dtype=dt)
+    st_sep = torch.empty(nparts, 2, C, device=DEV)
+    ops.glu_fwd(yd, g_sep)
+    ops.dwconv_fwd(g_sep, wd, bd, c_sep, st_sep, B, T, pad)
+    g_fus, c_fus = torch.full((M, C), 3.0, device=DEV, dtype=dt), torch.full((M, C), 3.0, device=DEV, dtype=dt)
+    st_fus = torch.empty(nparts, 2, C, device=DEV)
+    ops.glu_dwconv_fwd(yd, wd, bd, g_fus, c_fus, st_fus, B, T, pad)
+    assert torch.equal(g_fus, g_sep) and torch.equal(c_fus, c_sep) and torch.equal(st_fus, st_sep)
+    c_nog = torch.full((M, C), 3.0, device=DEV, dtype=dt)
+    ops.glu_dwconv_fwd(yd, wd, bd, None, c_nog, None, B, T, pad)           # evaluation form: no g, no statistics
+    assert torch.equal(c_nog, c_sep)
+    dg = torch.empty(M, C, device=DEV, dtype=torch.float32)
+    ops.dwconv_bwd_input(dev(dc, torch.float32) if dt == torch.float32 else dcd.float(), wd, dg, B, T, pad)
+    dy_ref = torch.empty(M, 2 * C, device=DEV, dtype=torch.float32)
+    ops.glu_bwd(yd.float(), dg, dy_ref)
+    dy = torch.full((M, 2 * C), 3.0, device=DEV, dtype=dt)
+    ops.dwconv_bwd_input_glu(dcd, wd, yd, dy, B, T, pad)
+    check("glu_dwconv_bwd", dy, dy_ref, tol(dt, 2e-5, 3e-2))
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_batchnorm_swish_train_and_eval(dt):
     M, C = 408, 128
     c = 1.5 * torch.randn(M, C, generator=g(36)) + 0.3
