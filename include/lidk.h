@@ -148,6 +148,11 @@ int lidk_dwconv_bwd_input(const void* dc, const float* w, void* dg, int B, int T
 /* Input gradient with the GLU backward fused behind it: dy [B*T][2C] = (dg*sigmoid(gate) | dg*a*sigmoid'(gate)), a/gate from y. */
 int lidk_dwconv_bwd_input_glu(const void* dc, const float* w, const void* y, void* dy, int B, int T, int C, int K, int pad_left,
                               int dtype, void* stream);
+/* The same with the BatchNorm+Swish backward "apply" step (lidk_bn_swish_bwd_apply) in front: the gradient dc at the conv
+ * output is formed from ds, c and the (all-rank) sums while the tile is loaded and never stored.  C % 4 == 0. */
+int lidk_dwconv_bwd_input_bn_glu(const void* ds, const void* c, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, const double* sums, double count, const float* w, const void* y, void* dy,
+                                 int B, int T, int C, int K, int pad_left, int dtype, void* stream);
 int lidk_dwconv_bwd_weight(const void* dc, const void* g, float* dw, float* db, float* partial, int B, int T, int C,
                            int K, int pad_left, int dtype, void* stream);
 /* BatchNorm1d training statistics (lid/conformer.py:197): sums [2][C] f64 = (sum x, sum x^2) over `count` rows (already

@@ -46,17 +46,24 @@ extern "C" int lidk_glu_bwd(const void* y, const void* dg, void* dy, int M, int 
   return launch_status();
 }
 
+__device__ __forceinline__ float swish_grad(float z) { float s = sigmoidf_(z); return s * (1.f + z * (1.f - s)); }
+
+// BatchNorm(+Swish) backward "apply" step as a prologue of the depthwise-conv input gradient (MODE 3)
+struct BnBwd { const void* c; const float *mean, *rstd, *gamma, *beta; const double* sums; double count; };
+
 // ------------------------------------------------------------------------------------ depthwise conv (fwd and dgrad)
 // out[b][t][ch] = bias[ch] + sum_k w[ch][k] * in[b][t + k - pad_left][ch]   (flip=1: w[ch][K-1-k], used for dgrad)
 // MODE 1 (forward, GLU fused in front): `in` is the pre-GLU tensor y [.][2C]; the tile is filled with y_a * sigmoid(y_gate)
 //         and the workgroup's own rows of that product are also written to gout (the weight gradient reads it later).
 // MODE 2 (dgrad, GLU backward fused behind): the result dg is not stored; out is dy [.][2C] with
 //         dy_a = dg * sigmoid(gate), dy_gate = dg * a * sigmoid(gate) * (1 - sigmoid(gate)), a/gate read from yglu.
+// MODE 3 = MODE 2 with the BatchNorm+Swish backward in front: `in` is ds (gradient at the Swish output) and the tile is
+//         filled with dc = gamma*rstd*(dz - sums0/count - xhat*sums1/count), dz = ds*swish'(z), computed from ds and bn.c.
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256)
 dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
               float* __restrict__ stat_partial, int B, int T_, int C, int K, int pad_left, int flip,
-              const T* __restrict__ yglu, T* __restrict__ gout) {
+              const T* __restrict__ yglu, T* __restrict__ gout, BnBwd bn) {
   __shared__ __attribute__((aligned(16))) T tile[DW_ROWS][64];
   __shared__ float red[4][2][64];
   __shared__ float wsh[64 * DW_KMAX];     // this block's 64 x K taps: one coalesced load; a lane's K taps are then a stride-K
@@ -82,6 +89,35 @@ dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float
         float4 a = load4(yr), gt = load4(yr + C);
         o.x = a.x * sigmoidf_(gt.x); o.y = a.y * sigmoidf_(gt.y); o.z = a.z * sigmoidf_(gt.z); o.w = a.w * sigmoidf_(gt.w);
         if (gout && r >= pad_left && r < pad_left + DW_TT) store4(gout + ((size_t)b * T_ + t) * C + c0 + cc, o);
+      }
+      store4(&tile[r][cc], o);
+    }
+  } else if (MODE == 3) {
+    // 4 channels per thread; a thread keeps the same channels for all its rows (256 % 16 == 0), so the per-channel
+    // constants are loaded once
+    const int cc = (threadIdx.x & 15) * 4;
+    const bool cok = c0 + cc < C;
+    float4 mu = make_float4(0, 0, 0, 0), rs = mu, gm = mu, bt = mu, m0 = mu, m1 = mu;
+    if (cok) {
+      const int cg = c0 + cc;
+      mu = load4(bn.mean + cg); rs = load4(bn.rstd + cg); gm = load4(bn.gamma + cg); bt = load4(bn.beta + cg);
+      m0 = make_float4((float)(bn.sums[cg] / bn.count), (float)(bn.sums[cg + 1] / bn.count), (float)(bn.sums[cg + 2] / bn.count),
+                       (float)(bn.sums[cg + 3] / bn.count));
+      m1 = make_float4((float)(bn.sums[C + cg] / bn.count), (float)(bn.sums[C + cg + 1] / bn.count),
+                       (float)(bn.sums[C + cg + 2] / bn.count), (float)(bn.sums[C + cg + 3] / bn.count));
+    }
+    const T* cbuf = (const T*)bn.c;
+    for (int q = threadIdx.x; q < DW_ROWS * 16; q += 256) {
+      int r = q >> 4, t = t0 - pad_left + r;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cok && t >= 0 && t < T_ && r < DW_TT + K - 1) {
+        const size_t e = ((size_t)b * T_ + t) * C + c0 + cc;
+        float4 x = load4(cbuf + e), d = load4(in + e);
+        float xh, dz;
+        xh = (x.x - mu.x) * rs.x; dz = d.x * swish_grad(xh * gm.x + bt.x); o.x = gm.x * rs.x * (dz - m0.x - xh * m1.x);
+        xh = (x.y - mu.y) * rs.y; dz = d.y * swish_grad(xh * gm.y + bt.y); o.y = gm.y * rs.y * (dz - m0.y - xh * m1.y);
+        xh = (x.z - mu.z) * rs.z; dz = d.z * swish_grad(xh * gm.z + bt.z); o.z = gm.z * rs.z * (dz - m0.z - xh * m1.z);
+        xh = (x.w - mu.w) * rs.w; dz = d.w * swish_grad(xh * gm.w + bt.w); o.w = gm.w * rs.w * (dz - m0.w - xh * m1.w);
       }
       store4(&tile[r][cc], o);
     }
@@ -116,7 +152,7 @@ dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float
     for (int k = 0; k < DW_KMAX; ++k) acc = fmaf(wr[k], x[o + k], acc);
     int t = t0 + wave * 8 + o;
     if (chok && t < T_) {
-      if (MODE == 2) {
+      if (MODE == 2 || MODE == 3) {
         const T* yr = yglu + ((size_t)b * T_ + t) * 2 * C + ch;
         const float a = to_f(yr[0]), sg = sigmoidf_(to_f(yr[C]));
         T* dr = out + ((size_t)b * T_ + t) * 2 * C + ch;
@@ -146,7 +182,7 @@ extern "C" int lidk_dwconv_fwd(const void* g, const float* w, const float* bias,
   if (!g || !w || !c || B <= 0 || T_ <= 0 || C <= 0 || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K) return LIDK_ERR_ARG;
   dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
   LIDK_DISPATCH(dtype, (dwconv_kernel<T, 0><<<grid, 256, 0, as_stream(stream)>>>((const T*)g, w, bias, (T*)c, stat_partial, B,
-                                                                                T_, C, K, pad_left, 0, nullptr, nullptr)));
+                                                                                T_, C, K, pad_left, 0, nullptr, nullptr, BnBwd{})));
   return launch_status();
 }
 
@@ -156,7 +192,7 @@ extern "C" int lidk_glu_dwconv_fwd(const void* y, const float* w, const float* b
     return LIDK_ERR_ARG;
   dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
   LIDK_DISPATCH(dtype, (dwconv_kernel<T, 1><<<grid, 256, 0, as_stream(stream)>>>((const T*)y, w, bias, (T*)c, stat_partial, B,
-                                                                                T_, C, K, pad_left, 0, nullptr, (T*)g)));
+                                                                                T_, C, K, pad_left, 0, nullptr, (T*)g, BnBwd{})));
   return launch_status();
 }
 
@@ -165,7 +201,7 @@ extern "C" int lidk_dwconv_bwd_input(const void* dc, const float* w, void* dg, i
   if (!dc || !w || !dg || B <= 0 || T_ <= 0 || C <= 0 || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K) return LIDK_ERR_ARG;
   dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
   LIDK_DISPATCH(dtype, (dwconv_kernel<T, 0><<<grid, 256, 0, as_stream(stream)>>>((const T*)dc, w, nullptr, (T*)dg, nullptr, B,
-                                                                                T_, C, K, K - 1 - pad_left, 1, nullptr, nullptr)));
+                                                                                T_, C, K, K - 1 - pad_left, 1, nullptr, nullptr, BnBwd{})));
   return launch_status();
 }
 
@@ -174,7 +210,21 @@ extern "C" int lidk_dwconv_bwd_input_glu(const void* dc, const float* w, const v
   if (!dc || !w || !y || !dy || B <= 0 || T_ <= 0 || C <= 0 || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K) return LIDK_ERR_ARG;
   dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
   LIDK_DISPATCH(dtype, (dwconv_kernel<T, 2><<<grid, 256, 0, as_stream(stream)>>>((const T*)dc, w, nullptr, (T*)dy, nullptr, B,
-                                                                                T_, C, K, K - 1 - pad_left, 1, (const T*)y, nullptr)));
+                                                                                T_, C, K, K - 1 - pad_left, 1, (const T*)y, nullptr, BnBwd{})));
+  return launch_status();
+}
+
+extern "C" int lidk_dwconv_bwd_input_bn_glu(const void* ds, const void* c, const float* mean, const float* rstd,
+                                            const float* gamma, const float* beta, const double* sums, double count,
+                                            const float* w, const void* y, void* dy, int B, int T_, int C, int K, int pad_left,
+                                            int dtype, void* stream) {
+  if (!ds || !c || !mean || !rstd || !gamma || !beta || !sums || count <= 0 || !w || !y || !dy || B <= 0 || T_ <= 0 || C <= 0 ||
+      (C & 3) || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K)
+    return LIDK_ERR_ARG;
+  dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
+  BnBwd bn{c, mean, rstd, gamma, beta, sums, count};
+  LIDK_DISPATCH(dtype, (dwconv_kernel<T, 3><<<grid, 256, 0, as_stream(stream)>>>((const T*)ds, w, nullptr, (T*)dy, nullptr, B,
+                                                                                T_, C, K, K - 1 - pad_left, 1, (const T*)y, nullptr, bn)));
   return launch_status();
 }
 
@@ -335,7 +385,6 @@ extern "C" int lidk_bn_swish_fwd(const void* c, const float* mean, const float* 
 }
 
 // ------------------------------------------------------------------------------------ BatchNorm + Swish backward
-__device__ __forceinline__ float swish_grad(float z) { float s = sigmoidf_(z); return s * (1.f + z * (1.f - s)); }
 
 // Column reduction over M rows of (dz, dz*xhat): a thread owns 4 consecutive channels (8/16-byte loads) and every
 // (256 / (C/4))-th row of its workgroup's row set; row-lanes are combined through LDS.  C % 4 == 0, C <= 1024.

@@ -59,6 +59,7 @@ SIGNATURES = {
     "lidk_glu_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "lidk_glu_dwconv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_dwconv_bwd_input_glu": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lidk_dwconv_bwd_input_bn_glu": (_I, [_P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_dwconv_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_dwconv_stat_parts": (_I, [_I, _I]),
     "lidk_dwconv_bwd_input": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -170,7 +170,10 @@ class _Work:
             S.dy1 = e(M, 2 * ci)                              # conv pointwise-1 output gradient
             S.dqkv = e(M, 3 * max(cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head))
             S.dyTs = [e(M, d) for _ in range(4)]              # T-typed dx at: block output (x0.5), x3, x2, x1
-            S.dc = e(M, ci)                                   # depthwise-conv output gradient
+            S.dc = e(M, ci)                                   # depthwise-conv output gradient (for its weight gradient)
+            S.ds = e(M, ci)                                   # gradient at the BatchNorm+Swish output
+            S.sums = torch.empty(2 * ci, device=dev, dtype=torch.float64)        # BN backward sums: all ranks / this rank
+            S.sums_local = torch.empty(2 * ci, device=dev, dtype=torch.float64)
             S.lnp = [f(L.LN_BWD_BLOCKS * 2 * d) for _ in range(5)]   # LayerNorm dgamma/dbeta partial rows: post, ff2, conv, attn, ff1
             self.sets.append(S)
         self.dmid = e(M, max(ci, cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head, d))   # ds / do
@@ -428,10 +431,11 @@ class Engine:
             collective()
             self.graphs.run(key + ("b",), lambda: fn("b"))
 
-    def _bn_collective(self, w: _Work, ci: int, training: bool = True):
+    def _bn_collective(self, w: _Work, ci: int, training: bool = True, sums=None):
         if self.stat_allreduce is None or not training:
             return None
-        return lambda: self.stat_allreduce(w.sums[:2 * ci])
+        t = (w.sums if sums is None else sums)[:2 * ci]
+        return lambda: self.stat_allreduce(t)
 
     def _enc_block_fwd(self, x, i, w: _Work, training: bool, part: str):
         bp, bb = self.enc_params[i], w.enc[i]
@@ -560,7 +564,7 @@ class Engine:
         C = bp.conv
         ci, K = C["dw"].shape[0], C["dw"].shape[2]
         pad_left = K // 2
-        ds = w.dmid.view(-1)[:M * ci].view(M, ci)
+        ds = S.ds.view(-1)[:M * ci].view(M, ci)
         dx3 = a
         t0, t1, t2, t3 = S.dyTs
         if part in ("all", "a"):
@@ -572,16 +576,15 @@ class Engine:
             self.k.gemm_nt(t1, C["w2"][1], ds, N=ci, K=d)
             self.k.bn_swish_bwd_reduce(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial)
             # sums is all-reduced in place by the SyncBN collective under DP; sums_local keeps this rank's share
-            self.k.reduce_partials_f64(w.partial, L.BN_PARTIAL_BLOCKS, 2 * ci, w.sums[:2 * ci], w.sums_local[:2 * ci])
+            self.k.reduce_partials_f64(w.partial, L.BN_PARTIAL_BLOCKS, 2 * ci, S.sums[:2 * ci], S.sums_local[:2 * ci])
         if part in ("all", "b"):
-            dc = S.dc.view(-1)[:M * ci].view(M, ci)
-            self.k.bn_swish_bwd_apply(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.sums[:2 * ci],
-                                      w.sums_local[:2 * ci], M * self.world_size, dc, C["dbn_w"], C["dbn_b"])
-            if wg:
-                self.k.dwconv_bwd_weight(dc, bb.g, C["ddw"].view(ci, K), C["ddwb"], w.dw_partial, B, T, pad_left)
+            # BatchNorm+Swish backward, depthwise-conv input gradient and GLU backward in one launch; the conv's weight
+            # gradient (which needs dc materialised) goes with the other weight gradients
             dy1 = S.dy1.view(-1)[:M * 2 * ci].view(M, 2 * ci)
-            self.k.dwconv_bwd_input_glu(dc, C["dw"].view(ci, K), bb.y, dy1, B, T, pad_left)     # conv dgrad + GLU backward
+            self.k.dwconv_bwd_input_bn_glu(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], S.sums[:2 * ci],
+                                           M * self.world_size, C["dw"].view(ci, K), bb.y, dy1, B, T, pad_left)
             if wg:
+                self._conv_wgrad(w, bp, bb, S)
                 self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
             self.k.gemm_nt(dy1, C["w1"][1], w.dh, N=d, K=2 * ci)
             self._ln_bwd(w, w.dh, bb.x2, bb.mean[2], bb.rstd[2], C, S.lnp[2], wg, dres=dx3, dx=b, dxT=t2, dxT_scale=1.0)
@@ -604,6 +607,18 @@ class Engine:
             self._ff_bwd(w, dx1, t3, x_in, bp.ff1, bb.h1, bb.a1, bb.u1, bb.mean[0], bb.rstd[0], dx_in_out, None, 1.0, S.da[1], wg,
                          S.lnp[4])
 
+    def _conv_wgrad(self, w: _Work, bp: _BlockParams, bb: _BlockBuf, S):
+        """BatchNorm parameter gradients and the depthwise-conv weight gradient: dc is materialised here (off the dgrad
+        chain, which forms it on the fly inside dwconv_bwd_input_bn_glu)."""
+        B, T, M = w.B, w.T, w.M
+        C = bp.conv
+        ci, K = C["dw"].shape[0], C["dw"].shape[2]
+        ds = S.ds.view(-1)[:M * ci].view(M, ci)
+        dc = S.dc.view(-1)[:M * ci].view(M, ci)
+        self.k.bn_swish_bwd_apply(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], S.sums[:2 * ci],
+                                  S.sums_local[:2 * ci], M * self.world_size, dc, C["dbn_w"], C["dbn_b"])
+        self.k.dwconv_bwd_weight(dc, bb.g, C["ddw"].view(ci, K), C["ddwb"], w.dw_partial, B, T, K // 2)
+
     def _block_wgrads(self, w: _Work, bp: _BlockParams, bb: _BlockBuf, S, post_norm: bool):
         """The ten weight-gradient launches of one block, reading the dY operands its dgrad chain left in scratch set S, and the
         LayerNorm dgamma/dbeta finalizers of its sites (post_norm: the block's own post_norm went through this path too)."""
@@ -623,8 +638,7 @@ class Engine:
             self._wgrad(w, dyT, u, P["dw2"], d, ff, P["db2"])
             self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
         self._wgrad(w, t1, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
-        dc = S.dc.view(-1)[:M * ci].view(M, ci)
-        self.k.dwconv_bwd_weight(dc, bb.g, C["ddw"].view(ci, K), C["ddwb"], w.dw_partial, B, T, K // 2)
+        self._conv_wgrad(w, bp, bb, S)
         dy1 = S.dy1.view(-1)[:M * 2 * ci].view(M, 2 * ci)
         self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
         self._wgrad(w, t2, bb.o, A["dwo"], d, inner, A["dbo"])
@@ -688,7 +702,7 @@ class Engine:
                     self._join()
 
             key = ("bb", id(w), kind, tag, x_in.data_ptr(), n & 1, prev[0] if prev else None)
-            self._run_split(key, fn, self._bn_collective(w, bpk.conv["dw"].shape[0]))
+            self._run_split(key, fn, self._bn_collective(w, bpk.conv["dw"].shape[0], sums=S.sums))
             if defer:
                 if prev is not None and self.on_stage_grads_ready:
                     self.on_stage_grads_ready(prev[4])

@@ -263,6 +263,14 @@ def dwconv_bwd_input_glu(dc, w, y, dy, B, T, pad_left):
           "dwconv_bwd_input_glu")
 
 
+def dwconv_bwd_input_bn_glu(ds, c, mean, rstd, gamma, beta, sums, count, w, y, dy, B, T, pad_left):
+    """BatchNorm+Swish backward (apply step) + depthwise-conv input gradient + GLU backward in one launch."""
+    Cc, K = w.shape
+    check(lib().lidk_dwconv_bwd_input_bn_glu(_p(ds), _p(c), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), float(count),
+                                             _p(w), _p(y), _p(dy), B, T, Cc, K, pad_left, _code(ds), _stream()),
+          "dwconv_bwd_input_bn_glu")
+
+
 def dwconv_bwd_weight(dc, g, dw, db, partial, B, T, pad_left):
     Cc, K = dw.shape
     check(lib().lidk_dwconv_bwd_weight(_p(dc), _p(g), _p(dw), _p(db), _p(partial), B, T, Cc, K, pad_left, _code(dc),

@@ -227,6 +227,14 @@ def dwconv_bwd_input_glu(dc, w, y, dy, B, T, pad_left):
     glu_bwd(y, dg, dy)
 
 
+def dwconv_bwd_input_bn_glu(ds, c, mean, rstd, gamma, beta, sums, count, w, y, dy, B, T, pad_left):
+    dz, xh = _dz(ds, c, mean, rstd, gamma, beta)
+    C = c.shape[1]
+    m0, m1 = (sums[:C] / count).float(), (sums[C:2 * C] / count).float()
+    dc = gamma * rstd * (dz - m0 - xh * m1)
+    dwconv_bwd_input_glu(dc, w, y, dy, B, T, pad_left)
+
+
 @torch.enable_grad()
 def dwconv_bwd_weight(dc, g, dw, db, partial, B, T, pad_left):
     w = torch.zeros_like(dw).requires_grad_()

@@ -381,6 +381,26 @@ def test_glu_dwconv_fused_matches_separate_kernels(dt, B, T, C, K):
     dy = torch.full((M, 2 * C), 3.0, device=DEV, dtype=dt)
     ops.dwconv_bwd_input_glu(dcd, wd, yd, dy, B, T, pad)
     check("glu_dwconv_bwd", dy, dy_ref, tol(dt, 2e-5, 3e-2))
+    # ... and with the BatchNorm+Swish backward in front (dc formed on the fly from ds, c and the batch sums)
+    cbuf = 1.5 * torch.randn(M, C, generator=g(134)) + 0.3
+    ds = torch.randn(M, C, generator=g(135))
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g(136)), 0.1 * torch.randn(C, generator=g(137))
+    cd, dsd, gd, btd = dev(cbuf, dt), dev(ds, dt), dev(gamma), dev(beta)
+    cr = rt(cbuf, dt).double()
+    mean, var = cr.mean(0), cr.var(0, unbiased=False)
+    md, rd = dev(mean.float()), dev((1.0 / torch.sqrt(var + 1e-5)).float())
+    partial = torch.empty(L.BN_PARTIAL_BLOCKS * 2 * C, device=DEV)
+    ops.bn_swish_bwd_reduce(dsd, cd, md, rd, gd, btd, partial)
+    sums = torch.empty(2 * C, device=DEV, dtype=torch.float64)
+    ops.reduce_partials_f64(partial, L.BN_PARTIAL_BLOCKS, 2 * C, sums)
+    dc32 = torch.empty(M, C, device=DEV, dtype=torch.float32)
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.bn_swish_bwd_apply(dsd.float(), cd.float(), md, rd, gd, btd, sums, sums, M, dc32, dgam, dbet)
+    ops.dwconv_bwd_input(dc32, wd, dg, B, T, pad)
+    ops.glu_bwd(yd.float(), dg, dy_ref)
+    dy.fill_(3.0)
+    ops.dwconv_bwd_input_bn_glu(dsd, cd, md, rd, gd, btd, sums, M, wd, yd, dy, B, T, pad)
+    check("bn_glu_dwconv_bwd", dy, dy_ref, tol(dt, 5e-5, 3e-2), tol(dt, 1e-5, 1e-2))
 
 
 @pytest.mark.parametrize("dt", DT)
