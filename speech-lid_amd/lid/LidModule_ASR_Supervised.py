@@ -159,11 +159,18 @@ class LidSuperviseModule(CCMLModule):
         feats = self.model.features(batch[0])
         n_frames = (feats.shape[1] * batch[2]).long().tolist()
         targets = batch[5].tolist()
-        for i, nf in enumerate(n_frames):                                  # per utterance at B=1, unpadded
-            s = self.lid_scores(feats[i:i + 1, :max(int(nf), 3)].contiguous())
-            prob = self.score_to_prob(s.squeeze(0).tolist())
-            self.eer.update([prob], [targets[i]])
-            self.cavg.update([prob], [targets[i]])
+        # Per utterance, unpadded, as the reference scores them.  Utterances with the same frame count go through
+        # the model together: in eval mode nothing couples the rows of a batch (BatchNorm uses running statistics, attention
+        # is per utterance), so the scores equal the B=1 scores while equal-length sets cost one forward instead of B.
+        groups: Dict[int, List[int]] = {}
+        for i, nf in enumerate(n_frames):
+            groups.setdefault(max(int(nf), 3), []).append(i)
+        for nf, idx in groups.items():
+            scores = self.lid_scores(feats[idx, :nf].contiguous()).tolist()
+            for row, i in zip(scores, idx):
+                prob = self.score_to_prob(row)
+                self.eer.update([prob], [targets[i]])
+                self.cavg.update([prob], [targets[i]])
         loss = float(out["loss"].detach())
         if not np.isnan(loss):
             self.avg_loss = 0.98 * self.avg_loss + 0.02 * loss

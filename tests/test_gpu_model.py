@@ -70,6 +70,20 @@ def test_eval_forward_and_lid_scores(cfg1_weights, cfg1_cfg, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_eval_rows_are_independent_of_the_batch(cfg1_weights, dt):
+    """Validation scores equal-length utterances together instead of one by one (LidSuperviseModule.val_loop): in eval mode the
+    logits of an utterance must not depend on what else is in the batch, bit for bit."""
+    g = load_npz("cfg1_eval.npz")
+    eng = make_engine(make_cfg(), cfg1_weights, dt)
+    mel = torch.from_numpy(g["mel"]).to(DEV)
+    full = {k: v.clone() for k, v in eng.forward(mel, None, training=False).items()}
+    for i in range(mel.shape[0]):
+        one = eng.forward(mel[i:i + 1].contiguous(), None, training=False)
+        for lang in "abc":
+            assert torch.equal(one[lang][0], full[lang][i]), (lang, i)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_train_step_A_loss_and_all_gradients(cfg1_weights, dt):
     g = load_npz("cfg1_trainA.npz")
     mel = torch.from_numpy(load_npz("cfg1_eval.npz")["mel"]).to(DEV)
