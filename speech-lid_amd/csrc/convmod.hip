@@ -66,7 +66,7 @@ dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float
               const T* __restrict__ yglu, T* __restrict__ gout, BnBwd bn) {
   __shared__ __attribute__((aligned(16))) T tile[DW_ROWS][64];
   __shared__ float red[4][2][64];
-  __shared__ float wsh[64 * DW_KMAX];     // this block's 64 x K taps: one coalesced load; a lane's K taps are then a stride-K
+  __shared__ __attribute__((aligned(16))) float wsh[64 * DW_KMAX];     // this block's 64 x K taps: one coalesced load; a lane's K taps are then a stride-K
                                           // LDS walk (K odd -> conflict free) instead of K global gathers of 64 cache lines each
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * 64, b = blockIdx.z;
@@ -145,23 +145,58 @@ dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float
 #pragma unroll
   for (int r = 0; r < 8 + DW_KMAX - 1; ++r) x[r] = to_f(tile[wave * 8 + r][lane]);
   float s1 = 0.f, s2 = 0.f;
+  float res[8];
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
     float acc = bv;
 #pragma unroll
     for (int k = 0; k < DW_KMAX; ++k) acc = fmaf(wr[k], x[o + k], acc);
-    int t = t0 + wave * 8 + o;
-    if (chok && t < T_) {
+    res[o] = acc;
+    if (chok && t0 + wave * 8 + o < T_) { s1 += acc; s2 = fmaf(acc, acc, s2); }
+  }
+  if ((C & 3) == 0) {
+    // results -> LDS (the input tile is dead) -> epilogue with 4 channels per thread: 8/16-byte loads of y and stores,
+    // instead of one 2-byte access per lane and row
+    __syncthreads();
+    float (*ot)[64] = reinterpret_cast<float (*)[64]>(&wsh[0]);     // 32 x 64 f32 = the taps' 8 KB, no longer needed
+#pragma unroll
+    for (int o = 0; o < 8; ++o) ot[wave * 8 + o][lane] = res[o];
+    __syncthreads();
+    for (int q = threadIdx.x; q < DW_TT * 16; q += 256) {
+      const int r = q >> 4, cc = (q & 15) * 4, t = t0 + r;
+      if (t >= T_ || c0 + cc >= C) continue;
+      const float4 v = *reinterpret_cast<const float4*>(&ot[r][cc]);
       if (MODE == 2 || MODE == 3) {
-        const T* yr = yglu + ((size_t)b * T_ + t) * 2 * C + ch;
-        const float a = to_f(yr[0]), sg = sigmoidf_(to_f(yr[C]));
-        T* dr = out + ((size_t)b * T_ + t) * 2 * C + ch;
-        dr[0] = from_f<T>(acc * sg);
-        dr[C] = from_f<T>(acc * a * sg * (1.f - sg));
+        const T* yr = yglu + ((size_t)b * T_ + t) * 2 * C + c0 + cc;
+        const float4 a = load4(yr), gt = load4(yr + C);
+        float4 da, dgt;
+        float sg;
+        sg = sigmoidf_(gt.x); da.x = v.x * sg; dgt.x = v.x * a.x * sg * (1.f - sg);
+        sg = sigmoidf_(gt.y); da.y = v.y * sg; dgt.y = v.y * a.y * sg * (1.f - sg);
+        sg = sigmoidf_(gt.z); da.z = v.z * sg; dgt.z = v.z * a.z * sg * (1.f - sg);
+        sg = sigmoidf_(gt.w); da.w = v.w * sg; dgt.w = v.w * a.w * sg * (1.f - sg);
+        T* dr = out + ((size_t)b * T_ + t) * 2 * C + c0 + cc;
+        store4(dr, da);
+        store4(dr + C, dgt);
       } else {
-        out[((size_t)b * T_ + t) * C + ch] = from_f<T>(acc);
+        store4(out + ((size_t)b * T_ + t) * C + c0 + cc, v);
       }
-      s1 += acc; s2 = fmaf(acc, acc, s2);
+    }
+  } else {
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      int t = t0 + wave * 8 + o;
+      if (chok && t < T_) {
+        if (MODE == 2 || MODE == 3) {
+          const T* yr = yglu + ((size_t)b * T_ + t) * 2 * C + ch;
+          const float a = to_f(yr[0]), sg = sigmoidf_(to_f(yr[C]));
+          T* dr = out + ((size_t)b * T_ + t) * 2 * C + ch;
+          dr[0] = from_f<T>(res[o] * sg);
+          dr[C] = from_f<T>(res[o] * a * sg * (1.f - sg));
+        } else {
+          out[((size_t)b * T_ + t) * C + ch] = from_f<T>(res[o]);
+        }
+      }
     }
   }
   if (stat_partial) {
