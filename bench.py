@@ -246,8 +246,8 @@ def main():
     batches = resident_batches(ds, rank, world, device, args.batch)
     n_total = args.warmup + args.steps + 8
 
-    def step_fn(i, batch):
-        trainer.train_step(i, batch, n_total)
+    def step_fn(i, batch, upcoming=None):
+        trainer.train_step(i, batch, n_total, upcoming)
 
     def sync():
         if world > 1:
@@ -260,12 +260,14 @@ def main():
     if trainer.engine.graphs.enabled and not args.stochastic_depth:
         for i in range(3 * N_LANGS):
             step_fn(i, batches[i % N_LANGS])
+    # From here on every step also starts the NEXT batch's feature kernels (normalize, dither, STFT/mel) on the feature
+    # stream, as Trainer.fit does: each timed step still contains exactly one batch's worth of feature work.
     for i in range(args.warmup):
-        step_fn(i, batches[i % N_LANGS])
+        step_fn(i, batches[i % N_LANGS], batches[(i + 1) % N_LANGS])
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step_fn(args.warmup + i, batches[(args.warmup + i) % N_LANGS])
+        step_fn(args.warmup + i, batches[(args.warmup + i) % N_LANGS], batches[(args.warmup + i + 1) % N_LANGS])
     host_issue = time.perf_counter() - t0          # host time to enqueue the K steps (no device sync inside)
     sync()
     elapsed = time.perf_counter() - t0

@@ -33,6 +33,17 @@ from ccml.loggers.logger import Logger
 from ccml.utils.profile import _time_cost_recoder, register_cost_statistic
 
 
+def _lookahead(iterable):
+    """(item, next item or None) pairs: the trainer starts the next batch's feature kernels before it issues a step."""
+    it = iter(iterable)
+    missing = object()
+    cur = next(it, missing)
+    while cur is not missing:
+        nxt = next(it, missing)
+        yield cur, (None if nxt is missing else nxt)
+        cur = nxt
+
+
 class Trainer:
     def __init__(self, total_epoch: int = 0, world_size: int = 1, local_rank: int = -1, accumulate_grad: int = 1,
                  eval_interval: int = 1, train_data_factor: float = 1.0, ddp: bool = False, backend: str = "gloo",
@@ -56,6 +67,7 @@ class Trainer:
             self._init_process_group(backend, init_method, master_addr, str(master_port))
             self.local_rank, self.world_size = dist.get_rank(), dist.get_world_size()
 
+        self._feat_stream = None
         self.train_dataset = self.val_dataset = self.test_dataset = None
         self.train_dataloader = self.val_dataloader = self.test_dataloader = None
         self.train_sampler = self.val_sampler = self.test_sampler = None
@@ -261,8 +273,22 @@ class Trainer:
         else:
             self.lr_scheduler.step()
 
-    def train_step(self, i: int, batch, n_batches: int):
-        """One micro-batch: forward, backward, and (on a stepping micro-batch) clip + optimizer + schedule."""
+    def prefetch(self, batch):
+        """Move an upcoming batch to the device and start its GPU feature extraction on the feature stream, so it overlaps
+        the training step that is about to be issued (the batch keeps the result; its ``to_mel`` waits for it)."""
+        if batch is None or self.device.type != "cuda":
+            return
+        wb = batch[0] if isinstance(batch, (list, tuple)) and len(batch) else None
+        if hasattr(wb, "prefetch_mel"):
+            wb.to(self.device, non_blocking=True)
+            if self._feat_stream is None:
+                self._feat_stream = torch.cuda.Stream(device=self.device)
+            wb.prefetch_mel(self._feat_stream)
+
+    def train_step(self, i: int, batch, n_batches: int, next_batch=None):
+        """One micro-batch: forward, backward, and (on a stepping micro-batch) clip + optimizer + schedule.  ``next_batch``
+        (optional) is the batch after this one: its feature extraction is started first, on its own stream."""
+        self.prefetch(next_batch)
         acc = self.accumulate_grad
         stepping = (i % acc == acc - 1) or (i == n_batches - 1)
         self._sync_grads = stepping or not self.ddp
@@ -307,14 +333,14 @@ class Trainer:
             value = {"avg_accumulate_loss": 0.0, "moving_avg_loss": 0.0}
             self.exec_callbacks("before_train_epoch", {})
             self.before_train_loop({})
-            with tqdm(enumerate(self.train_dataloader), total=n, desc="train", disable=self.local_rank > 0) as tbar:
+            with tqdm(enumerate(_lookahead(self.train_dataloader)), total=n, desc="train", disable=self.local_rank > 0) as tbar:
                 self.tbar = tbar
                 last = time.time()
-                for i, batch in tbar:
+                for i, (batch, upcoming) in tbar:
                     if i > self.train_data_factor * n:
                         break
                     _time_cost_recoder.recoder("get_batch", time.time() - last)
-                    out, loss, stepped = self.train_step(i, batch, n)
+                    out, loss, stepped = self.train_step(i, batch, n, upcoming)
                     results.append(self.detach_dict(out))
                     run_sum += loss
                     acc_sum += loss

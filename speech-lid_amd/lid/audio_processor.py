@@ -116,8 +116,32 @@ class WaveBatch:
             self.spans = self.spans.pin_memory()
         return self
 
+    _mel = None
+    _mel_ready = None
+
+    def prefetch_mel(self, stream) -> None:
+        """Start the feature kernels for this batch on ``stream`` (the Trainer's feature stream) so that they run beside the
+        training step of the batch before it; ``to_mel`` then only waits for their completion event.  The reference gets the
+        same overlap from its DataLoader workers, which compute mel on the CPU while the GPU trains."""
+        if self._mel is not None or not self.wav.is_cuda:
+            return
+        stream.wait_stream(torch.cuda.current_stream())          # the H2D copy of wav and everything issued before
+        with torch.cuda.stream(stream):
+            self._mel = self._compute_mel()
+            self._mel_ready = torch.cuda.Event()
+            self._mel_ready.record(stream)
+
     def to_mel(self) -> torch.Tensor:
         """-> (B, F, n_mels) f32 dB on the GPU (the model input)."""
+        if self._mel is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self._mel_ready)
+            mel, self._mel, self._mel_ready = self._mel, None, None
+            mel.record_stream(cur)
+            return mel
+        return self._compute_mel()
+
+    def _compute_mel(self) -> torch.Tensor:
         if getattr(_ops, "IS_HIP_BACKEND", False) and not self.wav.is_cuda:
             raise LidkError("WaveBatch.to_mel: the feature path runs on the GPU only (no CPU fallback)")
         x = self.wav.contiguous()
