@@ -121,6 +121,12 @@ int lidk_attn_fwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, 
 int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, const void* probs, int ldp, const void* dout,
                   void* dqkv, float* drel_emb, float* dscores, int B, int T, int heads, int dh, int max_pos, int dtype,
                   void* stream);
+/* Split form: lidk_attn_bwd with drel_emb == NULL leaves the relative-position embedding gradient out (allowed when
+ * lidk_attn_bwd_relpos_supported: bf16, dh 32/64, T within the MFMA kernels' LDS budget) and lidk_attn_bwd_relpos adds it
+ * later from the dS rows that call stored in `dscores`:  drel_emb[clamp(r)+max_pos][:] += scale * sum_i dS[i][i-r] q[i][:]. */
+int lidk_attn_bwd_relpos_supported(int T, int dh, int dtype);
+int lidk_attn_bwd_relpos(const void* qkv, const float* dscores, int ldp, float* drel_emb, int B, int T, int heads, int dh,
+                         int max_pos, int dtype, void* stream);
 /* Row stride (elements) the probs buffer must have for (T, dh, dtype): T rounded up to 32 when the MFMA kernels apply
  * (bf16, dh in {32,64}, T <= 256), else T.  probs is [B][heads][T][ldp]; rel_emb_T is the T-typed copy of rel_emb
  * (required by the MFMA kernels, may be NULL otherwise). */

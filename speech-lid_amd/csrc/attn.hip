@@ -506,7 +506,9 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
   }
 }
 
-template <int DH, bool DUAL>     // DUAL: LDS holds both phases' operands at once
+// PART 0: dV, dK and dE; 1: dV and dK only (dE = the relative-position embedding's weight gradient is left to a later
+// PART-2 launch, which the engine runs on the weight-gradient stream); 2: dE only (stages dS and Q only).
+template <int DH, bool DUAL, int PART = 0>     // DUAL: LDS holds both phases' operands at once
 __global__ void __launch_bounds__(1024)
 attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ probs, const bf16* __restrict__ dout,
                           const bf16* __restrict__ dsT, bf16* __restrict__ dqkv, float* __restrict__ demb, AttGeom g, int ldp,
@@ -538,10 +540,10 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
     }
   };
   // ---- phase A: dv[j][d] = sum_i P[i][j] dO[i][d]
-  stage(X, Y, probs, dout + (size_t)b * T_ * g.inner + h * DH, g.inner);
-  if (DUAL) stage(X2, Y2, dsT, qkv + (size_t)b * T_ * g.ld + h * DH, g.ld);
+  if (PART != 2) stage(X, Y, probs, dout + (size_t)b * T_ * g.inner + h * DH, g.inner);
+  if (DUAL || PART == 2) stage(X2, Y2, dsT, qkv + (size_t)b * T_ * g.ld + h * DH, g.ld);
   __syncthreads();
-  for (int jt = wave; jt < NJ; jt += NW) {
+  for (int jt = wave; jt < (PART == 2 ? 0 : NJ); jt += NW) {
     f32x4 acc[DH / 16];
 #pragma unroll
     for (int nt = 0; nt < DH / 16; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -560,13 +562,13 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
       }
   }
   // ---- phase B: dk[j][d] = scale * sum_i dS[i][j] q[i][d] ; dE[r][d] += scale * sum_i dS[i][i-r] q[i][d]
-  if (!DUAL) {
+  if (!DUAL && PART != 2) {
     __syncthreads();
     stage(X2, Y2, dsT, qkv + (size_t)b * T_ * g.ld + h * DH, g.ld);
     __syncthreads();
   }
   const int n_rt = 2 * Tp / 16;                          // offset tiles covering r in [-Tp, Tp)
-  for (int item = wave; item < NJ + n_rt; item += NW) {
+  for (int item = (PART == 2 ? NJ : 0) + wave; item < (PART == 1 ? NJ : NJ + n_rt); item += NW) {
     f32x4 acc[DH / 16];
 #pragma unroll
     for (int nt = 0; nt < DH / 16; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -632,19 +634,37 @@ static void att_bwd_mfma_launch(const void* qkv, const void* embT, const void* p
   (void)hipFuncSetAttribute((const void*)attn_bwd_rows_mfma_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
   attn_bwd_rows_mfma_kernel<DH><<<g.B * g.H, 64 * nw, l1, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)probs,
                                                            (const bf16*)dout, (bf16*)dqkv, (bf16*)dsT, g, ldp, scale);
-  const int nwc = min(16, max(4, (g.T + 15) / 16 + 2 * ((g.T + 31) / 32 * 32) / 16) / 2);   // phase B has NJ + n_rt items: two rounds
+  const int Tp = (g.T + 31) / 32 * 32;
   const bool dual = att_bwd_cols_mfma_lds(g.T, DH, true) <= 160 * 1024;
-  if (dual) {
-    l2 = att_bwd_cols_mfma_lds(g.T, DH, true);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_cols_mfma_kernel<DH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-    attn_bwd_cols_mfma_kernel<DH, true><<<g.B * g.H, 64 * nwc, l2, s>>>((const bf16*)qkv, (const bf16*)probs, (const bf16*)dout,
-                                                                       (const bf16*)dsT, (bf16*)dqkv, demb, g, ldp, scale);
-  } else {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_cols_mfma_kernel<DH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-    attn_bwd_cols_mfma_kernel<DH, false><<<g.B * g.H, 64 * nwc, l2, s>>>((const bf16*)qkv, (const bf16*)probs, (const bf16*)dout,
-                                                                        (const bf16*)dsT, (bf16*)dqkv, demb, g, ldp, scale);
+  if (dual) l2 = att_bwd_cols_mfma_lds(g.T, DH, true);
+#define LIDK_COLS_LAUNCH(DUAL_, PART_, NW_)                                                                                    \
+  do {                                                                                                                         \
+    (void)hipFuncSetAttribute((const void*)attn_bwd_cols_mfma_kernel<DH, DUAL_, PART_>,                                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);                                            \
+    attn_bwd_cols_mfma_kernel<DH, DUAL_, PART_><<<g.B * g.H, 64 * (NW_), l2, s>>>(                                             \
+        (const bf16*)qkv, (const bf16*)probs, (const bf16*)dout, (const bf16*)dsT, (bf16*)dqkv, demb, g, ldp, scale);           \
+  } while (0)
+  if (demb) {                                        // NJ + n_rt items in phase B: two rounds of 16 waves
+    const int nwc = min(16, max(4, (Tp / 16 + 2 * Tp / 16) / 2));
+    if (dual) LIDK_COLS_LAUNCH(true, 0, nwc); else LIDK_COLS_LAUNCH(false, 0, nwc);
+  } else {                                           // NJ items per phase: one wave each
+    const int nwc = min(16, max(4, Tp / 16));
+    if (dual) LIDK_COLS_LAUNCH(true, 1, nwc); else LIDK_COLS_LAUNCH(false, 1, nwc);
   }
 }
+
+// dE only, from the dS a previous lidk_attn_bwd (with drel_emb == NULL) left in `dsT`
+template <int DH>
+static void att_bwd_relpos_launch(const void* qkv, const void* dsT, int ldp, float* demb, AttGeom g, hipStream_t s) {
+  const float scale = 1.0f / sqrtf((float)DH);
+  const int Tp = (g.T + 31) / 32 * 32;
+  size_t l2 = att_bwd_cols_mfma_lds(g.T, DH);
+  const void *probs = nullptr, *dout = nullptr;
+  void* dqkv = nullptr;
+  const int nwc = min(16, max(4, 2 * Tp / 16 / 2));
+  LIDK_COLS_LAUNCH(false, 2, nwc);
+}
+#undef LIDK_COLS_LAUNCH
 
 // ------------------------------------------------------------------------------------ host side
 template <typename T>
@@ -720,12 +740,28 @@ static int att_bwd_launch(const void* qkv, const float* rel_emb, const void* pro
   return launch_status();
 }
 
+extern "C" int lidk_attn_bwd_relpos_supported(int T_, int dh, int dtype) {
+  return dtype == LIDK_BF16 && (dh == 32 || dh == 64) && T_ <= 16 * AF_NJ_MAX && att_bwd_rows_mfma_lds(T_, dh) <= 160 * 1024 &&
+         att_bwd_cols_mfma_lds(T_, dh) <= 160 * 1024;
+}
+
+extern "C" int lidk_attn_bwd_relpos(const void* qkv, const float* dscores, int ldp, float* drel_emb, int B, int T_, int heads,
+                                    int dh, int max_pos, int dtype, void* stream) {
+  if (!qkv || !dscores || !drel_emb || B <= 0 || T_ <= 0 || heads <= 0 || ldp != (T_ + 31) / 32 * 32) return LIDK_ERR_ARG;
+  if (!lidk_attn_bwd_relpos_supported(T_, dh, dtype)) return LIDK_ERR_UNSUPPORTED;
+  AttGeom g{B, T_, heads, dh, max_pos, heads * dh, 3 * heads * dh};
+  if (dh == 64) att_bwd_relpos_launch<64>(qkv, dscores, ldp, drel_emb, g, as_stream(stream));
+  else att_bwd_relpos_launch<32>(qkv, dscores, ldp, drel_emb, g, as_stream(stream));
+  return launch_status();
+}
+
 extern "C" int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, const void* probs, int ldp,
                              const void* dout, void* dqkv, float* drel_emb, float* dscores, int B, int T_, int heads, int dh,
                              int max_pos, int dtype, void* stream) {
-  if (!qkv || !rel_emb || !probs || !dout || !dqkv || !drel_emb || !dscores || B <= 0 || T_ <= 0 || heads <= 0 || ldp < T_)
+  if (!qkv || !rel_emb || !probs || !dout || !dqkv || !dscores || B <= 0 || T_ <= 0 || heads <= 0 || ldp < T_)
     return LIDK_ERR_ARG;
   if (!att_dh_ok(dh)) return LIDK_ERR_UNSUPPORTED;
+  if (!drel_emb && !lidk_attn_bwd_relpos_supported(T_, dh, dtype)) return LIDK_ERR_ARG;      // split form: MFMA path only
   AttGeom g{B, T_, heads, dh, max_pos, heads * dh, 3 * heads * dh};
   hipStream_t s = as_stream(stream);
   if (dtype == LIDK_BF16 && rel_emb_T && (dh == 32 || dh == 64) && ldp == (T_ + 31) / 32 * 32 && T_ <= 16 * AF_NJ_MAX &&

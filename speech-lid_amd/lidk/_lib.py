@@ -52,6 +52,8 @@ SIGNATURES = {
     "lidk_gemm_nt": (_I, [C.POINTER(GemmArgs), _I, _P]),
     "lidk_gemm_tn": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _I, _I, _P]),
     "lidk_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "lidk_attn_bwd_relpos_supported": (_I, [_I, _I, _I]),
+    "lidk_attn_bwd_relpos": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_attn_bwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_attn_ldp": (_I, [_I, _I, _I]),
     "lidk_selftest_tr16": (_I, [_P, _P, _P]),

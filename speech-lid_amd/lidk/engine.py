@@ -174,6 +174,7 @@ class _Work:
             S.ds = e(M, ci)                                   # gradient at the BatchNorm+Swish output
             S.sums = torch.empty(2 * ci, device=dev, dtype=torch.float64)        # BN backward sums: all ranks / this rank
             S.sums_local = torch.empty(2 * ci, device=dev, dtype=torch.float64)
+            S.dsc = f(B, max(cfg.heads, cfg.last_heads), T, (T + 31) // 32 * 32)     # attention dS rows (kept for the deferred dE)
             S.lnp = [f(L.LN_BWD_BLOCKS * 2 * d) for _ in range(5)]   # LayerNorm dgamma/dbeta partial rows: post, ff2, conv, attn, ff1
             self.sets.append(S)
         self.dmid = e(M, max(ci, cfg.heads * cfg.dim_head, cfg.last_heads * cfg.last_dim_head, d))   # ds / do
@@ -181,7 +182,6 @@ class _Work:
         self.dyT = self.sets[0].dyTs[0]                       # the head block (first in backward) uses set 0
         self.dxa, self.dxb = f(M, d), f(M, d)
         hmax = max(cfg.heads, cfg.last_heads)
-        self.dsc = f(B, hmax, T, (T + 31) // 32 * 32)
         self.partial = f(max(L.LN_PARTIAL_BLOCKS * 2 * cmax, L.LN_BWD_BLOCKS * 2 * d, L.BN_PARTIAL_BLOCKS * 2 * ci))
         self.stat_parts = eng.k.dwconv_stat_parts(B, T)
         self.stat_partial = f(self.stat_parts * 2 * ci)
@@ -219,6 +219,7 @@ class Engine:
         self.world_size = 1
         self.seed = 0
         self.step_count = 0
+        self._split_ok: Dict[tuple, bool] = {}
         # Second HIP stream for the weight-gradient GEMMs (LIDK_SIDE_STREAM=0 turns it off): a block's wgrads are deferred and
         # run beside the next block's dgrad chain, one fork/join per captured block graph: 9.75 vs 10.01 ms/step.  (Forking
         # at every wgrad site cost more in graph edges than the overlap won: 13.0 vs 11.85 ms/step at the time.)
@@ -597,7 +598,11 @@ class Engine:
             do = w.dmid.view(-1)[:M * inner].view(M, inner)
             self.k.gemm_nt(t2, A["wo"][1], do, N=inner, K=d)
             dqkv = S.dqkv.view(-1)[:M * 3 * inner].view(M, 3 * inner)
-            self.k.attn_bwd(bb.qkv, A["emb"], bb.probs, do, dqkv, A["demb"], w.dsc, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
+            # deferred mode: the relative-position embedding's gradient (a weight gradient, a third of this step's work)
+            # is left to _block_wgrads, which computes it from the dS rows kept in the scratch set
+            split = (not wg) and self._relpos_split(T, bp.dh)
+            self.k.attn_bwd(bb.qkv, A["emb"], bb.probs, do, dqkv, None if split else A["demb"], S.dsc, B, T, bp.heads, bp.dh,
+                            rel_emb_T=A["embT"])
             if wg:
                 self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
             self.k.gemm_nt(dqkv, A["wqkv"][1], w.dh, N=d, K=3 * inner)
@@ -644,6 +649,15 @@ class Engine:
         self._wgrad(w, t2, bb.o, A["dwo"], d, inner, A["dbo"])
         dqkv = S.dqkv.view(-1)[:M * 3 * inner].view(M, 3 * inner)
         self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
+        if self._relpos_split(T, bp.dh):
+            self.k.attn_bwd_relpos(bb.qkv, S.dsc, bb.probs.shape[-1], A["demb"], B, T, bp.heads, bp.dh)
+
+    def _relpos_split(self, T: int, dh: int) -> bool:
+        key = (T, dh)
+        if key not in self._split_ok:
+            self._split_ok[key] = bool(self._hip and hasattr(self.k, "attn_bwd_relpos_supported")
+                                       and self.k.attn_bwd_relpos_supported(T, dh, self.act_dtype))
+        return self._split_ok[key]
 
     def backward(self, dlogits: torch.Tensor):
         """dlogits (B, T, V+1) f32 for the language of the last training forward.  Accumulates into ``grad``."""

@@ -219,6 +219,17 @@ def attn_bwd(qkv, rel_emb, probs, dout, dqkv, drel_emb, dscores, B, T, heads, dh
                               _p(drel_emb), _p(dscores), B, T, heads, dh, max_pos, _code(qkv), _stream()), "attn_bwd")
 
 
+def attn_bwd_relpos_supported(T, dh, dtype):
+    return bool(lib().lidk_attn_bwd_relpos_supported(T, dh, dtype_code(dtype)))
+
+
+def attn_bwd_relpos(qkv, dscores, ldp, drel_emb, B, T, heads, dh):
+    """Relative-position embedding gradient from the dS rows an ``attn_bwd(..., drel_emb=None, ...)`` call left in dscores."""
+    max_pos = (drel_emb.shape[0] - 1) // 2
+    check(lib().lidk_attn_bwd_relpos(_p(qkv), _p(dscores), ldp, _p(drel_emb), B, T, heads, dh, max_pos, _code(qkv), _stream()),
+          "attn_bwd_relpos")
+
+
 def selftest_tr16(inp, out):
     check(lib().lidk_selftest_tr16(_p(inp), _p(out), _stream()), "selftest_tr16")
 

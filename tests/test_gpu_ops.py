@@ -284,6 +284,14 @@ def test_attention_fwd_bwd(dt, B, T, H, dh, maxpos, path):
     gs = float(qkv_r.grad.abs().max())
     check(f"attn_dqkv[{path}]", dqkv, qkv_r.grad, tol(dt, 2e-5 * max(1, gs), 3e-2 * max(1, gs)))
     check(f"attn_demb[{path}]", demb, emb_r.grad, tol(dt, 1e-4, 6e-2) * max(1.0, float(emb_r.grad.abs().max())))
+    if path == "mfma" and ops.attn_bwd_relpos_supported(T, dh, dt):
+        # split form: dqkv now, the embedding gradient later from the stored dS rows (the engine defers it)
+        dqkv2 = torch.zeros_like(dqkv)
+        demb2 = torch.zeros_like(ed)
+        ops.attn_bwd(qd, ed, probs, dev(dout, dt), dqkv2, None, dsc, B, T, H, dh, rel_emb_T=embT)
+        assert float(demb2.abs().max()) == 0.0 and torch.equal(dqkv2, dqkv)
+        ops.attn_bwd_relpos(qd, dsc, probs.shape[-1], demb2, B, T, H, dh)
+        check("attn_demb_split", demb2, demb, 1e-4 * max(1.0, float(demb.abs().max())))      # float atomics: order only
 
 
 def test_tr16_hardware_mapping():
