@@ -198,3 +198,51 @@ def test_graph_replay_matches_eager(cfg1_weights):
     assert rel < 1e-5                            # split-K float atomics make the sum order run-dependent
     for k in b0:
         assert torch.allclose(b0[k].float(), b1[k].float(), atol=1e-6), k
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_baseline_cfg2_depth_against_the_oracle(dt):
+    """BASELINE config 2 architecture at full depth and width (12 blocks, d = 256, 4 x 64 heads, ff x4, conv expansion 2,
+    kernel 31, head block 8 x 32; 3 of the 14 languages and 1 s utterances to keep the CPU oracle quick): one training
+    forward/backward on the HIP engine against the torch-CPU oracle with the same random weights.  f32 mode checks the
+    algorithm end to end through 13 blocks; bf16 mode is the production setting (tolerances as in the module docstring)."""
+    torch.manual_seed(5)
+    l2v, l2i = {"a": 30, "b": 40, "c": 50}, {"a": 0, "b": 1, "c": 2}
+    dims = dict(n_blocks=12, encoder_dim=256, dim_head=64, heads=4, last_dim_head=32)
+    cfg = ConformerCfg(lang2vocab=l2v, lang2index=l2i, dropout=0.0, pos_dropout=0.0, hidden_dim=32, **dims)
+    eng = Engine(cfg, act_dtype=dt)
+    eng.to(DEV)
+    weights = {k: v.detach().cpu().clone() for k, v in eng.state().items()}
+    B, F_ = 4, 101
+    mel = 20.0 * torch.randn(B, F_, 80) - 30.0
+    texts = torch.randint(0, 40, (B, 8))
+    eng.zero_grad()
+    out = eng.forward(mel.to(DEV), "b", training=True, keep_layers=[True] * 12)["b"]
+    ocfg = oc.ModelCfg(lang2vocab=l2v, lang2index=l2i, dropout=0.0, pos_dropout=0.0, **dims)
+    names = [k for k, v in weights.items() if v.is_floating_point() and "running_" not in k]
+    ref = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in weights.items()}
+    logits, _ = oc.forward(mel, ref, ocfg, "b", oc.RunOpts(training=True, keep_layers=[True] * 12))
+    err = float((out.cpu() - logits["b"].detach()).abs().max())
+    scale = float(logits["b"].detach().abs().max())
+    print(f"[cfg2-depth logits {dt}] max_abs_err={err:.3e} ref_max={scale:.3e}")
+    assert err <= (1e-4 if dt == torch.float32 else 0.1) * max(1.0, scale)
+    loss_ref = oc.ctc_loss(logits["b"], texts, torch.ones(B), torch.ones(B), blank=40)
+    loss_ref.backward()
+    g = {"texts": texts.numpy(), "wav_pct": np.ones(B, np.float32), "text_pct": np.ones(B, np.float32)}
+    loss, dl = gpu_ctc(out, g)
+    print(f"[cfg2-depth loss {dt}] got={loss:.5f} ref={float(loss_ref):.5f}")
+    assert abs(loss - float(loss_ref)) <= (1e-5 if dt == torch.float32 else 5e-3) * abs(float(loss_ref))
+    eng.backward(dl)
+    torch.cuda.synchronize()
+    worst_cos, worst_rel = 1.0, 0.0
+    for k in names:
+        gr = ref[k].grad
+        if gr is None or float(gr.norm()) < 1e-5:
+            continue
+        got, want = eng.gview(k).cpu().reshape(-1).double(), gr.reshape(-1).double()
+        cos = float((got @ want) / (got.norm() * want.norm() + 1e-30))
+        rel = float((got - want).norm() / want.norm())
+        worst_cos, worst_rel = min(worst_cos, cos), max(worst_rel, rel)
+    print(f"[cfg2-depth grads {dt}] worst_cos={worst_cos:.6f} worst_rel_l2={worst_rel:.3e}")
+    assert worst_cos >= (0.999999 if dt == torch.float32 else 0.99)
+    assert worst_rel <= (5e-4 if dt == torch.float32 else 0.15)
