@@ -35,8 +35,10 @@ enum { LIDK_ACT_NONE = 0, LIDK_ACT_SWISH = 1, LIDK_ACT_RELU = 2, LIDK_ACT_SWISH_
 int lidk_version(void);
 
 /* ------------------------------------------------------------------ feature path (rows a1-a5) */
-/* lid/audio_processor.py:108-115 normalize_wav: (x-mean)/(std_unbiased+1e-6) per utterance. in/out [B][L]. */
-int lidk_normalize_wav(const float* wav, float* out, int B, int L, void* stream);
+/* lid/audio_processor.py:108-115 normalize_wav: (x-mean)/(std_unbiased+1e-6) per utterance. in/out [B][L].
+ * n_samples (may be NULL): true length of every utterance of a ragged, zero-padded batch; statistics then run over the
+ * utterance's own samples and the tail of the row is zeroed. */
+int lidk_normalize_wav(const float* wav, float* out, int B, int L, const int32_t* n_samples, void* stream);
 /* lid/audio_processor.py:128-134 wav_augment dither + pre-emphasis: x += dither*U[0,1); y[0]=x[0], y[t]=x[t]-coef*x[t-1].
  * noise: optional [B][L] U[0,1) draws (parity tests); NULL -> counter-based generator keyed by (seed, index). */
 int lidk_dither_preemph(const float* wav, float* out, const float* noise, int B, int L, float coef, float dither,
@@ -45,10 +47,13 @@ int lidk_dither_preemph(const float* wav, float* out, const float* noise, int B,
  * lid/audio_processor.py:225-227 spectrogram_augment masks and lid/raw_datasets.py:345-365 collate layout.
  * wav [B][L] -> out [B][F][n_mels] f32 dB, F = 1 + (L + 2*pad)/hop.  window [512] (hann(win) centred), twiddle [256][2]
  * (cos,sin of 2*pi*k/512), melfb [257][n_mels].  utt_max [B] scratch (per-utterance dB max, used for the top_db floor).
- * spans [B][mask_times][4] int32 = (t0,t1,f0,f1) filled with 0.0 dB, or NULL/mask_times=0 for none. */
+ * spans [B][mask_times][4] int32 = (t0,t1,f0,f1) filled with 0.0 dB, or NULL/mask_times=0 for none.
+ * n_samples (may be NULL): ragged batch - utterance b has n_samples[b] samples, hence F_b = 1 + (n_samples[b] + 2*pad)/hop
+ * frames computed as if it were alone (reflection at its own end, its own top_db maximum); rows F_b..F-1 are exactly 0.0,
+ * the zero padding the reference's collate gives the mel. */
 int lidk_logmel(const float* wav, const float* window, const float* twiddle, const float* melfb, float* out,
                 float* utt_max, int B, int L, int pad, int hop, int n_mels, const int32_t* spans, int mask_times,
-                float top_db, void* stream);
+                float top_db, const int32_t* n_samples, void* stream);
 
 /* ------------------------------------------------------------------ generic element-wise helpers */
 /* y = scale * x with dtype conversion (x_dtype/y_dtype in {LIDK_F32, LIDK_BF16}). */

@@ -7,11 +7,14 @@
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------ normalize_wav
-__global__ void __launch_bounds__(1024) normalize_wav_kernel(const float* __restrict__ wav, float* __restrict__ out, int L) {
+__global__ void __launch_bounds__(1024) normalize_wav_kernel(const float* __restrict__ wav, float* __restrict__ out, int Lrow,
+                                                             const int32_t* __restrict__ n_samples) {
   __shared__ float red[16];
   __shared__ float bc;
-  const float* x = wav + (size_t)blockIdx.x * L;
-  float* y = out + (size_t)blockIdx.x * L;
+  const float* x = wav + (size_t)blockIdx.x * Lrow;
+  float* y = out + (size_t)blockIdx.x * Lrow;
+  // ragged batch: statistics over the utterance's own samples, zeros behind them
+  const int L = n_samples ? max(2, min(Lrow, n_samples[blockIdx.x])) : Lrow;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float s = 0.f;
   for (int i = threadIdx.x; i < L; i += blockDim.x) s += x[i];
@@ -31,11 +34,12 @@ __global__ void __launch_bounds__(1024) normalize_wav_kernel(const float* __rest
   __syncthreads();
   const float inv = bc;
   for (int i = threadIdx.x; i < L; i += blockDim.x) y[i] = (x[i] - mu) * inv;
+  for (int i = L + threadIdx.x; i < Lrow; i += blockDim.x) y[i] = 0.f;
 }
 
-extern "C" int lidk_normalize_wav(const float* wav, float* out, int B, int L, void* stream) {
+extern "C" int lidk_normalize_wav(const float* wav, float* out, int B, int L, const int32_t* n_samples, void* stream) {
   if (!wav || !out || B <= 0 || L < 2) return LIDK_ERR_ARG;
-  normalize_wav_kernel<<<B, 1024, 0, as_stream(stream)>>>(wav, out, L);
+  normalize_wav_kernel<<<B, 1024, 0, as_stream(stream)>>>(wav, out, L, n_samples);
   return launch_status();
 }
 
@@ -92,7 +96,7 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
 __global__ void __launch_bounds__(64 * STFT_WAVES)
 stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ twiddle,
                 const float* __restrict__ melfb, float* __restrict__ out, float* __restrict__ utt_max, int B, int L,
-                int pad, int hop, int F, int n_mels, int dbg) {
+                int pad, int hop, int F, int n_mels, int dbg, const int32_t* __restrict__ n_samples) {
   __shared__ float s_re[STFT_WAVES][LIDK_N_FFT];
   __shared__ float s_im[STFT_WAVES][LIDK_N_FFT];
   __shared__ float s_tw[LIDK_N_FFT / 2][2];
@@ -130,7 +134,6 @@ stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window,
   __syncthreads();
   float* re = s_re[wave];
   float* im = s_im[wave];
-  const int Lp = L + 2 * pad;
   const long nframes = (long)B * F;
   const long per_wave = (nframes + (long)gridDim.x * STFT_WAVES - 1) / ((long)gridDim.x * STFT_WAVES);
   const long fr0 = ((long)blockIdx.x * STFT_WAVES + wave) * per_wave, fr1 = min(nframes, fr0 + per_wave);
@@ -143,6 +146,13 @@ stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window,
       run_b = b; run_max = -INFINITY;
     }
     const float* x = wav + (size_t)b * L;
+    // ragged batch: the utterance has Lb samples and Fb frames of its own; the rows behind them are the zero padding the
+    // reference's collate adds to the mel (lid/raw_datasets.py:345-365) and take no part in the utterance maximum
+    const int Lb = n_samples ? min(L, n_samples[b]) : L, Lp = Lb + 2 * pad;
+    if (f >= 1 + Lp / hop) {
+      for (int m = lane; m < n_mels; m += 64) out[((size_t)b * F + f) * n_mels + m] = 0.f;
+      continue;
+    }
     // windowed frame, bit-reversed placement
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -151,7 +161,7 @@ stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window,
       if (p < 0) p = -p;
       if (p >= Lp) p = 2 * (Lp - 1) - p;
       int s = p - pad;
-      float v = (s >= 0 && s < L) ? x[s] * s_win[n] : 0.f;
+      float v = (s >= 0 && s < Lb) ? x[s] * s_win[n] : 0.f;
       int r = (int)(__brev((unsigned)n) >> 23);
       re[r] = v; im[r] = 0.f;
     }
@@ -207,11 +217,13 @@ stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window,
 }
 
 __global__ void db_floor_mask_kernel(float* __restrict__ out, const float* __restrict__ utt_max, const int32_t* __restrict__ spans,
-                                     int mask_times, int F, int n_mels, long n, float top_db) {
+                                     int mask_times, int F, int n_mels, long n, float top_db,
+                                     const int32_t* __restrict__ n_samples, int L, int pad, int hop) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     int m = (int)(i % n_mels);
     long bf = i / n_mels;
     int f = (int)(bf % F), b = (int)(bf / F);
+    if (n_samples && f >= 1 + (min(L, n_samples[b]) + 2 * pad) / hop) continue;       // zero padding rows stay zero
     float v = fmaxf(out[i], utt_max[b] - top_db);
     for (int r = 0; r < mask_times; ++r) {
       const int32_t* sp = spans + ((size_t)b * mask_times + r) * 4;
@@ -223,7 +235,7 @@ __global__ void db_floor_mask_kernel(float* __restrict__ out, const float* __res
 
 extern "C" int lidk_logmel(const float* wav, const float* window, const float* twiddle, const float* melfb, float* out,
                            float* utt_max, int B, int L, int pad, int hop, int n_mels, const int32_t* spans, int mask_times,
-                           float top_db, void* stream) {
+                           float top_db, const int32_t* n_samples, void* stream) {
   if (!wav || !window || !twiddle || !melfb || !out || !utt_max || B <= 0 || hop <= 0 || pad < 0 || n_mels <= 0) return LIDK_ERR_ARG;
   if (L + 2 * pad <= LIDK_N_FFT / 2) return LIDK_ERR_ARG;         // reflect padding needs more than n_fft/2 samples
   if (mask_times > 0 && !spans) return LIDK_ERR_ARG;
@@ -233,10 +245,10 @@ extern "C" int lidk_logmel(const float* wav, const float* window, const float* t
   long nframes = (long)B * F;
   int blocks = (int)((nframes + STFT_WAVES - 1) / STFT_WAVES); if (blocks > 256) blocks = 256;      // one workgroup per CU
   static const int dbg = getenv("LIDK_STFT_DBG") ? atoi(getenv("LIDK_STFT_DBG")) : 0;     // tuning aid: 1 no FFT, 2 no mel, 4 no max
-  stft_mel_kernel<<<blocks, 64 * STFT_WAVES, 0, s>>>(wav, window, twiddle, melfb, out, utt_max, B, L, pad, hop, F, n_mels, dbg);
+  stft_mel_kernel<<<blocks, 64 * STFT_WAVES, 0, s>>>(wav, window, twiddle, melfb, out, utt_max, B, L, pad, hop, F, n_mels, dbg, n_samples);
   long n = nframes * n_mels;
   int eb = (int)((n + 255) / 256); if (eb > 8192) eb = 8192;
-  db_floor_mask_kernel<<<eb, 256, 0, s>>>(out, utt_max, spans, mask_times > 0 ? mask_times : 0, F, n_mels, n, top_db);
+  db_floor_mask_kernel<<<eb, 256, 0, s>>>(out, utt_max, spans, mask_times > 0 ? mask_times : 0, F, n_mels, n, top_db, n_samples, L, pad, hop);
   return launch_status();
 }
 

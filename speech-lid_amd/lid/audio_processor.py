@@ -85,13 +85,14 @@ class WaveBatch:
 
     It stands where the reference's collate puts the mel tensor (``batch[0]``): ``Trainer.batch_to_device`` moves it with
     ``.to(device)`` and the model calls ``to_mel()``.  Utterances shorter than ``wav.shape[1]`` are zero padded and
-    ``n_samples`` holds their true lengths (their trailing frames are then those of the padded signal, as a zero-padded
-    mel from the reference's collate would be close to, but not equal to: variable-length batches are BASELINE config 5,
-    a "next" row)."""
+    ``n_samples`` holds their true lengths: every utterance is then normalised and transformed as if it were alone, and the
+    rows behind its own frames are exactly 0.0 - the zero-padded mel the reference's collate builds
+    (lid/raw_datasets.py:345-365)."""
 
     def __init__(self, wav: torch.Tensor, spans: Optional[torch.Tensor] = None, pad: int = 0, n_mels: int = 80, sr: int = 16000,
-                 normalize: bool = True, preemph: bool = False, dither_seed: int = 0):
+                 normalize: bool = True, preemph: bool = False, dither_seed: int = 0, n_samples: Optional[torch.Tensor] = None):
         self.wav, self.spans = wav, spans
+        self.n_samples = n_samples          # int32 (B,) true lengths of a ragged batch, or None when all rows are full
         self.pad, self.n_mels, self.sr = pad, n_mels, sr
         self.normalize, self.preemph, self.dither_seed = normalize, preemph, dither_seed
 
@@ -108,12 +109,16 @@ class WaveBatch:
         self.wav = self.wav.to(device, non_blocking=non_blocking)
         if self.spans is not None:
             self.spans = self.spans.to(device, non_blocking=non_blocking)
+        if self.n_samples is not None:
+            self.n_samples = self.n_samples.to(device, non_blocking=non_blocking)
         return self
 
     def pin_memory(self):
         self.wav = self.wav.pin_memory()
         if self.spans is not None:
             self.spans = self.spans.pin_memory()
+        if self.n_samples is not None:
+            self.n_samples = self.n_samples.pin_memory()
         return self
 
     _mel = None
@@ -145,9 +150,10 @@ class WaveBatch:
         if getattr(_ops, "IS_HIP_BACKEND", False) and not self.wav.is_cuda:
             raise LidkError("WaveBatch.to_mel: the feature path runs on the GPU only (no CPU fallback)")
         x = self.wav.contiguous()
+        ns = self.n_samples.contiguous() if self.n_samples is not None else None
         if self.normalize:
-            x = _ops.normalize_wav(x)
+            x = _ops.normalize_wav(x, n_samples=ns)
         if self.preemph:
             x = _ops.dither_preemph(x, coef=0.97, dither=1e-5, seed=self.dither_seed)
         spans = self.spans.contiguous() if self.spans is not None else None
-        return _ops.logmel(x, pad=self.pad, n_mels=self.n_mels, spans=spans)
+        return _ops.logmel(x, pad=self.pad, n_mels=self.n_mels, spans=spans, n_samples=ns)

@@ -192,8 +192,9 @@ class _CollateMixin:
         if self.train and fc.mask_times > 0:
             spans = torch.tensor([draw_specaug_spans(f, fc.n_mels, fc.t_mask, fc.f_mask, fc.mask_times) for f in frames],
                                  dtype=torch.int32)
+        ragged = torch.tensor(lens, dtype=torch.int32) if min(lens) != max(lens) else None
         wb = WaveBatch(wav, spans, pad=fc.pad, n_mels=fc.n_mels, sr=fc.sr, normalize=True, preemph=self.train,
-                       dither_seed=random.getrandbits(31) if self.train else 0)
+                       dither_seed=random.getrandbits(31) if self.train else 0, n_samples=ragged)
         wb.lang_id = int(langs[0])
         return wb, texts, wav_pct, text_pct, [b[2] for b in batch], langs
 

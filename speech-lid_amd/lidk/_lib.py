@@ -36,9 +36,9 @@ _P, _I, _L, _F, _D, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double,
 # name -> (restype, argtypes); must list every function declared in include/lidk.h (tests/test_abi.py checks)
 SIGNATURES = {
     "lidk_version": (_I, []),
-    "lidk_normalize_wav": (_I, [_P, _P, _I, _I, _P]),
+    "lidk_normalize_wav": (_I, [_P, _P, _I, _I, _P, _P]),
     "lidk_dither_preemph": (_I, [_P, _P, _P, _I, _I, _F, _F, _U64, _P]),
-    "lidk_logmel": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P]),
+    "lidk_logmel": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P, _P]),
     "lidk_scale_cast": (_I, [_P, _I, _P, _I, _L, _F, _P]),
     "lidk_scale_cast_2d": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _F, _P]),
     "lidk_dropout": (_I, [_P, _I, _P, _I, _P, _P, _L, _F, _U64, _P]),

@@ -76,10 +76,11 @@ def melscale_fbanks(n_mels=80, n_freqs=257, f_min=0.0, f_max=8000.0, sample_rate
     return torch.clamp(torch.min(down, up), min=0.0)
 
 
-def normalize_wav(wav, out=None):
+def normalize_wav(wav, out=None, n_samples=None):
+    """n_samples: optional int32 (B,) true lengths of a ragged, zero-padded batch."""
     out = torch.empty_like(wav) if out is None else out
     B, Lw = wav.shape
-    check(lib().lidk_normalize_wav(_p(wav), _p(out), B, Lw, _stream()), "normalize_wav")
+    check(lib().lidk_normalize_wav(_p(wav), _p(out), B, Lw, _p(n_samples), _stream()), "normalize_wav")
     return out
 
 
@@ -90,9 +91,9 @@ def dither_preemph(wav, coef=0.97, dither=1e-5, seed=0, noise=None, out=None):
     return out
 
 
-def logmel(wav, pad=0, hop=160, win_length=400, n_mels=80, spans=None, top_db=80.0, out=None):
+def logmel(wav, pad=0, hop=160, win_length=400, n_mels=80, spans=None, top_db=80.0, out=None, n_samples=None):
     """wav (B, L) f32 -> (B, F, n_mels) f32 dB with per-utterance top_db floor and optional SpecAugment spans
-    (int32 (B, mask_times, 4))."""
+    (int32 (B, mask_times, 4)).  n_samples: optional int32 (B,) true lengths; rows behind an utterance's own frames are 0."""
     B, Lw = wav.shape
     F_ = 1 + (Lw + 2 * pad) // hop
     win, tw, fb = fft_tables(wav.device, win_length, n_mels)
@@ -100,7 +101,7 @@ def logmel(wav, pad=0, hop=160, win_length=400, n_mels=80, spans=None, top_db=80
     umax = torch.empty(B, device=wav.device, dtype=torch.float32)
     mt = 0 if spans is None else spans.shape[1]
     check(lib().lidk_logmel(_p(wav), _p(win), _p(tw), _p(fb), _p(out), _p(umax), B, Lw, pad, hop, n_mels, _p(spans), mt,
-                            top_db, _stream()), "logmel")
+                            top_db, _p(n_samples), _stream()), "logmel")
     return out
 
 

@@ -360,9 +360,14 @@ def novograd_step(params, grads, exp_avg, exp_avg_sq, work, n_tensors, lr, betas
 
 
 # ------------------------------------------------------------------------------------------------ feature path (via the oracle)
-def normalize_wav(wav, out=None):
+def normalize_wav(wav, out=None, n_samples=None):
     from oracle import features as of
-    return of.normalize_wav(wav)
+    if n_samples is None:
+        return of.normalize_wav(wav)
+    y = torch.zeros_like(wav)
+    for i, n in enumerate(n_samples.tolist()):
+        y[i, :n] = of.normalize_wav(wav[i:i + 1, :n])[0]
+    return y
 
 
 def dither_preemph(wav, coef=0.97, dither=1e-5, seed=0, noise=None, out=None):
@@ -372,8 +377,20 @@ def dither_preemph(wav, coef=0.97, dither=1e-5, seed=0, noise=None, out=None):
     return of.dither_preemphasis(wav, noise if dither else None, coef)
 
 
-def logmel(wav, pad=0, hop=160, win_length=400, n_mels=80, spans=None, top_db=80.0, out=None):
+def logmel(wav, pad=0, hop=160, win_length=400, n_mels=80, spans=None, top_db=80.0, out=None, n_samples=None):
     from oracle import features as of
+    if n_samples is not None:                                           # ragged: each utterance alone, mel zero padded
+        specs = []
+        for i, n in enumerate(n_samples.tolist()):
+            m = of.wav2mel(wav[i:i + 1, :n], n_mels=n_mels, pad=pad)[0]
+            if spans is not None:
+                m = of.apply_specaug(m, [tuple(s) for s in spans[i].tolist()])
+            specs.append(m)
+        full = 1 + (wav.shape[1] + 2 * pad) // hop
+        out_ = torch.zeros(len(specs), full, n_mels)
+        for i, m in enumerate(specs):
+            out_[i, :m.shape[-1]] = m.transpose(0, 1)
+        return out_
     mel = of.wav2mel(wav, n_mels=n_mels, pad=pad)                       # (B, n_mels, F)
     if spans is not None:
         mel = torch.stack([of.apply_specaug(mel[i], [tuple(s) for s in spans[i].tolist()]) for i in range(mel.shape[0])])

@@ -484,6 +484,37 @@ def test_logmel_matches_oracle(L_, pad, B):
     check("logmel_specaug", out, ref_aug.transpose(1, 2), 5e-3)
 
 
+@pytest.mark.parametrize("pad", [0, 16])
+def test_ragged_batch_matches_the_reference_collate(pad):
+    """A ragged, zero-padded waveform batch with its true lengths: every utterance must come out exactly as if it had been
+    processed alone (own normalisation statistics, reflection at its own end, own top_db maximum, SpecAugment spans inside
+    its own frames) and the rows behind its frames must be 0.0 - the zero-padded mel of lid/raw_datasets.py:345-365."""
+    lens = [16000, 9000, 12345, 400]
+    L_ = max(lens)
+    raw = torch.zeros(len(lens), L_)
+    for i, n in enumerate(lens):
+        raw[i, :n] = 0.5 + (1.0 + i) * torch.randn(n, generator=g(56 + i))
+    ns = torch.tensor(lens, dtype=torch.int32)
+    norm = ops.normalize_wav(dev(raw), n_samples=dev(ns))
+    spans = torch.tensor([[[3, 9, 10, 22]], [[5, 6, 0, 5]], [[0, 2, 70, 80]], [[1, 2, 3, 4]]], dtype=torch.int32)
+    out = ops.logmel(norm, pad=pad, spans=dev(spans), n_samples=dev(ns))
+    full = 1 + (L_ + 2 * pad) // 160
+    assert out.shape == (len(lens), full, 80)
+    for i, n in enumerate(lens):
+        wi = of.normalize_wav(raw[i:i + 1, :n])
+        check(f"ragged_normalize[{i}]", norm[i, :n], wi[0], 3e-5)
+        assert float(norm[i, n:].abs().max()) == 0.0 if n < L_ else True
+        ref = of.apply_specaug(of.wav2mel(wi, pad=pad)[0], [tuple(s) for s in spans[i].tolist()])       # (80, F_i)
+        fi = ref.shape[-1]
+        assert fi == 1 + (n + 2 * pad) // 160
+        check(f"ragged_logmel[{i}]", out[i, :fi], ref.transpose(0, 1), 5e-3)
+        if fi < full:
+            assert float(out[i, fi:].abs().max()) == 0.0
+    ref_b, pct = of.collate_mel([of.apply_specaug(of.wav2mel(of.normalize_wav(raw[i:i + 1, :n]), pad=pad)[0],
+                                                  [tuple(s) for s in spans[i].tolist()]) for i, n in enumerate(lens)])
+    check("ragged_collate", out, ref_b, 5e-3)
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_im2col(dt):
     B, F_, C = 3, 101, 80
