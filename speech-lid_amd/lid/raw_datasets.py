@@ -245,8 +245,11 @@ class SyntheticMergedDataset(_CollateMixin, Dataset):
     Item i is a pure function of (seed, i): every rank and every epoch sees the same corpus."""
 
     def __init__(self, train: bool, langs: Dict[str, int], lang2vocab: Dict[str, int], items_per_lang: int = 64,
-                 seconds: float = 3.0, text_len: int = 20, seed: int = 1234, lang2tokenizer: Dict = None, **feature):
+                 seconds: float = 3.0, text_len: int = 20, seed: int = 1234, lang2tokenizer: Dict = None,
+                 min_seconds: Optional[float] = None, **feature):
+        """min_seconds: if given, item i lasts U[min_seconds, seconds] (a pure function of (seed, i)): ragged batches."""
         self.train, self.lang2index_dict, self.lang2vocab = train, dict(langs), dict(lang2vocab)
+        self.min_samples = None if min_seconds is None else int(min_seconds * feature.get("sr", 16000))
         self.feat = _FeatureCfg(**{"speed_shift": False, "pitch_shift": False, "reverb": False, **feature})
         self.type = self.feat.type
         self.n_samples, self.text_len, self.seed = int(seconds * self.feat.sr), text_len, seed
@@ -266,7 +269,10 @@ class SyntheticMergedDataset(_CollateMixin, Dataset):
         lang = self.datasets[index]["locale"]
         k = self.lang2index_dict[lang]
         g = torch.Generator().manual_seed((self.seed * 7919 + index) % (2 ** 31))
-        x = 0.1 * torch.randn(self.n_samples, generator=g)
+        n = self.n_samples
+        if self.min_samples is not None:
+            n = self.min_samples + int(torch.randint(0, max(self.n_samples - self.min_samples, 0) + 1, (1,), generator=g))
+        x = 0.1 * torch.randn(n, generator=g)
         f0, r = 300.0 + 500.0 * k, 0.97
         w = 2 * math.pi * f0 / self.feat.sr
         y = lfilter([1.0], [1.0, -2 * r * math.cos(w), r * r], x.numpy().astype(np.float64))

@@ -51,6 +51,38 @@ def test_trainer_fit_config1_bf16(tmp_path, monkeypatch):
     assert all(torch.isfinite(v.float()).all() for v in sd.values())
 
 
+def test_trainer_fit_ragged_batches(tmp_path, monkeypatch):
+    """Variable-length utterances (0.4-1.0 s) through the whole path: collate -> WaveBatch with true lengths -> per-utterance
+    features with zero-padded mel rows -> CTC with the collate's length fractions -> validation scoring of each utterance
+    unpadded (equal lengths batched together)."""
+    monkeypatch.chdir(tmp_path)
+    from ccml import seed_everything
+    from ccml.trainer import Trainer
+    from lid import hydra_lite
+    import lid.main as launcher
+    seed_everything(0)
+    cfg = hydra_lite.load_config(os.path.join(PKG, "lid", "conf"), "synthetic_cfg1",
+                                 ["trainer.total_epoch=2", "trainer.gpu_id=0", "data.synthetic.items_per_lang=12",
+                                  "data.synthetic.val_items_per_lang=4", "+data.synthetic.min_seconds=0.4", "module.interval=1000",
+                                  "trainer.log_interval=1000"])
+    module, sets, params = launcher.build(cfg)
+    lens = {sets["train"][i][0].shape[-1] for i in range(8)}
+    assert len(lens) > 1
+    batch = sets["train"].collate_fn([sets["train"][i] for i in range(4)])
+    assert batch[0].n_samples is not None and float(batch[2].min()) < 1.0
+    losses = []
+    orig = module.train_loop_end
+
+    def spy(outputs):
+        losses.append(float(torch.stack([o["loss"].float() for o in outputs]).mean()))
+        return orig(outputs)
+
+    module.train_loop_end = spy
+    trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
+    trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=params)
+    assert all(np.isfinite(losses)) and np.isfinite(module.last_val["val_loss"])
+
+
 def test_bench_contract_small():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--blocks", "2", "--steps", "3", "--warmup", "1",
                           "--cpu-steps", "1", "--cpu-batch", "2", "--batch", "8"], capture_output=True, text=True, timeout=900)
