@@ -71,6 +71,11 @@ class _GraphCache:
     def clear(self):
         self.state.clear()
 
+    def drop(self, work_id: int):
+        """Forget the graphs recorded against one workspace (every key carries id(workspace) in position 1)."""
+        for k in [k for k in self.state if len(k) > 1 and k[1] == work_id]:
+            del self.state[k]
+
 
 class _BlockParams:
     """Views of one ConformerBlock's parameters: f32 master / gradient views and T-typed GEMM operands."""
@@ -363,13 +368,19 @@ class Engine:
         self.w_conv3.copy_(c3.permute(0, 2, 1).reshape(c3.shape[0], -1))             # 19 K elements: layout glue, not math
 
     def work(self, B, F_):
+        """Workspace for a (batch, frames) shape.  Ragged training data produces many shapes, so a budget of workspaces is
+        kept (least recently used goes first; HBM is 288 GB and a cfg2 workspace is ~3 GB) and evicting one drops only the
+        hipGraphs that point into it."""
         key = (B, F_)
-        if key not in self._work:
-            if len(self._work) >= 4:
-                self._work.pop(next(iter(self._work)))
-                self.graphs.clear()                    # captured graphs point into the evicted workspace
-            self._work[key] = _Work(self, B, F_)
-        return self._work[key]
+        w = self._work.pop(key, None)
+        if w is None:
+            limit = int(_os_env("LIDK_MAX_WORKSPACES", "12"))
+            while len(self._work) >= max(limit, 1):
+                old = self._work.pop(next(iter(self._work)))
+                self.graphs.drop(id(old))              # captured graphs point into the evicted workspace
+            w = _Work(self, B, F_)
+        self._work[key] = w                            # (re)insert at the most-recently-used end
+        return w
 
     # ------------------------------------------------------------------ forward pieces
     def _front_fwd(self, w: _Work, mel, training, seed):
