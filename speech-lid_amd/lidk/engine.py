@@ -34,11 +34,12 @@ def _ceil(a, b):
 class _GraphCache:
     """hipGraph capture of fixed launch sequences (one ConformerBlock forward or backward).
 
-    A block's kernels always touch the same preallocated buffers and carry no per-step scalars, so the ~25 (forward) /
-    ~45 (backward) launches can be recorded once and replayed with a single host call: the Python/ctypes launch path costs
-    ~13 us per kernel, a graph replay ~15 us per block.  First use of a key runs eagerly (allocations, lazy views), second
-    use captures, later uses replay.  Disabled with LIDK_GRAPHS=0, on the CPU test backend, and for sequences that contain a
-    collective (SyncBatchNorm under data parallelism)."""
+    A block's kernels always touch the same preallocated buffers and carry no per-step scalars, so the ~18 (forward) /
+    ~35 (backward, including the previous block's weight gradients on the second stream) launches can be recorded once and
+    replayed with a single host call: the Python/ctypes launch path costs ~13 us per kernel, a graph replay ~15 us per
+    block.  First use of a key runs eagerly (allocations, lazy views), second use captures, later uses replay.  Disabled
+    with LIDK_GRAPHS=0 and on the CPU test backend; under data parallelism a block's sequence is cut at the SyncBatchNorm
+    all-reduce into two graphs (Engine._run_split).  A capture that fails switches the engine to eager launches."""
 
     def __init__(self, enabled: bool):
         self.enabled = enabled
