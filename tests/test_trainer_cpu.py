@@ -66,6 +66,30 @@ def test_fit_cfg1_end_to_end_checkpoint_and_resume(fake_backend, tmp_path, monke
     assert torch.equal(m3.model.state_dict()["model.last_projects.c.linear.bias"], state["model"]["model.last_projects.c.linear.bias"])
 
 
+def test_ragged_collate_matches_reference_layout(fake_backend):
+    """Host side of a variable-length batch: the collate carries the true lengths, the feature call is per utterance with
+    zero-padded mel rows (the reference's collate, lid/raw_datasets.py:345-365) and wav_percents are frame fractions."""
+    import lid.main as launcher
+    from lid.audio_processor import num_frames
+    from oracle import features as of
+    cfg = load_cfg("+data.synthetic.min_seconds=0.2")
+    module, sets, params = launcher.build(cfg)
+    ds = sets["val"]
+    items = [ds[i] for i in range(4)]
+    lens = [int(it[0].shape[-1]) for it in items]
+    assert len(set(lens)) > 1
+    wb, texts, wav_pct, text_pct, paths, langs = ds.collate_fn(items)
+    assert wb.n_samples.tolist() == lens and wb.wav.shape == (4, max(lens))
+    pad = wb.pad
+    frames = [num_frames(n, pad) for n in lens]
+    np.testing.assert_allclose(wav_pct.numpy(), np.array(frames, np.float32) / max(frames), rtol=1e-6)
+    mel = wb.to_mel()
+    ref, pct = of.collate_mel([of.wav2mel(of.normalize_wav(items[i][0].reshape(1, -1)), pad=pad)[0] for i in range(4)])
+    assert mel.shape == ref.shape
+    np.testing.assert_allclose(mel.numpy(), ref.numpy(), atol=1e-4)
+    np.testing.assert_allclose(pct.numpy(), wav_pct.numpy(), rtol=1e-6)
+
+
 def test_state_dict_keys_match_reference(cfg1_weights):
     from lid.ConformerLangModel import ConformerMutiLangModel
     m = ConformerMutiLangModel(lang2vocab={"a": 30, "b": 40, "c": 50}, lang2index={"a": 0, "b": 1, "c": 2}, hidden_dim=32,
