@@ -217,6 +217,36 @@ def gemm_roofline(trainer, batches, step_fn):
                              "TFLOP/s": round(fl2 / (ms2 * 1e-3) / 1e12, 1), "traffic": _pmc_traffic("gemm_tn_bf16_kernel")}}
 
 
+def phase_times(trainer, batches, step_fn):
+    """Device time of the phases of ONE more step (graphs on, as in the timed loop): features + forward + CTC, backward,
+    clip + optimizer + weight refresh.  HIP events on the main stream around the module's train_loop, loss.backward and the
+    trainer's optimizer step."""
+    ev = {k: torch.cuda.Event(enable_timing=True) for k in ("t0", "fwd", "bwd", "opt")}
+    mod = trainer.ccml_module
+    orig_loop, orig_opt = mod.train_loop, trainer._optimizer_step
+
+    def loop(batch):
+        ev["t0"].record()
+        out = orig_loop(batch)
+        ev["fwd"].record()
+        return out
+
+    def opt():
+        ev["bwd"].record()
+        orig_opt()
+        ev["opt"].record()
+
+    mod.train_loop, trainer._optimizer_step = loop, opt
+    try:
+        step_fn(1, batches[1 % len(batches)])
+        torch.cuda.synchronize()
+    finally:
+        mod.train_loop, trainer._optimizer_step = orig_loop, orig_opt
+    return {"features_forward_loss": round(ev["t0"].elapsed_time(ev["fwd"]), 3),
+            "backward": round(ev["fwd"].elapsed_time(ev["bwd"]), 3),
+            "clip_optimizer_refresh": round(ev["bwd"].elapsed_time(ev["opt"]), 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -276,7 +306,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
-    roof = gemm_roofline(trainer, batches, step_fn)      # every rank runs the instrumented step (it contains collectives)
+    phases = phase_times(trainer, batches, step_fn)      # every rank runs these extra steps (they contain collectives)
+    roof = gemm_roofline(trainer, batches, step_fn)
     if world > 1:
         dist.barrier()
     cpu = None
@@ -293,7 +324,8 @@ def main():
                                        f"3 s@16 kHz, batch={args.batch}/GPU, Novograd+clip, features on GPU",
                            "global_batch": world * args.batch, "utterance_seconds": SECONDS,
                            "parallelism": f"dp{world}", "stochastic_depth": bool(args.stochastic_depth)},
-                "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 3), "roofline": roof, "cpu_baseline": cpu}
+                "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 3), "phases_ms": phases, "roofline": roof,
+                "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -89,7 +89,7 @@ def test_bench_contract_small():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "phases_ms"):
         assert key in line, key
     roof = line["roofline"]
     assert line["value"] > 0 and roof["bound"] == "hbm" and roof["unit"] == "GB/s" and 0 < roof["frac"] < 1
