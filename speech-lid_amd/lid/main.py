@@ -15,8 +15,11 @@ from ccml import seed_everything  # noqa: E402
 from ccml.callbacks.ckpt_callback import CkptCallback  # noqa: E402
 from ccml.callbacks.lr_callback import LrCallback  # noqa: E402
 from ccml.callbacks.profile_callback import ProfileCallback  # noqa: E402
+from ccml.loggers.comet_logger import CometLogger  # noqa: E402
 from ccml.loggers.jsonl_logger import JsonlLogger  # noqa: E402
+from ccml.loggers.wandb_logger import WandbLogger  # noqa: E402,F401
 from ccml.trainer import Trainer  # noqa: E402
+from lid.LidModule_ASR import LidModule  # noqa: E402
 from lid.LidModule_ASR_Supervised import LidSuperviseModule  # noqa: E402
 from lid.raw_datasets import MergedDataset, MutiBatchSampler, SyntheticMergedDataset  # noqa: E402
 from lid.tokenizer import CTCTokenizer  # noqa: E402
@@ -39,8 +42,10 @@ def build(cfg, rank=0, world=1):
         lang2vocab[item["lang"]] = len(tokenizers[item["lang"]].export_vocab())
         for split in manifests:
             manifests[split].append(item.get(f"{split}_manifest"))
-    module = LidSuperviseModule(**cfg["module"], **cfg["model"], lang2vocab=lang2vocab, lang2index_dict=lang2index,
-                                tokenizer_dict=tokenizers)
+    # `supervised: true` selects the Conformer module, anything else the pretrained-backbone module (reference main.py:69-81)
+    module_cls = LidSuperviseModule if cfg.get("supervised", True) else LidModule
+    module = module_cls(**cfg["module"], **cfg["model"], lang2vocab=lang2vocab, lang2index_dict=lang2index,
+                        tokenizer_dict=tokenizers)
     feature = dict(data["feature"])
 
     def dataset(split, train):
@@ -74,7 +79,9 @@ def main(cfg) -> None:
             tcfg["gpu_id"] = int(os.environ["LOCAL_RANK"])
     module, sets, params = build(cfg, max(tcfg.get("local_rank", 0), 0), tcfg.get("world_size", 1) if tcfg.get("ddp") else 1)
     callbacks = [CkptCallback(file_name_metric=["epoch", "val_loss"], save_topk=2), LrCallback(), ProfileCallback()]
-    trainer = Trainer(callbacks=callbacks, loggers=[JsonlLogger("metrics.jsonl")], **tcfg)
+    comet = (cfg.get("logger") or {}).get("comet")                       # reference main.py:38,131: CometLogger(**comet_conf)
+    loggers = [CometLogger(**comet) if comet else JsonlLogger("metrics.jsonl")]
+    trainer = Trainer(callbacks=callbacks, loggers=loggers, **tcfg)
     if cfg["stage"] == "train":
         trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"],
                     dataloader_params=params)

@@ -95,3 +95,30 @@ def test_bench_contract_small():
     assert line["value"] > 0 and roof["bound"] == "hbm" and roof["unit"] == "GB/s" and 0 < roof["frac"] < 1
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0 < roof["mfma"]["frac"] < 1
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+
+
+def test_reference_schema_yaml_trains_from_disk(tmp_path, monkeypatch):
+    """A YAML in the reference's conf schema (tests/ref_schema.py: `supervised:`, model_name anchor + interpolation, vocab FILE
+    paths, xf label manifests + PCM wavs on disk, `logger.comet`, `backend: 'nccl'`, accumulate_grad 2) through this repo's
+    launcher and Trainer.fit on the GPU: file reading, ragged collate, GPU features, training, validation with Cavg, ckpt."""
+    import ref_schema
+    from ccml import seed_everything
+    from ccml.callbacks.ckpt_callback import CkptCallback
+    from ccml.loggers.comet_logger import CometLogger
+    from ccml.trainer import Trainer
+    from lid import hydra_lite
+    import lid.main as launcher
+    monkeypatch.chdir(tmp_path)
+    seed_everything(0)
+    corpus = ref_schema.make_corpus(str(tmp_path), n_train=8, n_val=3)
+    ref_schema.write_yaml(str(tmp_path / "conf"), corpus, gpu_id=0, total_epoch=2)
+    cfg = hydra_lite.load_config(str(tmp_path / "conf"), "xf_like")
+    module, sets, params = launcher.build(cfg)
+    trainer = Trainer(callbacks=[CkptCallback(file_name_metric=["epoch", "val_loss"], save_topk=2)],
+                      loggers=[CometLogger(**cfg["logger"]["comet"])], **dict(cfg["trainer"]))
+    trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=params)
+    assert np.isfinite(module.last_val["val_loss"]) and 0.0 <= module.last_val["cavg"] <= 1.0
+    assert module.model.lidk_engine.act_dtype == torch.float32               # use_amp: false -> f32 parity mode
+    assert os.path.exists("ckpt/last.pt") and trainer.current_step == 2 * 3     # 6 batches / accumulate_grad 2, 2 epochs
+    state = torch.load("ckpt/last.pt", weights_only=False)
+    assert {"model", "hyper_parameters", "epoch", "optimizer", "scalar", "logger"} <= set(state)
