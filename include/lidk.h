@@ -200,6 +200,10 @@ int lidk_ctc_loss(const float* logits, const int64_t* targets, const int64_t* in
 /* LangDiscriminator.forward ASR half (lid/ConformerLangModel.py:386-393) for ONE language head:
  * scores[b*score_stride] = sum_t [argmax!=blank] max_c log_softmax / (count*ln(blank) + 1e-5). */
 int lidk_lid_score(const float* logits, float* scores, int score_stride, int B, int T, int V1, int blank, void* stream);
+/* LangDiscriminator.linear on the detached scores (lid/ConformerLangModel.py:374-378,394): out [B,C] =
+ * W2 [C,H] relu(W0 [H,C] scores [B,C] + b0) + b2, H <= 64.  One wave per utterance: a row's result does not depend on the batch. */
+int lidk_lid_mlp(const float* scores, const float* w0, const float* b0, const float* w2, const float* b2, float* out,
+                 int B, int C, int H, void* stream);
 
 /* ------------------------------------------------------------------ fused clip + Novograd over the flat arenas
  * ccml/trainer.py:541-543 clip_grad_norm_(max_norm) + ccml/optim/novograd.py:75-145 (amsgrad=False, luc=False).

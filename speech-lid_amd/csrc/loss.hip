@@ -355,3 +355,31 @@ extern "C" int lidk_lid_score(const float* logits, float* scores, int score_stri
   lid_score_kernel<<<B, 256, 0, as_stream(stream)>>>(logits, scores, score_stride, T_, V1, blank);
   return launch_status();
 }
+
+// ------------------------------------------------------------------------------------ LangDiscriminator MLP
+// One wave per utterance: h = relu(W0 s + b0) (H <= 64 hidden units, one per lane), out_c = W2[c,:] . h + b2[c] by a wave
+// reduction per class.  Rows are independent of the batch and of each other, the summation order is fixed.
+__global__ void __launch_bounds__(64)
+lid_mlp_kernel(const float* __restrict__ scores, const float* __restrict__ w0, const float* __restrict__ b0,
+               const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out, int C, int H) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float h = 0.f;
+  if (lane < H) {
+    float acc = b0[lane];
+    for (int c = 0; c < C; ++c) acc = fmaf(w0[(size_t)lane * C + c], scores[(size_t)b * C + c], acc);
+    h = fmaxf(acc, 0.f);
+  }
+  for (int c = 0; c < C; ++c) {
+    float v = lane < H ? w2[(size_t)c * H + lane] * h : 0.f;
+    v = wave_sum(v);
+    if (lane == 0) out[(size_t)b * C + c] = v + b2[c];
+  }
+}
+
+extern "C" int lidk_lid_mlp(const float* scores, const float* w0, const float* b0, const float* w2, const float* b2,
+                            float* out, int B, int C, int H, void* stream) {
+  if (!scores || !w0 || !b0 || !w2 || !b2 || !out || B <= 0 || C <= 0) return LIDK_ERR_ARG;
+  if (H <= 0 || H > 64) return LIDK_ERR_UNSUPPORTED;
+  lid_mlp_kernel<<<B, 64, 0, as_stream(stream)>>>(scores, w0, b0, w2, b2, out, C, H);
+  return launch_status();
+}

@@ -229,8 +229,9 @@ class ConformerMutiLangModel(nn.Module):
         for lang, lg in logits.items():
             eng.k.lid_score(lg.contiguous(), scores[:, cfg.lang2index[lang]:], len(cfg.lang2vocab), cfg.lang2vocab[lang])
         pv = eng.pview
-        h = F.relu(F.linear(scores.detach(), pv("lang_discriminator.linear.0.weight"), pv("lang_discriminator.linear.0.bias")))
-        lin = F.linear(h, pv("lang_discriminator.linear.2.weight"), pv("lang_discriminator.linear.2.bias"))   # (B,C)x(C,32): glue
+        lin = torch.empty_like(scores)
+        eng.k.lid_mlp(scores, pv("lang_discriminator.linear.0.weight"), pv("lang_discriminator.linear.0.bias"),
+                      pv("lang_discriminator.linear.2.weight"), pv("lang_discriminator.linear.2.bias"), lin)
         return scores, lin
 
     # ------------------------------------------------------------------ reference helper surface

@@ -240,19 +240,34 @@ class _SynthLang:
 
 
 class SyntheticMergedDataset(_CollateMixin, Dataset):
-    """Synthetic LID data: language k is white noise through a 2-pole resonator at f_k = 300 + 500 k Hz
-    (radius 0.97), so each language has a distinct spectral signature; transcripts are ``text_len`` uniform tokens.
-    Item i is a pure function of (seed, i): every rank and every epoch sees the same corpus."""
+    """Synthetic LID data.  Language k is white noise through a 2-pole resonator at f_k = 300 + 500 k Hz (radius
+    0.97): a distinct spectral signature per language.  Item i is a pure function of (seed, i): every rank and every epoch sees
+    the same corpus.
+
+    ``transcript="random"``: ``text_len`` uniform tokens unrelated to the audio (throughput runs only: CTC can learn nothing).
+
+    ``transcript="tones"`` (learnable, used for the val-Cavg half of the metric): the utterance is cut into ``text_len`` equal
+    segments; segment j carries token t_j as a PAIR of simultaneous tones (f_a, f_b), f_a = 300 + 100 a Hz (a < 16),
+    f_b = 2200 + 200 b Hz (b < 16), on for the first 80 % of the segment with 5 ms raised-cosine edges (the gap gives CTC a
+    boundary between repeated tokens).  Which of the 256 (a, b) pairs spell token t is a LANGUAGE-SPECIFIC choice
+    (``torch.randperm(256, seed 99 + k)[t]``): like phoneme inventories, languages share the same sounds but not the same
+    symbols, so a head trained on language k reads its own language confidently and foreign audio - mostly pairs it never saw -
+    hesitantly, which is what the CTC-confidence LID score (lid/ConformerLangModel.py:383-395) measures."""
+
+    N_A = N_B = 16
 
     def __init__(self, train: bool, langs: Dict[str, int], lang2vocab: Dict[str, int], items_per_lang: int = 64,
                  seconds: float = 3.0, text_len: int = 20, seed: int = 1234, lang2tokenizer: Dict = None,
-                 min_seconds: Optional[float] = None, **feature):
+                 min_seconds: Optional[float] = None, transcript: str = "random", **feature):
         """min_seconds: if given, item i lasts U[min_seconds, seconds] (a pure function of (seed, i)): ragged batches."""
+        if transcript not in ("random", "tones"):
+            raise ValueError(f"transcript must be 'random' or 'tones', got {transcript!r}")
         self.train, self.lang2index_dict, self.lang2vocab = train, dict(langs), dict(lang2vocab)
         self.min_samples = None if min_seconds is None else int(min_seconds * feature.get("sr", 16000))
         self.feat = _FeatureCfg(**{"speed_shift": False, "pitch_shift": False, "reverb": False, **feature})
         self.type = self.feat.type
         self.n_samples, self.text_len, self.seed = int(seconds * self.feat.sr), text_len, seed
+        self.transcript = transcript
         self.lang2tokenizer = lang2tokenizer
         self.datasets, self.samplers = [], []
         for lang in langs:
@@ -260,26 +275,49 @@ class SyntheticMergedDataset(_CollateMixin, Dataset):
             s.set_base_value(len(self.datasets))
             self.samplers.append(s)
             self.datasets += [{"locale": lang, "path": f"synthetic://{lang}/{i}"} for i in range(items_per_lang)]
+        self._pairs = {}
+        if transcript == "tones":
+            for lang, k in self.lang2index_dict.items():
+                if self.lang2vocab[lang] > self.N_A * self.N_B:
+                    raise ValueError(f"'tones' transcripts support up to {self.N_A * self.N_B} symbols per language")
+                self._pairs[lang] = torch.randperm(self.N_A * self.N_B, generator=torch.Generator().manual_seed(99 + k)).tolist()
 
     def __len__(self):
         return len(self.datasets)
+
+    def _length(self, index: int, g: torch.Generator) -> int:
+        if self.min_samples is None:
+            return self.n_samples
+        return self.min_samples + int(torch.randint(0, max(self.n_samples - self.min_samples, 0) + 1, (1,), generator=g))
+
+    def text(self, index: int) -> torch.Tensor:
+        item = self.datasets[index]
+        g = torch.Generator().manual_seed((self.seed * 104729 + index + 4321) % (2 ** 31))
+        return torch.randint(0, self.lang2vocab[item["locale"]], (self.text_len,), generator=g)
 
     def waveform(self, index: int) -> torch.Tensor:
         from scipy.signal import lfilter
         lang = self.datasets[index]["locale"]
         k = self.lang2index_dict[lang]
         g = torch.Generator().manual_seed((self.seed * 7919 + index) % (2 ** 31))
-        n = self.n_samples
-        if self.min_samples is not None:
-            n = self.min_samples + int(torch.randint(0, max(self.n_samples - self.min_samples, 0) + 1, (1,), generator=g))
+        n = self._length(index, g)
         x = 0.1 * torch.randn(n, generator=g)
         f0, r = 300.0 + 500.0 * k, 0.97
         w = 2 * math.pi * f0 / self.feat.sr
         y = lfilter([1.0], [1.0, -2 * r * math.cos(w), r * r], x.numpy().astype(np.float64))
+        if self.transcript == "tones":
+            sr, seg = self.feat.sr, n // self.text_len
+            on, edge = int(0.8 * seg), int(0.005 * self.feat.sr)
+            tau = np.arange(on) / sr
+            env = np.ones(on)
+            ramp = 0.5 - 0.5 * np.cos(np.pi * np.arange(edge) / edge)
+            env[:edge], env[on - edge:] = ramp, ramp[::-1]
+            for j, t in enumerate(self.text(index).tolist()):
+                q = self._pairs[lang][t]
+                fa, fb = 300.0 + 100.0 * (q // self.N_B), 2200.0 + 200.0 * (q % self.N_B)
+                y[j * seg:j * seg + on] += env * (np.sin(2 * math.pi * fa * tau) + np.sin(2 * math.pi * fb * tau))
         return torch.from_numpy(y.astype(np.float32))
 
     def __getitem__(self, index):
         item = self.datasets[index]
-        g = torch.Generator().manual_seed((self.seed * 104729 + index + 4321) % (2 ** 31))
-        text = torch.randint(0, self.lang2vocab[item["locale"]], (self.text_len,), generator=g)
-        return self.waveform(index), text, item["path"], item["locale"]
+        return self.waveform(index), self.text(index), item["path"], item["locale"]

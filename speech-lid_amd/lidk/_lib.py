@@ -75,6 +75,7 @@ SIGNATURES = {
     "lidk_ctc_workspace_bytes": (_L, [_I, _I, _I, _I]),
     "lidk_ctc_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "lidk_lid_score": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "lidk_lid_mlp": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_novograd_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P]),
     "lidk_cast_weights": (_I, [_P, _P, _P, _I, _L, _I, _P]),
 }

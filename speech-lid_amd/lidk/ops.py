@@ -344,6 +344,13 @@ def lid_score(logits, scores_col, stride, blank):
     check(lib().lidk_lid_score(_p(logits), scores_col.data_ptr(), stride, B, T, V1, blank, _stream()), "lid_score")
 
 
+def lid_mlp(scores, w0, b0, w2, b2, out):
+    """LangDiscriminator MLP: out (B, C) = W2 relu(W0 scores + b0) + b2, all f32."""
+    B, Cn = scores.shape
+    check(lib().lidk_lid_mlp(_p(scores), _p(w0), _p(b0), _p(w2), _p(b2), _p(out), B, Cn, w0.shape[0], _stream()), "lid_mlp")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- optimizer
 def novograd_step(params, grads, exp_avg, exp_avg_sq, work, n_tensors, lr, betas, eps, weight_decay, grad_averaging,
                   max_norm, scratch, total_norm):

@@ -338,6 +338,11 @@ def lid_score(logits, scores_col, stride, blank):
     scores_col[:, 0] = (vmax * mask).sum(-1) / (mask.sum(-1) * math.log(blank) + 1e-5)
 
 
+def lid_mlp(scores, w0, b0, w2, b2, out):
+    out.copy_(F.linear(F.relu(F.linear(scores, w0, b0)), w2, b2))
+    return out
+
+
 def novograd_step(params, grads, exp_avg, exp_avg_sq, work, n_tensors, lr, betas, eps, weight_decay, grad_averaging,
                   max_norm, scratch, total_norm):
     items = {}

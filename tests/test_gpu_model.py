@@ -67,6 +67,14 @@ def test_eval_forward_and_lid_scores(cfg1_weights, cfg1_cfg, dt):
     assert float((scores.cpu() - ref).abs().max()) <= (1e-5 if dt == torch.float32 else 5e-3)
     if dt == torch.float32:
         assert torch.equal(scores.argmax(-1).cpu(), ref.argmax(-1))          # argmax language labels exact
+    # LangDiscriminator MLP (lid_linear, lid/ConformerLangModel.py:394) on the HIP scores against the reference's output
+    lin = torch.empty_like(scores)
+    pv = eng.pview
+    ops.lid_mlp(scores, pv("lang_discriminator.linear.0.weight"), pv("lang_discriminator.linear.0.bias"),
+                pv("lang_discriminator.linear.2.weight"), pv("lang_discriminator.linear.2.bias"), lin)
+    lerr = float((lin.cpu() - torch.from_numpy(g["lid_linear"])).abs().max())
+    print(f"[lid_linear {dt}] max_abs_err={lerr:.3e}")
+    assert lerr <= (1e-5 if dt == torch.float32 else 5e-3)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
