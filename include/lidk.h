@@ -73,8 +73,12 @@ int lidk_colsum(const void* x, int ldx, int x_dtype, float* out, float* partial,
 /* out [C][R] = in [R][C]^T */
 int lidk_transpose(const void* in, int ldi, void* out, int ldo, int R, int C, int dtype, void* stream);
 /* out[c] = sum_p partial[p][c] in float64 (deterministic column sum of scratch partials); out2 (may be NULL) gets a copy
- * (the SyncBatchNorm backward keeps the local sums while `out` is all-reduced in place). */
-int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double* out, double* out2, void* stream);
+ * (the SyncBatchNorm backward keeps the local sums while `out` is all-reduced in place).  tail > 0: out[ncols] (and
+ * out2[ncols]) = tail - the BatchNorm kernels' row count, stored behind the sums so that ONE all-reduce(SUM) of ncols+1
+ * doubles yields the global sums and the global count even when ranks hold different (B, T) shapes (what torch's
+ * SyncBatchNorm gets by all-gathering per-rank counts, reference ccml/trainer.py:428). */
+int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double* out, double* out2, double tail,
+                             void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm (nn.LayerNorm eps=1e-5, lid/conformer.py:85,190,250) */
 /* x [M][C] f32 -> yT (T, may be NULL) and/or y32 (f32, may be NULL); mean/rstd [M] saved for backward (may be NULL). */
@@ -166,7 +170,9 @@ int lidk_dwconv_bwd_input_bn_glu(const void* ds, const void* c, const float* mea
                                  int B, int T, int C, int K, int pad_left, int dtype, void* stream);
 int lidk_dwconv_bwd_weight(const void* dc, const void* g, float* dw, float* db, float* partial, int B, int T, int C,
                            int K, int pad_left, int dtype, void* stream);
-/* BatchNorm1d training statistics (lid/conformer.py:197): sums [2][C] f64 = (sum x, sum x^2) over `count` rows (already
+/* `count` convention of the three BatchNorm entry points below: count > 0 is the row count as a host scalar; count <= 0 means
+ * "read it from device memory at sums[2*C]" (see lidk_reduce_partials_f64's tail) - no per-shape scalar in a captured launch.
+ * BatchNorm1d training statistics (lid/conformer.py:197): sums [2][C] f64 = (sum x, sum x^2) over `count` rows (already
  * all-reduced over ranks for SyncBatchNorm, ccml/trainer.py:428) -> mean, rstd (biased var); running stats momentum update
  * with unbiased var; num_batches_tracked += 1. */
 int lidk_bn_train_stats(const double* sums, double count, float* mean, float* rstd, float* running_mean,

@@ -42,6 +42,9 @@ class RunOpts:
     pos_keep_mask: Optional[torch.Tensor] = None   # (B,T,d) bool/0-1, Dropout after x*sqrt(d)
     head_keep_mask: Optional[torch.Tensor] = None  # (B,T,d) Dropout in ConformerLinear
     bn_buffers: Dict[str, torch.Tensor] = field(default_factory=dict)  # updated running stats (training)
+    # data-parallel oracle: all-reduce(SUM) of a float64 tensor over the ranks (None = single process).  With it the
+    # BatchNorm layers follow torch.nn.SyncBatchNorm, which the reference's Trainer installs under DDP (ccml/trainer.py:428)
+    all_reduce: Optional[object] = None
 
 
 def _ln(x, sd, p):
@@ -98,7 +101,11 @@ def conv_module(x, sd, p, opts: RunOpts):
     pad = (k // 2, k // 2 - (k + 1) % 2)                                  # calc_same_padding :26-28
     c = F.conv1d(F.pad(g, pad), w, sd[p + ".4.conv.bias"], groups=w.shape[0])
     rm, rv = sd[p + ".5.running_mean"], sd[p + ".5.running_var"]
-    if opts.training:
+    if opts.training and opts.all_reduce is not None:
+        z, rm, rv = SyncBatchNorm.apply(c, sd[p + ".5.weight"], sd[p + ".5.bias"], rm, rv, opts.all_reduce)
+        opts.bn_buffers[p + ".5.running_mean"] = rm
+        opts.bn_buffers[p + ".5.running_var"] = rv
+    elif opts.training:
         rm, rv = rm.clone(), rv.clone()
         z = F.batch_norm(c, rm, rv, sd[p + ".5.weight"], sd[p + ".5.bias"], True, BN_MOMENTUM, BN_EPS)
         opts.bn_buffers[p + ".5.running_mean"] = rm
@@ -107,6 +114,44 @@ def conv_module(x, sd, p, opts: RunOpts):
         z = F.batch_norm(c, rm, rv, sd[p + ".5.weight"], sd[p + ".5.bias"], False, BN_MOMENTUM, BN_EPS)
     s = swish(z)
     return F.conv1d(s, sd[p + ".7.weight"], sd[p + ".7.bias"]).transpose(1, 2)
+
+
+class SyncBatchNorm(torch.autograd.Function):
+    """torch.nn.SyncBatchNorm restated for the CPU oracle (torch's own module is GPU-only): statistics over the rows of ALL
+    ranks.  Forward: every rank contributes (sum x, sum x^2, row count) - torch all-gathers per-rank mean/var/count, which
+    is the same global mean and biased variance; running_var gets the unbiased N/(N-1) correction with the GLOBAL count N.
+    Backward: dx = w*rstd*(dy - mean_N(dy) - xhat*mean_N(dy*xhat)) with both means over all ranks; dweight/dbias stay
+    rank-local (DDP averages them like any other gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, all_reduce):
+        C = x.shape[1]
+        xd = x.double()
+        pack = torch.cat([xd.sum((0, 2)), (xd * xd).sum((0, 2)), torch.tensor([x.shape[0] * x.shape[2]], dtype=torch.float64)])
+        all_reduce(pack)
+        n = float(pack[-1])
+        mean = pack[:C] / n
+        var = (pack[C:2 * C] / n - mean * mean).clamp_min(0)
+        rstd = 1.0 / torch.sqrt(var + BN_EPS)
+        xhat = ((xd - mean[None, :, None]) * rstd[None, :, None]).float()
+        ctx.save_for_backward(xhat, weight, rstd.float())
+        ctx.all_reduce, ctx.n = all_reduce, n
+        rm = (1 - BN_MOMENTUM) * running_mean + BN_MOMENTUM * mean.float()
+        rv = (1 - BN_MOMENTUM) * running_var + BN_MOMENTUM * (var * (n / max(n - 1, 1))).float()
+        ctx.mark_non_differentiable(rm, rv)
+        return xhat * weight[None, :, None] + bias[None, :, None], rm, rv
+
+    @staticmethod
+    def backward(ctx, dy, _drm, _drv):
+        xhat, weight, rstd = ctx.saved_tensors
+        C = dy.shape[1]
+        pack = torch.cat([dy.double().sum((0, 2)), (dy * xhat).double().sum((0, 2))])
+        dbias, dweight = pack[:C].float(), pack[C:].float()
+        pack = pack * weight.double().repeat(2)               # sums of dxhat = dy*w and dxhat*xhat
+        ctx.all_reduce(pack)
+        a, b = (pack[:C] / ctx.n).float(), (pack[C:] / ctx.n).float()
+        dx = rstd[None, :, None] * (dy * weight[None, :, None] - a[None, :, None] - xhat * b[None, :, None])
+        return dx, dweight, dbias, None, None, None
 
 
 def conformer_block(x, sd, p, heads, opts: RunOpts):

@@ -100,11 +100,12 @@ dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float
     float4 mu = make_float4(0, 0, 0, 0), rs = mu, gm = mu, bt = mu, m0 = mu, m1 = mu;
     if (cok) {
       const int cg = c0 + cc;
+      const double cnt = bn.count > 0 ? bn.count : bn.sums[2 * C];      // count <= 0: the global row count rides behind the sums
       mu = load4(bn.mean + cg); rs = load4(bn.rstd + cg); gm = load4(bn.gamma + cg); bt = load4(bn.beta + cg);
-      m0 = make_float4((float)(bn.sums[cg] / bn.count), (float)(bn.sums[cg + 1] / bn.count), (float)(bn.sums[cg + 2] / bn.count),
-                       (float)(bn.sums[cg + 3] / bn.count));
-      m1 = make_float4((float)(bn.sums[C + cg] / bn.count), (float)(bn.sums[C + cg + 1] / bn.count),
-                       (float)(bn.sums[C + cg + 2] / bn.count), (float)(bn.sums[C + cg + 3] / bn.count));
+      m0 = make_float4((float)(bn.sums[cg] / cnt), (float)(bn.sums[cg + 1] / cnt), (float)(bn.sums[cg + 2] / cnt),
+                       (float)(bn.sums[cg + 3] / cnt));
+      m1 = make_float4((float)(bn.sums[C + cg] / cnt), (float)(bn.sums[C + cg + 1] / cnt),
+                       (float)(bn.sums[C + cg + 2] / cnt), (float)(bn.sums[C + cg + 3] / cnt));
     }
     const T* cbuf = (const T*)bn.c;
     for (int q = threadIdx.x; q < DW_ROWS * 16; q += 256) {
@@ -253,7 +254,7 @@ extern "C" int lidk_dwconv_bwd_input_bn_glu(const void* ds, const void* c, const
                                             const float* gamma, const float* beta, const double* sums, double count,
                                             const float* w, const void* y, void* dy, int B, int T_, int C, int K, int pad_left,
                                             int dtype, void* stream) {
-  if (!ds || !c || !mean || !rstd || !gamma || !beta || !sums || count <= 0 || !w || !y || !dy || B <= 0 || T_ <= 0 || C <= 0 ||
+  if (!ds || !c || !mean || !rstd || !gamma || !beta || !sums || !w || !y || !dy || B <= 0 || T_ <= 0 || C <= 0 ||
       (C & 3) || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K)
     return LIDK_ERR_ARG;
   dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
@@ -359,12 +360,13 @@ extern "C" int lidk_dwconv_bwd_weight(const void* dc, const void* g, float* dw, 
 }
 
 // ------------------------------------------------------------------------------------ BatchNorm statistics
-__global__ void bn_train_stats_kernel(const double* __restrict__ sums, double count, float* __restrict__ mean,
+__global__ void bn_train_stats_kernel(const double* __restrict__ sums, double count_arg, float* __restrict__ mean,
                                       float* __restrict__ rstd, float* __restrict__ rmean, float* __restrict__ rvar,
                                       int64_t* __restrict__ nbt, float momentum, float eps, int C) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
+  const double count = count_arg > 0 ? count_arg : sums[2 * C];       // count <= 0: the global row count rides behind the sums
   double mu = sums[c] / count;
   double var = sums[C + c] / count - mu * mu;
   if (var < 0) var = 0;
@@ -375,7 +377,7 @@ __global__ void bn_train_stats_kernel(const double* __restrict__ sums, double co
 }
 extern "C" int lidk_bn_train_stats(const double* sums, double count, float* mean, float* rstd, float* running_mean,
                                    float* running_var, int64_t* nbt, float momentum, float eps, int C, void* stream) {
-  if (!sums || !mean || !rstd || count <= 0 || C <= 0) return LIDK_ERR_ARG;
+  if (!sums || !mean || !rstd || C <= 0) return LIDK_ERR_ARG;
   bn_train_stats_kernel<<<cdiv(C, 256), 256, 0, as_stream(stream)>>>(sums, count, mean, rstd, running_mean, running_var,
                                                                      nbt, momentum, eps, C);
   return launch_status();
@@ -479,9 +481,10 @@ extern "C" int lidk_bn_swish_bwd_reduce(const void* ds, const void* c, const flo
 template <typename T>
 __global__ void bn_swish_bwd_apply_kernel(const T* __restrict__ ds, const T* __restrict__ c, const float* __restrict__ mean,
                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                          const float* __restrict__ beta, const double* __restrict__ sums, double count,
+                                          const float* __restrict__ beta, const double* __restrict__ sums, double count_arg,
                                           T* __restrict__ dc, long M, int C, const double* __restrict__ sums_local,
                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const double count = count_arg > 0 ? count_arg : sums[2 * C];       // count <= 0: the global row count rides behind the sums
   if (blockIdx.x == 0) {        // parameter gradients from this rank's own sums (DDP averages them like any other gradient)
     for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
       if (dbeta) dbeta[ch] += (float)sums_local[ch];
@@ -518,7 +521,7 @@ extern "C" int lidk_bn_swish_bwd_apply(const void* ds, const void* c, const floa
                                        const float* gamma, const float* beta, const double* sums,
                                        const double* sums_local, double count, void* dc, float* dgamma, float* dbeta,
                                        int M, int C, int dtype, void* stream) {
-  if (!ds || !c || !mean || !rstd || !gamma || !beta || !sums || !sums_local || !dc || count <= 0 || M <= 0 || C <= 0 || (C & 3)) return LIDK_ERR_ARG;
+  if (!ds || !c || !mean || !rstd || !gamma || !beta || !sums || !sums_local || !dc || M <= 0 || C <= 0 || (C & 3)) return LIDK_ERR_ARG;
   hipStream_t s = as_stream(stream);
   LIDK_DISPATCH(dtype, bn_swish_bwd_apply_kernel<T><<<ew_blocks((long)M * C / 4), 256, 0, s>>>(
                            (const T*)ds, (const T*)c, mean, rstd, gamma, beta, sums, count, (T*)dc, M, C, sums_local, dgamma,

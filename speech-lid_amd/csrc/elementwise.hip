@@ -177,10 +177,17 @@ extern "C" int lidk_colsum(const void* x, int ldx, int xd, float* out, float* pa
   return launch_status();
 }
 
-extern "C" int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double* out, double* out2, void* stream) {
+__global__ void write_tail_f64_kernel(double* out, double* out2, int ncols, double tail) {
+  out[ncols] = tail;
+  if (out2) out2[ncols] = tail;
+}
+
+extern "C" int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double* out, double* out2, double tail,
+                                        void* stream) {
   if (!partial || !out || nparts <= 0 || ncols <= 0) return LIDK_ERR_ARG;
   colreduce_kernel<double, double, false><<<cdiv(ncols, 16), 1024, 0, as_stream(stream)>>>(partial, nparts, ncols, out,
                                                                                           (double*)nullptr, ncols, 1.0f, out2);
+  if (tail > 0) write_tail_f64_kernel<<<1, 1, 0, as_stream(stream)>>>(out, out2, ncols, tail);
   return launch_status();
 }
 

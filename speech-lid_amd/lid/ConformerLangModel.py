@@ -191,11 +191,19 @@ class ConformerMutiLangModel(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _layer_keep(self) -> List[bool]:
-        """Stochastic depth decisions with the reference's python-random stream (lid/conformer.py:460-466)."""
+        """Stochastic depth decisions (lid/conformer.py:460-466).  Single process: the reference's own stream (the global
+        python ``random``).  Data parallel: every rank must skip the SAME blocks (a skipped block's stage never issues its
+        gradient all-reduce), so the draws come from a dedicated generator keyed by (seed, training-forward count) that
+        nothing else - collate, callbacks, an uneven loader - can advance on one rank only."""
         n = self.cfg.n_blocks
         if not (self.training and self.use_stochastic_depth):
             return [True] * n
-        return [random.random() <= 1 - ((i + 1) / n) * (1 - self.stochastic_depth_p) for i in range(n)]
+        eng = self.lidk_engine
+        rng = random
+        if eng.on_stage_grads_ready is not None or eng.stat_allreduce is not None:
+            self._train_forwards = getattr(self, "_train_forwards", 0) + 1
+            rng = random.Random(eng.seed * 1000003 + self._train_forwards)
+        return [rng.random() <= 1 - ((i + 1) / n) * (1 - self.stochastic_depth_p) for i in range(n)]
 
     def features(self, x):
         if hasattr(x, "to_mel"):                      # lid.audio_processor.WaveBatch: features computed on the GPU

@@ -45,7 +45,7 @@ SIGNATURES = {
     "lidk_relu_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
     "lidk_colsum": (_I, [_P, _I, _I, _P, _P, _I, _I, _F, _P]),
     "lidk_transpose": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
-    "lidk_reduce_partials_f64": (_I, [_P, _I, _I, _P, _P, _P]),
+    "lidk_reduce_partials_f64": (_I, [_P, _I, _I, _P, _P, _D, _P]),
     "lidk_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "lidk_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_layernorm_param_grads": (_I, [_P, _I, _I, _P, _P, _P]),

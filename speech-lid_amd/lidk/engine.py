@@ -178,8 +178,10 @@ class _Work:
             S.dyTs = [e(M, d) for _ in range(4)]              # T-typed dx at: block output (x0.5), x3, x2, x1
             S.dc = e(M, ci)                                   # depthwise-conv output gradient (for its weight gradient)
             S.ds = e(M, ci)                                   # gradient at the BatchNorm+Swish output
-            S.sums = torch.empty(2 * ci, device=dev, dtype=torch.float64)        # BN backward sums: all ranks / this rank
-            S.sums_local = torch.empty(2 * ci, device=dev, dtype=torch.float64)
+            # BN backward sums (all ranks / this rank); element [2*ci] carries the row count, which the same all-reduce
+            # turns into the global count (ranks may hold different (B, T) shapes)
+            S.sums = torch.empty(2 * ci + 1, device=dev, dtype=torch.float64)
+            S.sums_local = torch.empty(2 * ci + 1, device=dev, dtype=torch.float64)
             S.dsc = f(B, max(cfg.heads, cfg.last_heads), T, (T + 31) // 32 * 32)     # attention dS rows (kept for the deferred dE)
             S.lnp = [f(L.LN_BWD_BLOCKS * 2 * d) for _ in range(5)]   # LayerNorm dgamma/dbeta partial rows: post, ff2, conv, attn, ff1
             self.sets.append(S)
@@ -192,8 +194,7 @@ class _Work:
         self.stat_parts = eng.k.dwconv_stat_parts(B, T)
         self.stat_partial = f(self.stat_parts * 2 * ci)
         self.dw_partial = f(B * ci * (max(cfg.conv_kernel_size, 31) + 1))
-        self.sums = torch.empty(2 * ci, device=dev, dtype=torch.float64)
-        self.sums_local = torch.empty(2 * ci, device=dev, dtype=torch.float64)
+        self.sums = torch.empty(2 * ci + 1, device=dev, dtype=torch.float64)        # (sum x, sum x^2) [2*ci] + row count
         self.dconv3 = f(cfg.n_mels, 3 * cfg.n_mels)
         self.logits: Dict[str, torch.Tensor] = {}
 
@@ -421,12 +422,13 @@ class Engine:
             pad_left = K // 2
             if training:                   # GLU fused into the depthwise conv's tile load; g is kept for the weight gradient
                 self.k.glu_dwconv_fwd(bb.y, dw2d, C["dwb"], bb.g, bb.c, w.stat_partial, B, T, pad_left)
-                self.k.reduce_partials_f64(w.stat_partial, w.stat_parts, 2 * ci, w.sums[:2 * ci])
+                self.k.reduce_partials_f64(w.stat_partial, w.stat_parts, 2 * ci, w.sums[:2 * ci + 1], tail=M)
             else:
                 self.k.glu_dwconv_fwd(bb.y, dw2d, C["dwb"], None, bb.c, None, B, T, pad_left)
         if part in ("all", "b"):
             if training:
-                self.k.bn_train_stats(w.sums[:2 * ci], M * self.world_size, bb.bn_mean, bb.bn_rstd, C["rm"], C["rv"], C["nbt"])
+                # count 0: read the (all-reduced) row count from w.sums[2*ci]
+                self.k.bn_train_stats(w.sums[:2 * ci + 1], 0, bb.bn_mean, bb.bn_rstd, C["rm"], C["rv"], C["nbt"])
             else:
                 self.k.bn_eval_stats(C["rm"], C["rv"], bb.bn_mean, bb.bn_rstd)
             self.k.bn_swish_fwd(bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], bb.s)
@@ -447,7 +449,7 @@ class Engine:
     def _bn_collective(self, w: _Work, ci: int, training: bool = True, sums=None):
         if self.stat_allreduce is None or not training:
             return None
-        t = (w.sums if sums is None else sums)[:2 * ci]
+        t = (w.sums if sums is None else sums)[:2 * ci + 1]              # sums + row count in one collective
         return lambda: self.stat_allreduce(t)
 
     def _enc_block_fwd(self, x, i, w: _Work, training: bool, part: str):
@@ -589,13 +591,14 @@ class Engine:
             self.k.gemm_nt(t1, C["w2"][1], ds, N=ci, K=d)
             self.k.bn_swish_bwd_reduce(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial)
             # sums is all-reduced in place by the SyncBN collective under DP; sums_local keeps this rank's share
-            self.k.reduce_partials_f64(w.partial, L.BN_PARTIAL_BLOCKS, 2 * ci, S.sums[:2 * ci], S.sums_local[:2 * ci])
+            self.k.reduce_partials_f64(w.partial, L.BN_PARTIAL_BLOCKS, 2 * ci, S.sums[:2 * ci + 1], S.sums_local[:2 * ci + 1],
+                                       tail=M)
         if part in ("all", "b"):
             # BatchNorm+Swish backward, depthwise-conv input gradient and GLU backward in one launch; the conv's weight
             # gradient (which needs dc materialised) goes with the other weight gradients
             dy1 = S.dy1.view(-1)[:M * 2 * ci].view(M, 2 * ci)
-            self.k.dwconv_bwd_input_bn_glu(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], S.sums[:2 * ci],
-                                           M * self.world_size, C["dw"].view(ci, K), bb.y, dy1, B, T, pad_left)
+            self.k.dwconv_bwd_input_bn_glu(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], S.sums[:2 * ci + 1],
+                                           0, C["dw"].view(ci, K), bb.y, dy1, B, T, pad_left)
             if wg:
                 self._conv_wgrad(w, bp, bb, S)
                 self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
@@ -632,8 +635,8 @@ class Engine:
         ci, K = C["dw"].shape[0], C["dw"].shape[2]
         ds = S.ds.view(-1)[:M * ci].view(M, ci)
         dc = S.dc.view(-1)[:M * ci].view(M, ci)
-        self.k.bn_swish_bwd_apply(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], S.sums[:2 * ci],
-                                  S.sums_local[:2 * ci], M * self.world_size, dc, C["dbn_w"], C["dbn_b"])
+        self.k.bn_swish_bwd_apply(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], S.sums[:2 * ci + 1],
+                                  S.sums_local[:2 * ci + 1], 0, dc, C["dbn_w"], C["dbn_b"])
         self.k.dwconv_bwd_weight(dc, bb.g, C["ddw"].view(ci, K), C["ddwb"], w.dw_partial, B, T, K // 2)
 
     def _block_wgrads(self, w: _Work, bp: _BlockParams, bb: _BlockBuf, S, post_norm: bool):

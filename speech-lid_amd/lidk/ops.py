@@ -142,8 +142,10 @@ def transpose(x, out):
     return out
 
 
-def reduce_partials_f64(partial, nparts, ncols, out, out2=None):
-    check(lib().lidk_reduce_partials_f64(_p(partial), nparts, ncols, _p(out), _p(out2), _stream()), "reduce_partials_f64")
+def reduce_partials_f64(partial, nparts, ncols, out, out2=None, tail=0.0):
+    """tail > 0 is stored at out[ncols] (and out2[ncols]): the row count behind the BatchNorm sums (one all-reduce for both)."""
+    check(lib().lidk_reduce_partials_f64(_p(partial), nparts, ncols, _p(out), _p(out2), float(tail), _stream()),
+          "reduce_partials_f64")
     return out
 
 

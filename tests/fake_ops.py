@@ -54,10 +54,12 @@ def transpose(x, out):
     return out
 
 
-def reduce_partials_f64(partial, nparts, ncols, out, out2=None):
-    out.copy_(partial[:nparts * ncols].view(nparts, ncols).double().sum(0))
+def reduce_partials_f64(partial, nparts, ncols, out, out2=None, tail=0.0):
+    out[:ncols].copy_(partial[:nparts * ncols].view(nparts, ncols).double().sum(0))
+    if tail > 0:
+        out[ncols] = tail
     if out2 is not None:
-        out2.copy_(out)
+        out2[:out.shape[0]].copy_(out)
     return out
 
 
@@ -230,6 +232,7 @@ def dwconv_bwd_input_glu(dc, w, y, dy, B, T, pad_left):
 def dwconv_bwd_input_bn_glu(ds, c, mean, rstd, gamma, beta, sums, count, w, y, dy, B, T, pad_left):
     dz, xh = _dz(ds, c, mean, rstd, gamma, beta)
     C = c.shape[1]
+    count = count if count > 0 else float(sums[2 * C])
     m0, m1 = (sums[:C] / count).float(), (sums[C:2 * C] / count).float()
     dc = gamma * rstd * (dz - m0 - xh * m1)
     dwconv_bwd_input_glu(dc, w, y, dy, B, T, pad_left)
@@ -247,6 +250,7 @@ def dwconv_bwd_weight(dc, g, dw, db, partial, B, T, pad_left):
 
 def bn_train_stats(sums, count, mean, rstd, running_mean, running_var, nbt, momentum=0.1, eps=1e-5):
     C = mean.shape[0]
+    count = count if count > 0 else float(sums[2 * C])
     mu = sums[:C] / count
     var = (sums[C:2 * C] / count - mu * mu).clamp_min(0)
     mean.copy_(mu.float())
@@ -287,6 +291,7 @@ def bn_swish_bwd_reduce(ds, c, mean, rstd, gamma, beta, partial):
 def bn_swish_bwd_apply(ds, c, mean, rstd, gamma, beta, sums, sums_local, count, dc, dgamma, dbeta):
     dz, xh = _dz(ds, c, mean, rstd, gamma, beta)
     C = c.shape[1]
+    count = count if count > 0 else float(sums[2 * C])
     m0, m1 = (sums[:C] / count).float(), (sums[C:2 * C] / count).float()
     dc.copy_((gamma * rstd * (dz - m0 - xh * m1)).to(dc.dtype))
     if dbeta is not None:
