@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Conformer-LID training throughput in audio-seconds/sec (BASELINE.json metric).
+"""Headline benchmark: Conformer-LID training throughput in audio-seconds/sec + validation Cavg (BASELINE.json metric).
 
+    python bench.py                                   # N = 1, 200 timed steps after 20 warm-up steps
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one pass of the whole hot path over one batch of synthetic input already resident in HBM:
 raw 3 s @ 16 kHz waveforms -> normalize + dither/pre-emphasis -> log-mel + SpecAugment (HIP) -> 12-layer d256 Conformer +
-one 14-language CTC head, forward and backward (HIP, bf16 MFMA GEMMs) -> [N>1: gradient all-reduce over RCCL, SyncBN
-statistics] -> global-norm clip(20) + Novograd + bf16 weight refresh (HIP) -> TriStage LR step.  Batch 64 per GPU (weak
+one 14-language CTC head, forward and backward (HIP, bf16 MFMA GEMMs) -> [N>1: gradient all-reduce over RCCL (bf16 payload),
+SyncBN statistics] -> global-norm clip(20) + Novograd + bf16 weight refresh (HIP) -> TriStage LR step.  Batch 64 per GPU (weak
 scaling), BASELINE.json configs[1]; nothing is skipped or cached between steps.  Stochastic depth is OFF in the headline
 number (every layer runs every step, matching the 21.67 GFLOP/utterance accounting of SURVEY 8d); pass
---stochastic-depth to time the reference default (p=0.7, ~16 % fewer executed blocks on average).
+--stochastic-depth to time the reference default (p=0.7, ~16 % fewer executed blocks on average).  The run exits non-zero
+if any timed step produced a non-finite loss.
 
-Prints ONE JSON line (rank 0) with the contract's fields plus:
-  roofline     : the dominant kernel (gemm_nt: every Linear / 1x1 conv forward and data gradient; two instantiations of
-                 the same 64x64-tile MFMA kernel, tile-pipelined for the wide K = 256 shapes):
-                 algorithmic bytes of every launch of one training step / their summed durations, each launch bracketed by
-                 HIP events on its own stream (HBM roofline: these K <= 1024 GEMMs are below the machine balance); the MFMA
-                 rate of the same launches and the weight-gradient kernel are reported in the same object
-  cpu_baseline : the CPU oracle (oracle/, torch fp32) running the same step on this host's cores, bounded sample
+Prints ONE JSON line (rank 0) with the contract's fields (``value`` = K steps of whole-job audio over the wall time between
+two barrier + synchronize brackets, max over ranks) plus:
+  chunks_ms_per_step / median_ms_per_step : the K steps split into 5 consecutive chunks by HIP events (no extra syncs)
+  roofline      : the dominant kernel (gemm_nt: every Linear / 1x1 conv forward and data gradient): algorithmic bytes of every
+                  launch of one training step / their summed durations, each launch bracketed by HIP events on its own stream
+                  (HBM roofline); MFMA rate of the same launches, the weight-gradient kernel, and ``features`` = the feature
+                  path (normalize, dither/pre-emphasis, STFT/mel/dB/SpecAugment: 4 L + 4*80 F bytes per utterance) likewise.
+                  ``traffic`` comes from a committed rocprofv3 --pmc pass of this command (``traffic_source`` names the file);
+                  it is not measured by this process
+  val_cavg      : (N = 1) the model keeps training on the learnable synthetic corpus for --cavg-steps more steps, then the
+                  held-out set is scored through the module's own val_loop (all 14 heads, CTC-confidence LID score,
+                  lid/eer.py::CAvg)
+  fit           : (N = 1) the same training through Trainer.fit INCLUDING DataLoader workers, collate, pinned H2D copies
+                  (what a user of the launcher gets from in-memory data); never used for ``value``
+  cpu_baseline  : the CPU oracle (oracle/, torch fp32) running the same step on all of this host's cores, bounded sample
 """
 import argparse
 import json
@@ -37,6 +47,9 @@ HBM_PEAK_GBS = 8000.0               # HBM3E peak, same guide ("HBM": 8 TB/s spec
 SECONDS = 3.0
 BATCH = 64
 N_LANGS = 14
+SETUP_ROUNDS = 3                    # visits of every language before warm-up (eager, capture, replay of each head's graphs)
+PMC_FILE = os.path.join("profiles", "r02", "pmc_traffic.json")
+PMC_FALLBACK = os.path.join("profiles", "r01", "pmc_traffic.json")
 
 
 def build(args, rank, world, device):
@@ -45,11 +58,13 @@ def build(args, rank, world, device):
     from lid import hydra_lite
     import lid.main as launcher
     seed_everything(0)
+    per_lang = args.batch * world * args.resident
     ov = [f"trainer.gpu_id={device.index}", "trainer.use_amp=true", f"trainer.ddp={'true' if world > 1 else 'false'}",
           f"trainer.world_size={world}", f"trainer.local_rank={rank}", "trainer.backend=nccl", "trainer.total_epoch=1000",
-          f"data.sampler_common.train_batch_size={args.batch}", f"data.synthetic.items_per_lang={max(args.batch * world, 8)}",
-          "data.synthetic.val_items_per_lang=2", "data.synthetic.test_items_per_lang=2", "module.interval=1000000",
-          "trainer.log_interval=1000000", f"model.n_blocks={args.blocks}"]
+          f"data.sampler_common.train_batch_size={args.batch}", f"data.synthetic.items_per_lang={per_lang}",
+          f"data.synthetic.val_items_per_lang={args.val_items}", "data.synthetic.test_items_per_lang=2",
+          "module.interval=1000000", "trainer.log_interval=1000000", f"model.n_blocks={args.blocks}",
+          f"module.optimizer_param.lr={args.lr}"]
     cfg = hydra_lite.load_config(os.path.join(ROOT, "speech-lid_amd", "lid", "conf"), "synthetic_cfg2", ov)
     module, sets, params = launcher.build(cfg, rank, world)
     module.model.use_stochastic_depth = bool(args.stochastic_depth)
@@ -59,28 +74,69 @@ def build(args, rank, world, device):
     trainer.dataloader_params = params
     module.point_trainer(trainer)
     trainer.trainer_prepare()
+    # the TriStage schedule spans exactly the optimizer steps this run takes (set-up, warm-up, timed, instrumented, Cavg phase)
+    trainer.total_steps = SETUP_ROUNDS * N_LANGS + args.warmup + args.steps + 2 + max(args.cavg_steps, 0)
+    trainer.optimizer, trainer.lr_scheduler, trainer.scheduler_param = module.config_optim()
     trainer._zero_grad()
-    return cfg, module, trainer, sets["train"]
+    return cfg, module, trainer, sets
 
 
-def resident_batches(ds, rank, world, device, batch):
-    """One batch per language, built once and moved to HBM (each rank gets different utterances of the same language)."""
-    out = []
+class CachedDataset(torch.utils.data.Dataset):
+    """The synthetic corpus materialised once in host memory (items are pure functions of the seed): what remains per batch
+    is indexing, collate (padding, SpecAugment span draws), pinning and the H2D copy - the DataLoader path of a real corpus
+    held in memory."""
+
+    def __init__(self, ds):
+        self.ds = ds
+        self.items = [ds[i] for i in range(len(ds))]
+        self.samplers, self.train, self.type = ds.samplers, ds.train, ds.type
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+    def collate_fn(self, batch):
+        return self.ds.collate_fn(batch)
+
+
+def resident_batches(ds, rank, world, device, batch, resident):
+    """``resident`` batches per language, built once and moved to HBM (each rank gets different utterances of the language).
+    Order: round-robin over languages, so consecutive steps train different heads."""
     per_lang = len(ds) // N_LANGS
-    for k in range(N_LANGS):
-        base = k * per_lang
-        idx = [base + (rank * batch + j) % per_lang for j in range(batch)]
-        b = list(ds.collate_fn([ds[i] for i in idx]))
-        b[0] = b[0].to(device)
-        for j in (1, 2, 3, 5):
-            b[j] = b[j].to(device)
-        out.append(b)
+    out = []
+    for r in range(resident):
+        for k in range(N_LANGS):
+            base = k * per_lang
+            idx = [base + ((r * world + rank) * batch + j) % per_lang for j in range(batch)]
+            b = list(ds.collate_fn([ds[i] for i in idx]))
+            b[0] = b[0].to(device)
+            for j in (1, 2, 3, 5):
+                b[j] = b[j].to(device)
+            out.append(b)
     return out
 
 
-def cpu_baseline(module, ds, steps, batch, threads):
+def host_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, usable
+
+
+def cpu_baseline(module, ds, steps, warm, batch, threads, cpu_model):
     """The oracle (torch-CPU fp32 restatement, pinned to the reference) running the same training step on host cores."""
-    import random
     from oracle import conformer as oc
     from oracle import features as of
     from oracle import optim as oo
@@ -93,7 +149,7 @@ def cpu_baseline(module, ds, steps, batch, threads):
     states = {k: oo.NovogradState() for k in names}
     per_lang = len(ds) // N_LANGS
     times = []
-    for step in range(steps + 1):
+    for step in range(steps + warm):
         k = step % N_LANGS
         lang = list(cfg.lang2vocab)[k]
         items = [ds[k * per_lang + j % per_lang] for j in range(batch)]
@@ -119,42 +175,48 @@ def cpu_baseline(module, ds, steps, batch, threads):
                 sd[n].grad = None
                 sd[n].requires_grad_(False)
             sd.update(opts.bn_buffers)
-        if step > 0:
+        if step >= warm:
             times.append(time.time() - t0)
-    t = sum(times) / len(times)
-    return {"value": round(batch * SECONDS / t, 2), "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
-            "sample": f"{steps} steps of batch {batch} (3 s utterances) after 1 warm-up step, {t:.2f} s/step, fp32 torch-CPU oracle"}
+    times.sort()
+    t = times[len(times) // 2]
+    return {"value": round(batch * SECONDS / t, 2), "unit": "audio-seconds/sec", "cores": threads, "cpu_model": cpu_model,
+            "kind": "port",
+            "sample": f"median of {steps} steps of batch {batch} (3 s utterances) after {warm} warm-up steps, {t:.2f} s/step, "
+                      f"fp32 torch-CPU oracle with torch.set_num_threads({threads}) = every core this process may use"}
 
 
 def _pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/r01/pmc_traffic.json, produced by
-    tools/gpu_pmc_bench.sh on this same command): FETCH_SIZE and WRITE_SIZE are in KB; FETCH_SIZE counts 64 B per 128-B
-    request on gfx950 and is doubled, as MI355X_MICROARCH.md (HBM) prescribes; WRITE_SIZE is exact for 16-byte stores."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    raw = json.load(open(path))
-    hits = [v for name, v in raw.items() if kernel_prefix in name and "FETCH_SIZE_KB_per_launch_raw" in v
-            and "WRITE_SIZE_KB_per_launch_raw" in v]
-    n = sum(v.get("launches_fetch", 0) for v in hits)
-    if not n:
-        return None
-    kb = sum((2.0 * v["FETCH_SIZE_KB_per_launch_raw"] + v["WRITE_SIZE_KB_per_launch_raw"]) * v["launches_fetch"] for v in hits)
-    return round(kb / n * 1024.0)                                    # launch-weighted mean over the kernel's instantiations
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (tools/gpu_pmc_bench.sh on this same
+    command): FETCH_SIZE and WRITE_SIZE are in KB; FETCH_SIZE counts 64 B per 128-B request on gfx950 and is doubled, as
+    MI355X_MICROARCH.md (HBM) prescribes; WRITE_SIZE is exact for 16-byte stores.  -> (bytes, source file) or (None, None)."""
+    for rel in (PMC_FILE, PMC_FALLBACK):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        raw = json.load(open(path))
+        hits = [v for name, v in raw.items() if kernel_prefix in name and "FETCH_SIZE_KB_per_launch_raw" in v
+                and "WRITE_SIZE_KB_per_launch_raw" in v]
+        n = sum(v.get("launches_fetch", 0) for v in hits)
+        if not n:
+            continue
+        kb = sum((2.0 * v["FETCH_SIZE_KB_per_launch_raw"] + v["WRITE_SIZE_KB_per_launch_raw"]) * v["launches_fetch"] for v in hits)
+        return round(kb / n * 1024.0), rel                              # launch-weighted mean over the kernel's instantiations
+    return None, None
 
 
-def gemm_roofline(trainer, batches, step_fn):
+def roofline(trainer, batches, step_fn):
     """Bracket every launch of the dominant kernel (gemm_nt: every Linear / 1x1 conv forward and its data gradient) of ONE
-    training step with HIP events on the launch stream, and the weight-gradient GEMM (gemm_tn) likewise.  With K = 256..1024
-    these GEMMs sit below the machine balance (about 150 FLOP per algorithmic byte against 2500 TF/s / 8 TB/s = 312), so the
-    roofline that bounds them is HBM: achieved = algorithmic bytes (operands read once, outputs written once; DESIGN.md
-    section 5) / measured time.  The MFMA rate of the same launches is reported beside it.  The step runs through the eager
-    launch path (events cannot be recorded inside a hipGraph capture); kernels and shapes are those of the timed steps.  The
-    cost of an empty event bracket is measured and subtracted."""
+    training step with HIP events on the launch stream, the weight-gradient GEMM (gemm_tn) and the feature path likewise.
+    With K = 256..1024 these GEMMs sit below the machine balance (about 150 FLOP per algorithmic byte against
+    2500 TF/s / 8 TB/s = 312), so the roofline that bounds them is HBM: achieved = algorithmic bytes (operands read once,
+    outputs written once) / measured time.  The MFMA rate of the same launches is reported beside it.
+    The step runs through the eager launch path (events cannot be recorded inside a hipGraph capture); kernels and shapes
+    are those of the timed steps.  The cost of an empty event bracket is measured and subtracted."""
+    from lid.audio_processor import WaveBatch
     eng = trainer.engine
     k = eng.k
-    orig_nt, orig_tn = k.gemm_nt, k.gemm_tn
-    rec = {"nt": [], "tn": []}
+    orig_nt, orig_tn, orig_mel = k.gemm_nt, k.gemm_tn, WaveBatch._compute_mel
+    rec = {"nt": [], "tn": [], "feat": []}
 
     def esz(t):
         return t.element_size()
@@ -182,14 +244,19 @@ def gemm_roofline(trainer, batches, step_fn):
         nbytes = m * n1 * esz(X) + m * n2 * esz(Y) + n1 * n2 * 4
         return bracket("tn", orig_tn, 2.0 * m * n1 * n2, nbytes, X, Y, C, *a, M=M, N1=N1, N2=N2, **kw)
 
+    def timed_mel(self):
+        Bn, Ln = self.wav.shape
+        F_ = 1 + (Ln + 2 * self.pad) // 160
+        return bracket("feat", lambda: orig_mel(self), 0.0, Bn * (4 * Ln + 4 * self.n_mels * F_))
+
     graphs_on = eng.graphs.enabled
     eng.graphs.enabled = False
-    k.gemm_nt, k.gemm_tn = timed_nt, timed_tn
+    k.gemm_nt, k.gemm_tn, WaveBatch._compute_mel = timed_nt, timed_tn, timed_mel
     try:
         step_fn(0, batches[0])
         torch.cuda.synchronize()
     finally:
-        k.gemm_nt, k.gemm_tn = orig_nt, orig_tn
+        k.gemm_nt, k.gemm_tn, WaveBatch._compute_mel = orig_nt, orig_tn, orig_mel
         eng.graphs.enabled = graphs_on
     empty = []
     for _ in range(200):
@@ -205,16 +272,28 @@ def gemm_roofline(trainer, batches, step_fn):
 
     ms, fl, by, n = tot("nt")
     ms2, fl2, by2, n2 = tot("tn")
+    ms3, _, by3, n3 = tot("feat")
     gbs = by / (ms * 1e-3) / 1e9
+    traffic, src = _pmc_traffic("gemm_nt_bf16_")
+    traffic2, _ = _pmc_traffic("gemm_tn_bf16_kernel")
+    feat = None
+    if n3 and ms3 > 0:
+        f_gbs = by3 / (ms3 * 1e-3) / 1e9
+        feat = {"bound": "hbm", "achieved": round(f_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_gbs / HBM_PEAK_GBS, 4),
+                "kernels": "normalize_wav + dither_preemph + stft_mel + db_floor_mask (one batch)", "ms_per_batch": round(ms3, 4),
+                "algorithmic_bytes_per_batch": int(by3)}
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": _pmc_traffic("gemm_nt_bf16_"), "kernel": "gemm_nt (gemm_nt_bf16_pipe_kernel + gemm_nt_bf16_direct_kernel, 64x64 tiles)",
+            "traffic": traffic, "traffic_source": (f"{src} (committed rocprofv3 --pmc pass of this command; not measured in this run)"
+                                                   if src else None),
+            "kernel": "gemm_nt (gemm_nt_bf16_pipe_kernel + gemm_nt_bf16_direct_kernel, 64x64 tiles)",
             "launches_per_step": n, "avg_launch_us": round(ms * 1e3 / n, 2), "kernel_ms_per_step": round(ms, 3),
             "algorithmic_bytes_per_launch": round(by / n), "event_bracket_overhead_us": round(ovh * 1e3, 2),
             "mfma": {"achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
             "wgrad_kernel": {"kernel": "gemm_tn_bf16_kernel<64,64>", "launches_per_step": n2,
                              "avg_launch_us": round(ms2 * 1e3 / n2, 2), "GB/s": round(by2 / (ms2 * 1e-3) / 1e9, 1),
-                             "TFLOP/s": round(fl2 / (ms2 * 1e-3) / 1e12, 1), "traffic": _pmc_traffic("gemm_tn_bf16_kernel")}}
+                             "TFLOP/s": round(fl2 / (ms2 * 1e-3) / 1e12, 1), "traffic": traffic2},
+            "features": feat}
 
 
 def phase_times(trainer, batches, step_fn):
@@ -247,17 +326,90 @@ def phase_times(trainer, batches, step_fn):
             "clip_optimizer_refresh": round(ev["bwd"].elapsed_time(ev["opt"]), 3)}
 
 
+def cavg_phase(args, module, trainer, batches, step_fn, first_step):
+    """Keep training on the learnable corpus (the timed steps were ordinary training steps of the same run), then score the
+    held-out utterances through the module's own validation loop."""
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.cavg_steps):
+        out, loss, _ = step_fn(first_step + i, batches[i % len(batches)], batches[(i + 1) % len(batches)])
+        last = loss
+    torch.cuda.synchronize()
+    train_s = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    trainer._evaluate(0)
+    torch.cuda.synchronize()
+    val = dict(module.last_val)
+    return {"val_cavg": val["cavg"], "val_eer": round(float(val["eer"]), 4), "val_cer": round(float(val["val_wer"]), 4),
+            "val_loss": round(float(val["val_loss"]), 4), "train_loss_last": round(float(last), 4) if last is not None else None,
+            "optimizer_steps_total": int(trainer.current_step), "extra_train_steps": args.cavg_steps,
+            "extra_train_seconds": round(train_s, 1), "validation_seconds": round(time.perf_counter() - t1, 1),
+            "held_out_utterances": len(trainer.val_dataset), "chance": 0.5,
+            "note": "learnable synthetic corpus (tone-pair transcripts, language-specific symbol tables); CTC-confidence LID "
+                    "score of all 14 heads per utterance -> score_to_prob -> lid/eer.py::CAvg"}
+
+
+class _EpochTimer:
+    """Callback for the Trainer.fit measurement: wall time of each training epoch (device drained at the end of the epoch)."""
+
+    def __init__(self):
+        self.trainer, self.spans, self._t = None, [], None
+
+    def add_trainer(self, trainer):
+        self.trainer = trainer
+
+    def before_train_epoch(self, value):
+        torch.cuda.synchronize()
+        self._t = time.perf_counter()
+
+    def after_train_epoch(self, value):
+        torch.cuda.synchronize()
+        self.spans.append(time.perf_counter() - self._t)
+
+    def after_train_loop(self, value):
+        pass
+
+    after_eval_loop = after_eval_epoch = test_loop_end = after_train_loop
+
+
+def fit_throughput(args, cfg, module, sets, params, device):
+    """Trainer.fit over the cached corpus with DataLoader workers: per-epoch wall time -> audio-s/s including data loading."""
+    from ccml.trainer import Trainer
+    train = CachedDataset(sets["train"])
+    timer = _EpochTimer()
+    tcfg = dict(cfg["trainer"])
+    tcfg.update(total_epoch=args.fit_epochs, eval_interval=10 ** 6)
+    trainer = Trainer(callbacks=[timer], loggers=[], **tcfg)
+    p = dict(params)
+    p.update(num_workers=args.fit_workers, prefetch_factor=2, pin_memory=True)
+    trainer.fit(module, train_dataset=train, val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=p)
+    n_batches = len(trainer.train_dataloader)
+    spans = timer.spans[1:] or timer.spans                        # the first epoch starts the workers and captures graphs
+    best = sorted(spans)[len(spans) // 2]
+    return {"audio_s_per_s": round(n_batches * args.batch * SECONDS / best, 1), "ms_per_step": round(best / n_batches * 1e3, 3),
+            "batches_per_epoch": n_batches, "epochs_timed": len(spans), "num_workers": args.fit_workers,
+            "includes": "DataLoader worker processes (in-memory corpus), collate with SpecAugment span draws, pinned-memory H2D "
+                        "copy of raw waveforms, GPU features, training step; median epoch after the first"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--chunks", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--blocks", type=int, default=12)
+    ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--resident", type=int, default=2, help="resident batches per language")
+    ap.add_argument("--val-items", type=int, default=16, help="held-out utterances per language")
     ap.add_argument("--stochastic-depth", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cavg-steps", type=int, default=3000, help="extra training steps before the validation Cavg (0 = skip)")
+    ap.add_argument("--fit-epochs", type=int, default=4, help="epochs of the Trainer.fit measurement (0 = skip)")
+    ap.add_argument("--fit-workers", type=int, default=4)
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -271,13 +423,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        args.cavg_steps = 0                      # the Cavg / fit / CPU legs belong to the N = 1 run (see the docstring)
+        args.fit_epochs = 0
 
-    cfg, module, trainer, ds = build(args, rank, world, device)
-    batches = resident_batches(ds, rank, world, device, args.batch)
-    n_total = args.warmup + args.steps + 8
+    cfg, module, trainer, sets = build(args, rank, world, device)
+    ds = sets["train"]
+    batches = resident_batches(ds, rank, world, device, args.batch, args.resident)
+    nb = len(batches)
+    n_total = 10 ** 9
 
     def step_fn(i, batch, upcoming=None):
-        trainer.train_step(i, batch, n_total, upcoming)
+        return trainer.train_step(i, batch, n_total, upcoming)
 
     def sync():
         if world > 1:
@@ -287,17 +443,29 @@ def main():
     # Untimed set-up (the analogue of JIT compilation): each language head's block sequence is captured into a hipGraph on
     # its second use, so visit every language three times before the contract's W warm-up steps.  These are ordinary training
     # steps; nothing they compute is reused by the timed steps.
+    it = 0
     if trainer.engine.graphs.enabled and not args.stochastic_depth:
-        for i in range(3 * N_LANGS):
-            step_fn(i, batches[i % N_LANGS])
+        for _ in range(SETUP_ROUNDS * N_LANGS):
+            step_fn(it, batches[it % nb])
+            it += 1
     # From here on every step also starts the NEXT batch's feature kernels (normalize, dither, STFT/mel) on the feature
     # stream, as Trainer.fit does: each timed step still contains exactly one batch's worth of feature work.
-    for i in range(args.warmup):
-        step_fn(i, batches[i % N_LANGS], batches[(i + 1) % N_LANGS])
+    for _ in range(args.warmup):
+        step_fn(it, batches[it % nb], batches[(it + 1) % nb])
+        it += 1
+    chunks = max(1, min(args.chunks, args.steps))
+    bounds = [args.steps * c // chunks for c in range(chunks + 1)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(chunks + 1)]
+    losses = []
     sync()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
-        step_fn(args.warmup + i, batches[(args.warmup + i) % N_LANGS], batches[(args.warmup + i + 1) % N_LANGS])
+        _, loss, _ = step_fn(it, batches[it % nb], batches[(it + 1) % nb])
+        it += 1
+        losses.append(loss)
+        if i + 1 in bounds[1:]:
+            marks[bounds.index(i + 1, 1)].record()
     host_issue = time.perf_counter() - t0          # host time to enqueue the K steps (no device sync inside)
     sync()
     elapsed = time.perf_counter() - t0
@@ -305,17 +473,26 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    loss_vals = torch.stack([l.float() for l in losses]).cpu()
+    finite = bool(torch.isfinite(loss_vals).all())
+    chunk_ms = [marks[c].elapsed_time(marks[c + 1]) / max(bounds[c + 1] - bounds[c], 1) for c in range(chunks)]
 
     phases = phase_times(trainer, batches, step_fn)      # every rank runs these extra steps (they contain collectives)
-    roof = gemm_roofline(trainer, batches, step_fn)
+    roof = roofline(trainer, batches, step_fn)
+    it += 2
     if world > 1:
         dist.barrier()
-    cpu = None
+    cavg = fit = cpu = None
+    if args.cavg_steps > 0:
+        cavg = cavg_phase(args, module, trainer, batches, step_fn, it)
+    if args.fit_epochs > 0:
+        fit = fit_throughput(args, cfg, module, sets, trainer.dataloader_params, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = min(os.cpu_count() or 1, 16)
-        cpu = cpu_baseline(module, ds, args.cpu_steps, args.cpu_batch, threads)
+        cpu_model, usable = host_info()
+        cpu = cpu_baseline(module, ds, args.cpu_steps, 2, args.cpu_batch, usable, cpu_model)
     if rank == 0:
         audio_s = world * args.batch * SECONDS * args.steps
+        med = sorted(chunk_ms)[len(chunk_ms) // 2]
         line = {"metric": "audio-seconds/sec LID training, Conformer d256", "value": round(audio_s / elapsed, 1),
                 "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -323,12 +500,18 @@ def main():
                 "config": {"workload": f"ConformerLangModel {args.blocks}-layer d256, 14-lang CTC heads, log-mel 80-bin, "
                                        f"3 s@16 kHz, batch={args.batch}/GPU, Novograd+clip, features on GPU",
                            "global_batch": world * args.batch, "utterance_seconds": SECONDS,
-                           "parallelism": f"dp{world}", "stochastic_depth": bool(args.stochastic_depth)},
+                           "parallelism": f"dp{world}", "stochastic_depth": bool(args.stochastic_depth),
+                           "grad_payload": trainer.grad_compress if world > 1 else None},
+                "chunks_ms_per_step": [round(c, 3) for c in chunk_ms], "median_ms_per_step": round(med, 3),
+                "value_at_median": round(world * args.batch * SECONDS / (med * 1e-3), 1),
+                "loss_first_last": [round(float(loss_vals[0]), 4), round(float(loss_vals[-1]), 4)], "loss_finite": finite,
                 "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 3), "phases_ms": phases, "roofline": roof,
-                "cpu_baseline": cpu}
+                "val_cavg": cavg["val_cavg"] if cavg else None, "cavg": cavg, "fit": fit, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if not finite:
+        raise SystemExit("bench.py: a timed training step produced a non-finite loss")
 
 
 if __name__ == "__main__":

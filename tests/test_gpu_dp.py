@@ -14,7 +14,7 @@ from conftest import PKG, ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir, amp, backend="gloo", force_ddp=False, tag=""):
+def _worker(rank, world, port, out_dir, amp, backend="gloo", force_ddp=False, tag="", compress="none"):
     sys.path[:0] = [ROOT, PKG]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from ccml import seed_everything
@@ -26,7 +26,7 @@ def _worker(rank, world, port, out_dir, amp, backend="gloo", force_ddp=False, ta
           "data.feature.mask_times=0", f"data.sampler_common.train_batch_size={4 // world}", "data.synthetic.items_per_lang=8",
           "data.synthetic.val_items_per_lang=2", "data.synthetic.seconds=0.5", f"trainer.ddp={'true' if (world > 1 or force_ddp) else 'false'}",
           f"trainer.world_size={world}", f"trainer.local_rank={rank}", f"trainer.backend={backend}", f"trainer.master_port={port}",
-          "module.interval=1000", "trainer.log_interval=1000"]
+          "module.interval=1000", "trainer.log_interval=1000", f"+trainer.grad_compress={compress}"]
     cfg = hydra_lite.load_config(os.path.join(PKG, "lid", "conf"), "synthetic_cfg1", ov)
     module, sets, params = launcher.build(cfg, rank, world)
     module.model.lidk_engine.cfg.pos_dropout = 0.0
@@ -40,13 +40,16 @@ def _worker(rank, world, port, out_dir, amp, backend="gloo", force_ddp=False, ta
                os.path.join(out_dir, f"w{world}_r{rank}{tag}.pt"))
 
 
-@pytest.mark.parametrize("amp", [False])
-def test_two_ranks_match_one_process_on_gpu(tmp_path, amp):
+@pytest.mark.parametrize("compress", ["none", "bf16"])
+def test_two_ranks_match_one_process_on_gpu(tmp_path, compress):
+    """compress = gradient payload of the exchange: f32 ('none', exact up to summation order) or bf16 (the default on the GPU:
+    each gradient element is rounded to 8 significant bits once per rank before the sum)."""
+    amp = False
     ctx = mp.get_context("spawn")
     p = ctx.Process(target=_worker, args=(0, 1, 29711, str(tmp_path), amp))
     p.start(); p.join(400)
     assert p.exitcode == 0
-    procs = [ctx.Process(target=_worker, args=(r, 2, 29713, str(tmp_path), amp)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29713, str(tmp_path), amp, "gloo", False, "", compress)) for r in range(2)]
     [q.start() for q in procs]
     [q.join(500) for q in procs]
     assert [q.exitcode for q in procs] == [0, 0]
@@ -57,8 +60,9 @@ def test_two_ranks_match_one_process_on_gpu(tmp_path, amp):
         assert torch.equal(r0[k], r1[k]), f"ranks diverged on {k}"
         if one[k].is_floating_point() and not k.endswith(("conv.net.4.conv.bias", "conv.net.5.running_mean")):
             worst = max(worst, float((r0[k] - one[k]).abs().max()))
-            np.testing.assert_allclose(r0[k].numpy(), one[k].numpy(), rtol=5e-3, atol=5e-5, err_msg=k)
-    print(f"[dp 2x2 vs 1x4] max |param diff| = {worst:.3e}")
+            rtol, atol = (5e-3, 5e-5) if compress == "none" else (5e-2, 1e-3)
+            np.testing.assert_allclose(r0[k].numpy(), one[k].numpy(), rtol=rtol, atol=atol, err_msg=k)
+    print(f"[dp 2x2 vs 1x4, payload {compress}] max |param diff| = {worst:.3e}")
 
 
 def test_single_rank_rccl_process_group_with_graph_capture(tmp_path):

@@ -84,8 +84,10 @@ def test_trainer_fit_ragged_batches(tmp_path, monkeypatch):
 
 
 def test_bench_contract_small():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--blocks", "2", "--steps", "3", "--warmup", "1",
-                          "--cpu-steps", "1", "--cpu-batch", "2", "--batch", "8"], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--blocks", "2", "--steps", "10", "--warmup", "2",
+                          "--cpu-steps", "1", "--cpu-batch", "2", "--batch", "8", "--cavg-steps", "30", "--val-items", "2",
+                          "--fit-epochs", "2", "--fit-workers", "2", "--resident", "1"],
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -95,6 +97,12 @@ def test_bench_contract_small():
     assert line["value"] > 0 and roof["bound"] == "hbm" and roof["unit"] == "GB/s" and 0 < roof["frac"] < 1
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0 < roof["mfma"]["frac"] < 1
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    assert line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["cpu_model"]
+    assert line["loss_finite"] is True and len(line["chunks_ms_per_step"]) == 5 and line["median_ms_per_step"] > 0
+    assert roof["traffic_source"] is None or "not measured in this run" in roof["traffic_source"]
+    assert roof["features"]["unit"] == "GB/s" and 0 < roof["features"]["frac"] < 1
+    assert 0.0 <= line["val_cavg"] <= 1.0 and line["cavg"]["held_out_utterances"] == 28
+    assert line["fit"]["audio_s_per_s"] > 0 and "DataLoader" in line["fit"]["includes"]
 
 
 def test_reference_schema_yaml_trains_from_disk(tmp_path, monkeypatch):
