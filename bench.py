@@ -118,7 +118,14 @@ def resident_batches(ds, rank, world, device, batch, resident):
     return out
 
 
+def log(msg):
+    """Progress to stderr (the JSON line is the only thing on stdout); also keeps a long run visibly alive."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def host_info():
+    """(CPU model string, cores this process may actually use) - the smaller of the scheduler affinity and the cgroup CPU
+    quota (a container on a shared host sees every core in the affinity mask but is throttled to its quota)."""
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -132,11 +139,24 @@ def host_info():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                usable = max(1, min(usable, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
     return model, usable
 
 
-def cpu_baseline(module, ds, steps, warm, batch, threads, cpu_model):
-    """The oracle (torch-CPU fp32 restatement, pinned to the reference) running the same training step on host cores."""
+def cpu_baseline(module, ds, steps, warm, batch, threads, cpu_model, budget_s=40.0):
+    """The oracle (torch-CPU fp32 restatement, pinned to the reference) running the same training step on host cores.
+    Bounded: stops early (never before 3 timed steps) once ``budget_s`` seconds of CPU work have been spent."""
     from oracle import conformer as oc
     from oracle import features as of
     from oracle import optim as oo
@@ -149,7 +169,10 @@ def cpu_baseline(module, ds, steps, warm, batch, threads, cpu_model):
     states = {k: oo.NovogradState() for k in names}
     per_lang = len(ds) // N_LANGS
     times = []
+    began = time.time()
     for step in range(steps + warm):
+        if len(times) >= 3 and time.time() - began > budget_s:
+            break
         k = step % N_LANGS
         lang = list(cfg.lang2vocab)[k]
         items = [ds[k * per_lang + j % per_lang] for j in range(batch)]
@@ -177,6 +200,8 @@ def cpu_baseline(module, ds, steps, warm, batch, threads, cpu_model):
             sd.update(opts.bn_buffers)
         if step >= warm:
             times.append(time.time() - t0)
+        log(f"cpu baseline step {step + 1}/{steps + warm}: {time.time() - t0:.2f} s")
+    steps = len(times)
     times.sort()
     t = times[len(times) // 2]
     return {"value": round(batch * SECONDS / t, 2), "unit": "audio-seconds/sec", "cores": threads, "cpu_model": cpu_model,
@@ -334,12 +359,19 @@ def cavg_phase(args, module, trainer, batches, step_fn, first_step):
     for i in range(args.cavg_steps):
         out, loss, _ = step_fn(first_step + i, batches[i % len(batches)], batches[(i + 1) % len(batches)])
         last = loss
+        if (i + 1) % 500 == 0:
+            log(f"cavg phase: {i + 1}/{args.cavg_steps} extra steps, loss {float(loss):.3f}, lr {trainer.optimizer.param_groups[0]['lr']:.5f}")
+        if args.cavg_eval_every > 0 and (i + 1) % args.cavg_eval_every == 0 and i + 1 < args.cavg_steps:
+            trainer._evaluate(0)                       # exploration aid: intermediate validation (not part of the default run)
+            log(f"cavg phase: step {i + 1} validation {module.last_val}")
+            trainer.model.train()
     torch.cuda.synchronize()
     train_s = time.perf_counter() - t0
     t1 = time.perf_counter()
     trainer._evaluate(0)
     torch.cuda.synchronize()
     val = dict(module.last_val)
+    log(f"cavg phase: validation {val}")
     return {"val_cavg": val["cavg"], "val_eer": round(float(val["eer"]), 4), "val_cer": round(float(val["val_wer"]), 4),
             "val_loss": round(float(val["val_loss"]), 4), "train_loss_last": round(float(last), 4) if last is not None else None,
             "optimizer_steps_total": int(trainer.current_step), "extra_train_steps": args.cavg_steps,
@@ -375,19 +407,25 @@ class _EpochTimer:
 def fit_throughput(args, cfg, module, sets, params, device):
     """Trainer.fit over the cached corpus with DataLoader workers: per-epoch wall time -> audio-s/s including data loading."""
     from ccml.trainer import Trainer
+    from ccml.utils.profile import _time_cost_recoder as rec
     train = CachedDataset(sets["train"])
     timer = _EpochTimer()
     tcfg = dict(cfg["trainer"])
     tcfg.update(total_epoch=args.fit_epochs, eval_interval=10 ** 6)
     trainer = Trainer(callbacks=[timer], loggers=[], **tcfg)
     p = dict(params)
-    p.update(num_workers=args.fit_workers, prefetch_factor=2, pin_memory=True)
+    p.update(num_workers=args.fit_workers, prefetch_factor=4, pin_memory=True, persistent_workers=args.fit_workers > 0)
+    rec._clear()
     trainer.fit(module, train_dataset=train, val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=p)
     n_batches = len(trainer.train_dataloader)
+    steps_all = max(n_batches * args.fit_epochs, 1)
+    host = {k: round(v / steps_all * 1e3, 3) for k, v in rec.values_map.items()}      # host ms per step, all epochs
+    log(f"fit: epoch seconds {[round(x, 2) for x in timer.spans]}, host ms/step by section {host}")
     spans = timer.spans[1:] or timer.spans                        # the first epoch starts the workers and captures graphs
     best = sorted(spans)[len(spans) // 2]
     return {"audio_s_per_s": round(n_batches * args.batch * SECONDS / best, 1), "ms_per_step": round(best / n_batches * 1e3, 3),
             "batches_per_epoch": n_batches, "epochs_timed": len(spans), "num_workers": args.fit_workers,
+            "epoch_seconds": [round(x, 3) for x in timer.spans], "host_ms_per_step": host,
             "includes": "DataLoader worker processes (in-memory corpus), collate with SpecAugment span draws, pinned-memory H2D "
                         "copy of raw waveforms, GPU features, training step; median epoch after the first"}
 
@@ -408,6 +446,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cavg-steps", type=int, default=3000, help="extra training steps before the validation Cavg (0 = skip)")
+    ap.add_argument("--cavg-eval-every", type=int, default=0, help="also validate every K extra steps (exploration aid)")
     ap.add_argument("--fit-epochs", type=int, default=4, help="epochs of the Trainer.fit measurement (0 = skip)")
     ap.add_argument("--fit-workers", type=int, default=4)
     args = ap.parse_args()
@@ -428,7 +467,9 @@ def main():
 
     cfg, module, trainer, sets = build(args, rank, world, device)
     ds = sets["train"]
+    log("model built; materialising resident batches")
     batches = resident_batches(ds, rank, world, device, args.batch, args.resident)
+    log(f"{len(batches)} resident batches in HBM; set-up + warm-up")
     nb = len(batches)
     n_total = 10 ** 9
 
@@ -473,6 +514,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.3f} ms/step")
     loss_vals = torch.stack([l.float() for l in losses]).cpu()
     finite = bool(torch.isfinite(loss_vals).all())
     chunk_ms = [marks[c].elapsed_time(marks[c + 1]) / max(bounds[c + 1] - bounds[c], 1) for c in range(chunks)]
@@ -486,9 +528,11 @@ def main():
     if args.cavg_steps > 0:
         cavg = cavg_phase(args, module, trainer, batches, step_fn, it)
     if args.fit_epochs > 0:
+        log("Trainer.fit measurement")
         fit = fit_throughput(args, cfg, module, sets, trainer.dataloader_params, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_model, usable = host_info()
+        log(f"cpu baseline on {usable} cores ({cpu_model})")
         cpu = cpu_baseline(module, ds, args.cpu_steps, 2, args.cpu_batch, usable, cpu_model)
     if rank == 0:
         audio_s = world * args.batch * SECONDS * args.steps

@@ -113,6 +113,19 @@ typedef struct lidk_gemm_args {
 } lidk_gemm_args;
 int lidk_gemm_nt(const lidk_gemm_args* args, int dtype, void* stream);
 
+/* LayerNorm fused into the GEMM that consumes it (PreNorm -> Linear / 1x1 Conv1d: lid/conformer.py:81-89 with :163 ff
+ * up-projection, :98-100 q/kv projections, :190-192 conv module) for K == 256 (the model width) and N % 256 == 0, bf16:
+ *   out = epilogue( LN(x)[M][256] . B[N][256]^T ),  LN(x) = (x - mean) * rstd * gamma + beta per row, eps as nn.LayerNorm.
+ * x [M][ldx] f32 is the residual stream; a workgroup normalises its 64-row panel once, keeps it in LDS and walks 4 column
+ * chunks of B.  h [M][256] (T, optional), mean/rstd [M] (optional) receive what lidk_layernorm_fwd would have written (the
+ * backward pass reads them).  args->A is ignored when x != NULL; with x == NULL the same row-panel kernel runs on the bf16
+ * operand args->A (no LayerNorm).  Epilogues: none / bias / bias+Swish with out2 = pre-activation / SWISH_GRAD with aux;
+ * alpha must be 1, res NULL, out of type T.  Returns LIDK_ERR_UNSUPPORTED for other shapes (lidk_ln_gemm_supported == 0):
+ * callers then issue lidk_layernorm_fwd + lidk_gemm_nt. */
+int lidk_ln_gemm_supported(int M, int N, int K, int dtype);
+int lidk_ln_gemm_nt(const lidk_gemm_args* args, const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                    void* h, float* mean, float* rstd, int dtype, void* stream);
+
 /* Weight-gradient GEMM ("TN"): C[N1][N2] (f32) += alpha * sum_{m<M} X[m][n1] * Y[m][n2]; colsum[n1] (f32, optional) += alpha *
  * sum_m X[m][n1] (the bias gradient).  X [M][ldx], Y [M][ldy] are the activations as stored (T, row-major); rows are readable
  * (zero padded) up to the next multiple of 8 columns; ldx, ldy % 8 == 0.  The contraction over M is split `splitk` ways with

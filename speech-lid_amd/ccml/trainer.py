@@ -202,7 +202,7 @@ class Trainer:
                         num_workers: int = 0, prefetch_factor: int = 2, train_sampler: Sampler = None,
                         val_sampler: Sampler = None, test_sampler: Sampler = None, train_batch_sampler: Sampler = None,
                         val_batch_sampler: Sampler = None, test_batch_sampler: Sampler = None, test_batch_size: int = None,
-                        **_unused):
+                        persistent_workers: bool = False, **_unused):
         self.train_sampler, self.val_sampler, self.test_sampler = train_sampler, val_sampler, test_sampler
         self.train_batch_sampler, self.val_batch_sampler = train_batch_sampler, val_batch_sampler
         self.test_batch_sampler = test_batch_sampler
@@ -210,6 +210,7 @@ class Trainer:
         extra = dict(num_workers=num_workers, pin_memory=pin)
         if num_workers > 0:
             extra["prefetch_factor"] = prefetch_factor
+            extra["persistent_workers"] = bool(persistent_workers)     # keep the worker processes across epochs
 
         def build(ds, batch_sampler, sampler, bs, shuffle, drop_last):
             cf = getattr(ds, "collate_fn", None)

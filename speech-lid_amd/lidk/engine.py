@@ -227,6 +227,7 @@ class Engine:
         self.seed = 0
         self.step_count = 0
         self._split_ok: Dict[tuple, bool] = {}
+        self._ln_gemm_ok: Dict[tuple, bool] = {}
         # Second HIP stream for the weight-gradient GEMMs (LIDK_SIDE_STREAM=0 turns it off): a block's wgrads are deferred and
         # run beside the next block's dgrad chain, one fork/join per captured block graph: 9.75 vs 10.01 ms/step.  (Forking
         # at every wgrad site cost more in graph edges than the overlap won: 13.0 vs 11.85 ms/step at the time.)
@@ -398,9 +399,24 @@ class Engine:
             return w.x0d
         return w.x0
 
+    def _ln_gemm(self, x, P, W, out, h, mean, rstd, **epi):
+        """PreNorm + the projection that consumes it.  For the model width the row-panel kernel does both in one launch
+        (LayerNorm in the operand load; h / mean / rstd still written for backward); otherwise two launches."""
+        M, N = x.shape[0], W.shape[0]
+        key = (M, N)
+        ok = self._ln_gemm_ok.get(key)
+        if ok is None:
+            ok = self._ln_gemm_ok[key] = bool(
+                self._hip and _os_env("LIDK_LN_GEMM", "1") != "0" and hasattr(self.k, "ln_gemm_supported")
+                and self.k.ln_gemm_supported(M, N, x.shape[1], self.act_dtype))
+        if ok:
+            self.k.ln_gemm_nt(x, P["ln_w"], P["ln_b"], W, out, h=h, mean=mean, rstd=rstd, **epi)
+        else:
+            self.k.layernorm_fwd(x, P["ln_w"], P["ln_b"], yT=h, mean=mean, rstd=rstd)
+            self.k.gemm_nt(h, W, out, **epi)
+
     def _ff_fwd(self, x, P, h, a, u, xo, mean, rstd):
-        self.k.layernorm_fwd(x, P["ln_w"], P["ln_b"], yT=h, mean=mean, rstd=rstd)
-        self.k.gemm_nt(h, P["w1"][0], u, bias=P["b1"], act=L.ACT_SWISH, out2=a)
+        self._ln_gemm(x, P, P["w1"][0], u, h, mean, rstd, bias=P["b1"], act=L.ACT_SWISH, out2=a)
         self.k.gemm_nt(u, P["w2"][0], xo, bias=P["b2"], alpha=0.5, res=x)
 
     def _block_fwd(self, x, bp: _BlockParams, bb: _BlockBuf, w: _Work, training: bool, part: str = "all"):
@@ -412,12 +428,10 @@ class Engine:
         if part in ("all", "a"):
             self._ff_fwd(x, bp.ff1, bb.h1, bb.a1, bb.u1, bb.x1, bb.mean[0], bb.rstd[0])
             A = bp.attn
-            self.k.layernorm_fwd(bb.x1, A["ln_w"], A["ln_b"], yT=bb.h2, mean=bb.mean[1], rstd=bb.rstd[1])
-            self.k.gemm_nt(bb.h2, A["wqkv"][0], bb.qkv)
+            self._ln_gemm(bb.x1, A, A["wqkv"][0], bb.qkv, bb.h2, bb.mean[1], bb.rstd[1])
             self.k.attn_fwd(bb.qkv, A["emb"], bb.o, bb.probs, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
             self.k.gemm_nt(bb.o, A["wo"][0], bb.x2, bias=A["bo"], res=bb.x1)
-            self.k.layernorm_fwd(bb.x2, C["ln_w"], C["ln_b"], yT=bb.h3, mean=bb.mean[2], rstd=bb.rstd[2])
-            self.k.gemm_nt(bb.h3, C["w1"][0], bb.y, bias=C["b1"])
+            self._ln_gemm(bb.x2, C, C["w1"][0], bb.y, bb.h3, bb.mean[2], bb.rstd[2], bias=C["b1"])
             dw2d = C["dw"].view(ci, K)
             pad_left = K // 2
             if training:                   # GLU fused into the depthwise conv's tile load; g is kept for the weight gradient

@@ -192,6 +192,31 @@ def gemm_nt(A, B, out, bias=None, act=L.ACT_NONE, alpha=1.0, res=None, out2=None
     return out
 
 
+def ln_gemm_supported(M, N, K, dtype):
+    return bool(lib().lidk_ln_gemm_supported(M, N, K, dtype_code(dtype)))
+
+
+def ln_gemm_nt(x, gamma, beta, B, out, h=None, mean=None, rstd=None, bias=None, act=L.ACT_NONE, out2=None, aux=None, A=None,
+               eps=1e-5):
+    """out[M,N] = epilogue(LN(x)[M,256] @ B[N,256]^T) with the LayerNorm fused into the operand load (x f32 residual stream;
+    h / mean / rstd get what layernorm_fwd would have written).  x=None, A=bf16 operand: the same row-panel kernel without LN."""
+    src = x if x is not None else A
+    M, K = src.shape
+    N = B.shape[0]
+    g = L.GemmArgs()
+    g.A, g.B = (_pv(A) if A is not None else None), _pv(B)
+    g.M, g.N, g.K, g.lda, g.ldb = M, N, K, (A.stride(0) if A is not None else 0), B.stride(0)
+    g.bias, g.act, g.alpha = _p(bias), act, 1.0
+    g.res, g.ldres = None, 0
+    g.out, g.ldo, g.out_f32 = _pv(out), out.stride(0), 0
+    g.out2, g.ldo2 = _pv(out2), (out2.stride(0) if out2 is not None else 0)
+    g.aux, g.ldaux = _pv(aux), (aux.stride(0) if aux is not None else 0)
+    g.splitk = 1
+    check(lib().lidk_ln_gemm_nt(C.byref(g), _pv(x), (x.stride(0) if x is not None else 0), _p(gamma), _p(beta), eps, _p(h),
+                                _p(mean), _p(rstd), _code(B), _stream()), "ln_gemm_nt")
+    return out
+
+
 def gemm_tn(X, Y, C, colsum=None, alpha=1.0, splitk=1, M=None, N1=None, N2=None):
     """C[N1,N2] (f32) += alpha * X[:M,:N1]^T @ Y[:M,:N2]; colsum[N1] (f32, optional) += alpha * X.sum(0)."""
     M = X.shape[0] if M is None else M

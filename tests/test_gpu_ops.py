@@ -13,6 +13,7 @@ import torch.nn.functional as F
 import lidk
 from lidk import ops
 from lidk import _lib as L
+from lidk._lib import LidkError
 from oracle import conformer as oc
 from oracle import features as of
 from oracle import optim as oo
@@ -634,3 +635,63 @@ def test_novograd_clip_and_cast():
         W = pd[offs[0]:offs[0] + 64 * 48].reshape(64, 48).cpu()
         assert torch.equal(wT[:64 * 48].reshape(64, 48).cpu(), W.to(dt))
         assert torch.equal(wT[64 * 48 + 8:64 * 48 + 8 + 64 * 48].reshape(48, 64).cpu(), W.t().contiguous().to(dt))
+
+
+# ----------------------------------------------------------------------------------------------- LayerNorm fused into the consuming GEMM
+@pytest.mark.parametrize("mode", ["plain", "bias", "bias_swish_pre", "swish_grad"])
+@pytest.mark.parametrize("M,N", [(9664, 1024), (9664, 768), (200, 256), (77, 512)])
+def test_ln_gemm_matches_layernorm_then_gemm(mode, M, N):
+    """lidk_ln_gemm_nt (row-panel kernel, LN in the operand load) against lidk_layernorm_fwd + lidk_gemm_nt on the same
+    inputs: h / mean / rstd bit-identical (same arithmetic), outputs equal up to MFMA accumulation order; and against torch."""
+    torch.manual_seed(M + N)
+    K = 256
+    x = (3.0 * torch.randn(M, K, device=DEV) + 0.5)
+    gamma, beta = 1 + 0.1 * torch.randn(K, device=DEV), 0.1 * torch.randn(K, device=DEV)
+    W = (0.06 * torch.randn(N, K, device=DEV)).bfloat16()
+    bias = 0.1 * torch.randn(N, device=DEV) if mode in ("bias", "bias_swish_pre") else None
+    aux = torch.randn(M, N, device=DEV).bfloat16() if mode == "swish_grad" else None
+    act = {"plain": L.ACT_NONE, "bias": L.ACT_NONE, "bias_swish_pre": L.ACT_SWISH, "swish_grad": L.ACT_SWISH_GRAD}[mode]
+    assert ops.ln_gemm_supported(M, N, K, torch.bfloat16)
+    # reference path: the two existing launches
+    h0 = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
+    mean0, rstd0 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.layernorm_fwd(x, gamma, beta, yT=h0, mean=mean0, rstd=rstd0)
+    out0 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    pre0 = torch.empty_like(out0) if mode == "bias_swish_pre" else None
+    ops.gemm_nt(h0, W, out0, bias=bias, act=act, out2=pre0, aux=aux)
+    # fused
+    h1 = torch.zeros_like(h0)
+    mean1, rstd1 = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+    out1 = torch.zeros_like(out0)
+    pre1 = torch.zeros_like(out0) if mode == "bias_swish_pre" else None
+    ops.ln_gemm_nt(x, gamma, beta, W, out1, h=h1, mean=mean1, rstd=rstd1, bias=bias, act=act, out2=pre1, aux=aux)
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h1) and torch.equal(mean0, mean1) and torch.equal(rstd0, rstd1)
+    scale = float(out0.float().abs().max())
+    err = float((out0.float() - out1.float()).abs().max())
+    print(f"[ln_gemm {mode} M={M} N={N}] max |fused - unfused| = {err:.3e} (max |out| {scale:.2f})")
+    assert err <= 2e-2 * scale                       # bf16 outputs: one ulp at the top of the range is 2^-8 relative
+    if pre0 is not None:
+        assert float((pre0.float() - pre1.float()).abs().max()) <= 2e-2 * float(pre0.float().abs().max())
+    ref = F.layer_norm(x, (K,), gamma, beta, 1e-5).bfloat16().float() @ W.float().t()
+    if bias is not None:
+        ref = ref + bias
+    if mode == "bias_swish_pre":
+        ref = ref * torch.sigmoid(ref)
+    if mode == "swish_grad":
+        s = torch.sigmoid(aux.float())
+        ref = ref * (s * (1 + aux.float() * (1 - s)))
+    assert float((out1.float() - ref).abs().max()) <= 3e-2 * max(1.0, float(ref.abs().max()))
+    # the same kernel without LayerNorm, on the bf16 operand
+    out2 = torch.zeros_like(out0)
+    ops.ln_gemm_nt(None, None, None, W, out2, A=h0, bias=bias, act=act, out2=pre1, aux=aux)
+    assert torch.equal(out1, out2)
+
+
+def test_ln_gemm_refuses_unsupported_shapes():
+    x = torch.randn(64, 128, device=DEV)
+    W = torch.randn(256, 128, device=DEV).bfloat16()
+    assert not ops.ln_gemm_supported(64, 256, 128, torch.bfloat16) and not ops.ln_gemm_supported(64, 320, 256, torch.bfloat16)
+    assert not ops.ln_gemm_supported(64, 256, 256, torch.float32)
+    with pytest.raises(LidkError):
+        ops.ln_gemm_nt(x, torch.ones(128, device=DEV), torch.zeros(128, device=DEV), W, torch.empty(64, 256, device=DEV, dtype=torch.bfloat16))

@@ -52,6 +52,33 @@ run("dgrad dh (N=256,K=1024)", M, 256, 1024)
 run("dgrad dh (N=256,K=768)", M, 256, 768)
 run("dgrad dh (N=256,K=512)", M, 256, 512)
 run("dgrad (N=256,K=256)", M, 256, 256)
+def run_panel(name, m, n, ln, **kw):
+    """row-panel kernel (K = 256): LN fused (reads the f32 residual stream) or bf16 operand"""
+    k = 256
+    x = torch.randn(m, k, device=dev); A = x.bfloat16(); B = torch.randn(n, k, device=dev).bfloat16()
+    gamma, beta = torch.ones(k, device=dev), torch.zeros(k, device=dev)
+    h = torch.empty(m, k, device=dev, dtype=torch.bfloat16); mean = torch.empty(m, device=dev); rstd = torch.empty(m, device=dev)
+    bias = torch.randn(n, device=dev) if kw.pop("bias", True) else None
+    out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+    extra = {}
+    if kw.get("act") == L.ACT_SWISH: extra["out2"] = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+    if kw.get("act") == L.ACT_SWISH_GRAD: extra["aux"] = torch.randn(m, n, device=dev).bfloat16(); bias = None
+    if ln:
+        us = t(lambda: ops.ln_gemm_nt(x, gamma, beta, B, out, h=h, mean=mean, rstd=rstd, bias=bias, **kw, **extra))
+        us0 = t(lambda: (ops.layernorm_fwd(x, gamma, beta, yT=h, mean=mean, rstd=rstd), ops.gemm_nt(h, B, out, bias=bias, **kw, **extra)))
+    else:
+        us = t(lambda: ops.ln_gemm_nt(None, None, None, B, out, A=A, bias=bias, **kw, **extra))
+        us0 = t(lambda: ops.gemm_nt(A, B, out, bias=bias, **kw, **extra))
+    print(f"{name:34s} M={m:5d} N={n:5d} K={k:5d}  panel {us:8.1f} us   current path {us0:8.1f} us")
+
+if os.environ.get("PANEL"):
+    run_panel("LN + ff up (bias+swish+pre)", M, 1024, True, act=L.ACT_SWISH)
+    run_panel("LN + qkv (plain)", M, 768, True, bias=False)
+    run_panel("LN + pw1 (bias)", M, 1024, True)
+    run_panel("ff up, bf16 A", M, 1024, False, act=L.ACT_SWISH)
+    run_panel("dgrad da (swish_grad), bf16 A", M, 1024, False, act=L.ACT_SWISH_GRAD)
+    run_panel("dgrad N=256 K=256 plain", M, 256, False, bias=False)
+    sys.exit(0)
 if os.environ.get("BLAS_REF"):      # what the vendor library (hipBLASLt via torch) reaches on the same shapes, plain bf16 output
     for (m, n, k) in ((M, 1024, 256), (M, 768, 256), (M, 512, 256), (M, 256, 256), (M, 256, 1024), (1024, 256, M), (256, 1024, M), (256, 256, M)):
         A = torch.randn(m, k, device=dev).bfloat16(); B = torch.randn(n, k, device=dev).bfloat16(); out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
