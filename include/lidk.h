@@ -43,6 +43,15 @@ int lidk_normalize_wav(const float* wav, float* out, int B, int L, const int32_t
  * noise: optional [B][L] U[0,1) draws (parity tests); NULL -> counter-based generator keyed by (seed, index). */
 int lidk_dither_preemph(const float* wav, float* out, const float* noise, int B, int L, float coef, float dither,
                         uint64_t seed, void* stream);
+
+/* Speed perturbation (lid/audio_processor.py:136-156: sox "speed" v then "rate" sr, v drawn from {0.9, 1.0, 1.1}) as polyphase
+ * resampling on the device: y[b][n] = sum_j taps[(n*p) % q][j] * x[b][(n*p) / q - left + j] for n < n_out[b], 0 behind.
+ * tables: device array of n_tables records {const float* taps [q][ntaps]; int p, q, ntaps, left;} (v = p/q; host-built
+ * windowed-sinc rows); table_of [B] selects the record of each utterance.  x [B][Lin] (n_in [B] true lengths or NULL),
+ * y [B][Lout], n_out [B] = round(n_in / v).  The sox resampler's own filter is not part of the reference tree: parity unpinned,
+ * checked against scipy.signal.resample_poly and a float64 restatement. */
+int lidk_speed_perturb(const float* x, int B, int Lin, const int32_t* n_in, float* y, int Lout, const int32_t* n_out,
+                       const void* tables, int n_tables, const int32_t* table_of, void* stream);
 /* lid/audio_processor.py:72-105 _internal_wav2mel (torchaudio MelSpectrogram + AmplitudeToDB(top_db=80)) fused with
  * lid/audio_processor.py:225-227 spectrogram_augment masks and lid/raw_datasets.py:345-365 collate layout.
  * wav [B][L] -> out [B][F][n_mels] f32 dB, F = 1 + (L + 2*pad)/hop.  window [512] (hann(win) centred), twiddle [256][2]
@@ -219,6 +228,11 @@ int lidk_ctc_loss(const float* logits, const int64_t* targets, const int64_t* in
 /* LangDiscriminator.forward ASR half (lid/ConformerLangModel.py:386-393) for ONE language head:
  * scores[b*score_stride] = sum_t [argmax!=blank] max_c log_softmax / (count*ln(blank) + 1e-5). */
 int lidk_lid_score(const float* logits, float* scores, int score_stride, int B, int T, int V1, int blank, void* stream);
+/* Greedy CTC decode on the device (CTCTokenizer.ctc_decode, lid/tokenizer.py:55-70): per frame argmax (ties -> lowest index), a
+ * frame's symbol is kept iff it is not `blank` and differs from the previous frame's.  logits [B][T][V1] f32; in_len [B]
+ * (int64, may be NULL = T frames); ids [B][T] int32 receives the kept symbols of utterance b at ids[b][0..out_len[b]). */
+int lidk_ctc_greedy(const float* logits, const int64_t* in_len, int* ids, int* out_len, int B, int T, int V1, int blank,
+                    void* stream);
 /* LangDiscriminator.linear on the detached scores (lid/ConformerLangModel.py:374-378,394): out [B,C] =
  * W2 [C,H] relu(W0 [H,C] scores [B,C] + b0) + b2, H <= 64.  One wave per utterance: a row's result does not depend on the batch. */
 int lidk_lid_mlp(const float* scores, const float* w0, const float* b0, const float* w2, const float* b2, float* out,

@@ -151,3 +151,28 @@ def power_spectrogram_np(wav: np.ndarray, win: int = 400, hop: int = 160, pad: i
     for t in range(nfr):
         out[:, t] = np.abs(np.fft.rfft(x[t * hop:t * hop + N_FFT] * w)) ** 2
     return out
+
+
+def speed_perturb_np(x, p: int, q: int, zeros: int = 16, beta: float = 8.6):
+    """Speed perturbation y[n] = x(n*p/q), n < round(len/v) (lid/audio_processor.py:136-156: sox "speed" v + "rate" sr with
+    v = p/q in {9/10, 1, 11/10}), restated in float64 numpy as direct band-limited interpolation: Kaiser-windowed sinc,
+    cut-off min(1, q/p) of Nyquist, `zeros` zero crossings per side, unit DC gain per output sample.  sox's own resampling
+    filter is not part of the reference tree (parity unpinned); tests also compare with scipy.signal.resample_poly."""
+    import numpy as np
+    x = np.asarray(x, dtype=np.float64)
+    n_out = int(len(x) * q / p + 0.5)
+    if p == q:
+        return x[:n_out].copy()
+    fc = min(1.0, q / p)
+    half = zeros / fc
+    y = np.zeros(n_out)
+    for n in range(n_out):
+        c = n * p / q
+        k = np.arange(int(np.floor(c - half)), int(np.ceil(c + half)) + 1)
+        t = k - c
+        w = np.where(np.abs(t) <= half, np.i0(beta * np.sqrt(np.clip(1.0 - (t / half) ** 2, 0.0, 1.0))) / np.i0(beta), 0.0)
+        h = fc * np.sinc(fc * t) * w
+        h = h / h.sum()
+        ok = (k >= 0) & (k < len(x))
+        y[n] = float((h[ok] * x[k[ok]]).sum())
+    return y

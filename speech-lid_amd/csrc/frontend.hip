@@ -75,6 +75,47 @@ extern "C" int lidk_dither_preemph(const float* wav, float* out, const float* no
   return launch_status();
 }
 
+// ------------------------------------------------------------------------------------ speed perturbation (polyphase resampling)
+// lid/audio_processor.py:136-156: sox effects ["speed", v], ["rate", sr] with v in {0.9, 1.0, 1.1} = band-limited resampling
+// y[n] = x(n * v), output length round(L / v).  v = up/down... written as a rational p/q (11/10, 9/10): output sample n reads
+// the input around n*p/q, i.e. integer base (n*p) / q and fractional phase (n*p) % q - one of q fixed FIR rows of a
+// host-built windowed-sinc table (cut-off min(1, q/p) of Nyquist, Kaiser window).  A streaming kernel: every input sample is
+// read from HBM once (the taps overlap in L1/L2), every output written once.  Utterance b uses row table_of[b] of a small
+// set of tables (one per distinct factor in the batch); factor 1 is an exact copy (single unit tap).
+struct ResampleTable { const float* taps; int p, q, ntaps, left; };   // taps [q][ntaps]; tap j of phase r weighs x[base - left + j]
+
+__global__ void __launch_bounds__(256)
+speed_perturb_kernel(const float* __restrict__ x, int Lin, const int32_t* __restrict__ n_in, float* __restrict__ y, int Lout,
+                     const int32_t* __restrict__ n_out, const ResampleTable* __restrict__ tables,
+                     const int32_t* __restrict__ table_of) {
+  const int b = blockIdx.y;
+  const ResampleTable tb = tables[table_of[b]];
+  const int nin = n_in ? min(n_in[b], Lin) : Lin, nout = min(n_out[b], Lout);
+  const float* xr = x + (size_t)b * Lin;
+  float* yr = y + (size_t)b * Lout;
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < Lout; n += gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    if (n < nout) {
+      const long pos = (long)n * tb.p;
+      const int base = (int)(pos / tb.q) - tb.left, ph = (int)(pos % tb.q);
+      const float* h = tb.taps + (size_t)ph * tb.ntaps;
+      for (int j = 0; j < tb.ntaps; ++j) {
+        const int k = base + j;
+        if (k >= 0 && k < nin) acc = fmaf(h[j], xr[k], acc);
+      }
+    }
+    yr[n] = acc;                                       // zeros behind the utterance's own samples (ragged batch layout)
+  }
+}
+
+extern "C" int lidk_speed_perturb(const float* x, int B, int Lin, const int32_t* n_in, float* y, int Lout, const int32_t* n_out,
+                                  const void* tables, int n_tables, const int32_t* table_of, void* stream) {
+  if (!x || !y || x == y || !n_out || !tables || !table_of || B <= 0 || Lin <= 0 || Lout <= 0 || n_tables <= 0) return LIDK_ERR_ARG;
+  dim3 grid(cdiv(Lout, 256 * 4) > 0 ? cdiv(Lout, 256 * 4) : 1, B);
+  speed_perturb_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, Lin, n_in, y, Lout, n_out, (const ResampleTable*)tables, table_of);
+  return launch_status();
+}
+
 // ------------------------------------------------------------------------------------ log-mel
 __global__ void fill_kernel(float* p, int n, float v) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

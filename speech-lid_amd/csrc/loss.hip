@@ -383,3 +383,53 @@ extern "C" int lidk_lid_mlp(const float* scores, const float* w0, const float* b
   lid_mlp_kernel<<<B, 64, 0, as_stream(stream)>>>(scores, w0, b0, w2, b2, out, C, H);
   return launch_status();
 }
+
+// ------------------------------------------------------------------------------------ greedy CTC decode
+// CTCTokenizer.ctc_decode (lid/tokenizer.py:55-70) on the device: per frame argmax over the vocabulary (ties -> lowest index,
+// as torch.argmax), then keep a frame's symbol iff it is not blank and differs from the previous FRAME's symbol.  One
+// workgroup per utterance: waves take frames round-robin for the argmax, a wave-level prefix sum packs the kept symbols.
+__global__ void __launch_bounds__(256)
+ctc_greedy_kernel(const float* __restrict__ logits, const int64_t* __restrict__ in_len, int* __restrict__ ids,
+                  int* __restrict__ out_len, int T_, int V1, int blank) {
+  extern __shared__ int s_arg[];                     // [T_]
+  __shared__ int s_base;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = in_len ? (int)min((int64_t)T_, max((int64_t)0, in_len[b])) : T_;
+  const float* lg = logits + (size_t)b * T_ * V1;
+  for (int t = wave; t < n; t += 4) {
+    float mx = NEG_INF; int arg = 0x7fffffff;
+    for (int c = lane; c < V1; c += 64) {
+      float v = lg[(size_t)t * V1 + c];
+      if (v > mx) { mx = v; arg = c; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      float om = __shfl_xor(mx, o, 64); int oa = __shfl_xor(arg, o, 64);
+      if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
+    }
+    if (lane == 0) s_arg[t] = arg;
+  }
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  if (wave == 0) {                                    // one wave packs: 64 frames per round, ballot prefix
+    for (int t0 = 0; t0 < n; t0 += 64) {
+      const int t = t0 + lane;
+      int sym = blank, prev = blank;
+      if (t < n) { sym = s_arg[t]; prev = t > 0 ? s_arg[t - 1] : blank; }
+      const bool keep = t < n && sym != blank && sym != prev;
+      const unsigned long long m = __ballot(keep);
+      const int pos = s_base + __popcll(m & ((1ull << lane) - 1ull));
+      if (keep) ids[(size_t)b * T_ + pos] = sym;
+      if (lane == 0) s_base += __popcll(m);          // same wave: program order, no barrier needed
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) out_len[b] = s_base;
+  }
+}
+
+extern "C" int lidk_ctc_greedy(const float* logits, const int64_t* in_len, int* ids, int* out_len, int B, int T_, int V1,
+                               int blank, void* stream) {
+  if (!logits || !ids || !out_len || B <= 0 || T_ <= 0 || V1 <= 1 || blank < 0 || blank >= V1) return LIDK_ERR_ARG;
+  if ((size_t)T_ * 4 > 150 * 1024) return LIDK_ERR_UNSUPPORTED;      // frame symbols live in LDS
+  ctc_greedy_kernel<<<B, 256, (size_t)T_ * 4, as_stream(stream)>>>(logits, in_len, ids, out_len, T_, V1, blank);
+  return launch_status();
+}

@@ -88,7 +88,8 @@ class LidSuperviseModule(CCMLModule):
         res = {"loss": loss, "wer": self._last_wer, "lang": lang, "predict_texts": [], "label_texts": []}
         if with_text:
             tok = self.tokenizer_dict[lang]
-            pred = tok.ctc_decode(torch.argmax(out.detach(), dim=-1), predictions_len=in_len)
+            k = self.model.lidk_engine.k                     # greedy collapse on the device; the host only maps ids to symbols
+            pred = tok.ids_to_text(*k.ctc_greedy(out.detach().contiguous(), in_len.contiguous(), tok.blank_id))
             label = tok.decoder(texts, target_lengths=tg_len)
             self._last_wer = float(self.model.model.wer_fn(pred, label))
             res.update(wer=self._last_wer, predict_texts=pred, label_texts=label)
@@ -139,7 +140,9 @@ class LidSuperviseModule(CCMLModule):
         feats = wav2mel(x, win_length=0.025, hop_length=0.01, n_mels=80, n_fft=512, pad=0, sr=sr).transpose(1, 2).contiguous()
         with torch.no_grad():
             out, (lid_asr, _) = self.model(feats, sr, language)
-        texts = {l: self.tokenizer_dict[l].ctc_decode(torch.argmax(o, dim=-1)) for l, o in out.items()}
+        k = self.model.lidk_engine.k
+        texts = {l: self.tokenizer_dict[l].ids_to_text(*k.ctc_greedy(o.contiguous(), None, self.tokenizer_dict[l].blank_id))
+                 for l, o in out.items()}
         return texts, lid_asr, out
 
     def infer(self, x, language: str = None, device=None):

@@ -6,7 +6,9 @@ waveforms (``WaveBatch``) and one fused launch sequence produces the ``(B, F, n_
 reflect-padded STFT (LDS FFT-512) -> |X|^2 -> mel -> dB -> per-utterance top_db floor -> SpecAugment masks.  SpecAugment
 spans are drawn on the host with torch's generator in torchaudio's draw order, so runs are reproducible from the seed.
 
-Out of scope (CPU-only libsox effects): speed / pitch perturbation, reverb, awgn, the kaldi fbank variant.
+Speed perturbation (sox "speed" {0.9, 1.0, 1.1} + "rate", lid/audio_processor.py:136-156) is polyphase resampling on the GPU
+(``speed_perturb``); the draw happens in the collate like the reference's per-item draw.
+Out of scope (CPU-only libsox effects): pitch perturbation, reverb, awgn, the kaldi fbank variant.
 """
 from typing import List, Optional
 
@@ -14,6 +16,19 @@ import torch
 
 from lidk import ops as _ops
 from lidk._lib import LidkError
+
+
+SPEED_FACTORS = ((9, 10), (1, 1), (11, 10))       # speed v = p/q: the reference's random.choice([0.9, 1.0, 1.1])
+
+
+def speed_out_len(n_samples: int, p: int, q: int) -> int:
+    """Samples left after speeding an utterance up by v = p/q."""
+    return _ops.speed_out_len(n_samples, p, q)
+
+
+def speed_perturb(wav: torch.Tensor, factors, n_samples: Optional[torch.Tensor] = None):
+    """wav (B, L) on the GPU, factors [(p, q)] per utterance -> (wav' (B, L'), n_samples' int32 (B,), lengths list)."""
+    return _ops.speed_perturb(wav.contiguous(), list(factors), n_samples)
 
 
 def frame_geometry(sr: int = 16000, win_length: float = 0.025, hop_length: float = 0.01):
@@ -31,10 +46,16 @@ def normalize_wav(wav: torch.Tensor) -> torch.Tensor:
 
 def wav_augment(wav: torch.Tensor, sr: int, speed_shift: bool = False, pitch_shift: bool = False, reverb: bool = False,
                 seed: int = 0):
-    """Dither (1e-5 * U[0,1)) + pre-emphasis 0.97.  The sox effects of the reference are not available."""
-    if speed_shift or pitch_shift or reverb:
-        raise NotImplementedError("sox speed/pitch/reverb are CPU-only libsox effects outside the lidk hot path")
-    return _ops.dither_preemph(wav.contiguous(), coef=0.97, dither=1e-5, seed=seed), sr
+    """Dither (1e-5 * U[0,1)) + pre-emphasis 0.97, then (speed_shift) one speed factor drawn from {0.9, 1.0, 1.1} for the
+    whole (1, L) or (B, L) input, as the reference's per-utterance call does.  Pitch shift and reverb (libsox) are not built."""
+    import random as _random
+    if pitch_shift or reverb:
+        raise NotImplementedError("sox pitch/reverb are CPU-only libsox effects outside the lidk hot path")
+    out = _ops.dither_preemph(wav.contiguous(), coef=0.97, dither=1e-5, seed=seed)
+    if speed_shift:
+        f = _random.choice(SPEED_FACTORS)
+        out, _, _ = _ops.speed_perturb(out, [f] * out.shape[0])
+    return out, sr
 
 
 def wav2mel(x: torch.Tensor, use_kaildi: bool = False, win_length: float = 0.025, hop_length: float = 0.01,
@@ -90,15 +111,20 @@ class WaveBatch:
     (lid/raw_datasets.py:345-365)."""
 
     def __init__(self, wav: torch.Tensor, spans: Optional[torch.Tensor] = None, pad: int = 0, n_mels: int = 80, sr: int = 16000,
-                 normalize: bool = True, preemph: bool = False, dither_seed: int = 0, n_samples: Optional[torch.Tensor] = None):
+                 normalize: bool = True, preemph: bool = False, dither_seed: int = 0, n_samples: Optional[torch.Tensor] = None,
+                 speed=None):
         self.wav, self.spans = wav, spans
         self.n_samples = n_samples          # int32 (B,) true lengths of a ragged batch, or None when all rows are full
+        self.speed = speed                  # per-utterance (p, q) speed factors (training augmentation) or None
         self.pad, self.n_mels, self.sr = pad, n_mels, sr
         self.normalize, self.preemph, self.dither_seed = normalize, preemph, dither_seed
 
     @property
     def shape(self):
         B, L = self.wav.shape
+        if self.speed is not None:          # frames after the speed perturbation
+            lens = self.n_samples.tolist() if self.n_samples is not None else [L] * B
+            L = max(speed_out_len(n, p, q) for n, (p, q) in zip(lens, self.speed))
         return (B, num_frames(L, self.pad), self.n_mels)
 
     @property
@@ -155,5 +181,7 @@ class WaveBatch:
             x = _ops.normalize_wav(x, n_samples=ns)
         if self.preemph:
             x = _ops.dither_preemph(x, coef=0.97, dither=1e-5, seed=self.dither_seed)
+        if self.speed is not None:          # reference order: dither, pre-emphasis, then the sox speed effect
+            x, ns, _ = _ops.speed_perturb(x, self.speed, ns)
         spans = self.spans.contiguous() if self.spans is not None else None
         return _ops.logmel(x, pad=self.pad, n_mels=self.n_mels, spans=spans, n_samples=ns)

@@ -19,7 +19,7 @@ import torch
 from torch.nn.utils.rnn import pad_sequence
 from torch.utils.data import Dataset, Sampler
 
-from lid.audio_processor import WaveBatch, draw_specaug_spans, num_frames
+from lid.audio_processor import SPEED_FACTORS, WaveBatch, draw_specaug_spans, num_frames, speed_out_len
 
 
 # ------------------------------------------------------------------------------------------------ audio I/O (host side)
@@ -169,8 +169,9 @@ class _FeatureCfg:
                  **_ignored):
         self.type, self.pad, self.sr, self.n_mels = type, pad, sr, n_mels
         self.t_mask, self.f_mask, self.mask_times = t_mask, f_mask, mask_times
-        if speed_shift or pitch_shift or reverb:
-            logging.warning("speed/pitch/reverb perturbation are libsox CPU effects outside the lidk path: disabled")
+        self.speed_shift = bool(speed_shift)          # speed perturbation {0.9, 1.0, 1.1}: polyphase resampling on the GPU
+        if pitch_shift or reverb:
+            logging.warning("pitch shift and reverb are libsox CPU effects outside the lidk path: disabled")
 
 
 class _CollateMixin:
@@ -186,15 +187,24 @@ class _CollateMixin:
             wav_pct = torch.FloatTensor([n / max(lens) for n in lens])
             return wavs, texts, wav_pct, text_pct, [b[2] for b in batch], langs
         wav = pad_sequence(wavs, batch_first=True)
+        speed = None
+        if self.train and fc.speed_shift:
+            # one draw per utterance, as the reference's wav_augment (lid/audio_processor.py:136-139); the resampling itself
+            # runs on the GPU behind normalisation and pre-emphasis, and the lengths below are the perturbed ones
+            speed = [random.choice(SPEED_FACTORS) for _ in lens]
+            in_lens, lens = lens, [speed_out_len(n, p, q) for n, (p, q) in zip(lens, speed)]
         frames = [num_frames(n, fc.pad) for n in lens]
         wav_pct = torch.FloatTensor([f / max(frames) for f in frames])
         spans = None
         if self.train and fc.mask_times > 0:
             spans = torch.tensor([draw_specaug_spans(f, fc.n_mels, fc.t_mask, fc.f_mask, fc.mask_times) for f in frames],
                                  dtype=torch.int32)
-        ragged = torch.tensor(lens, dtype=torch.int32) if min(lens) != max(lens) else None
+        if speed is not None:
+            ragged = torch.tensor(in_lens, dtype=torch.int32)
+        else:
+            ragged = torch.tensor(lens, dtype=torch.int32) if min(lens) != max(lens) else None
         wb = WaveBatch(wav, spans, pad=fc.pad, n_mels=fc.n_mels, sr=fc.sr, normalize=True, preemph=self.train,
-                       dither_seed=random.getrandbits(31) if self.train else 0, n_samples=ragged)
+                       dither_seed=random.getrandbits(31) if self.train else 0, n_samples=ragged, speed=speed)
         wb.lang_id = int(langs[0])
         return wb, texts, wav_pct, text_pct, [b[2] for b in batch], langs
 

@@ -38,6 +38,12 @@ class CTCTokenizer:
             out.append("".join(chars))
         return out
 
+    def ids_to_text(self, ids: torch.Tensor, lengths: torch.Tensor) -> List[str]:
+        """Collapsed symbol ids (B, T) + counts (B,) from the device-side greedy decode (lidk.ops.ctc_greedy) -> text.
+        One small device->host copy per batch; no per-frame work on the host."""
+        rows, lens = ids.cpu().tolist(), lengths.cpu().tolist()
+        return ["".join(self.labels_map[c] for c in row[:n]) for row, n in zip(rows, lens)]
+
     def decoder(self, targets: torch.Tensor, target_lengths: torch.Tensor) -> List[str]:
         ids = targets.long().cpu().tolist()
         lens = target_lengths.long().cpu().tolist()

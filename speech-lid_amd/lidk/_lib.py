@@ -38,6 +38,7 @@ SIGNATURES = {
     "lidk_version": (_I, []),
     "lidk_normalize_wav": (_I, [_P, _P, _I, _I, _P, _P]),
     "lidk_dither_preemph": (_I, [_P, _P, _P, _I, _I, _F, _F, _U64, _P]),
+    "lidk_speed_perturb": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
     "lidk_logmel": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P, _P]),
     "lidk_scale_cast": (_I, [_P, _I, _P, _I, _L, _F, _P]),
     "lidk_scale_cast_2d": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _F, _P]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "lidk_ctc_workspace_bytes": (_L, [_I, _I, _I, _I]),
     "lidk_ctc_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "lidk_lid_score": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "lidk_ctc_greedy": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "lidk_lid_mlp": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_novograd_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P]),
     "lidk_cast_weights": (_I, [_P, _P, _P, _I, _L, _I, _P]),

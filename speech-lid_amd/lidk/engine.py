@@ -37,20 +37,24 @@ class _GraphCache:
     A block's kernels always touch the same preallocated buffers and carry no per-step scalars, so the ~18 (forward) /
     ~35 (backward, including the previous block's weight gradients on the second stream) launches can be recorded once and
     replayed with a single host call: the Python/ctypes launch path costs ~13 us per kernel, a graph replay ~15 us per
-    block.  First use of a key runs eagerly (allocations, lazy views), second use captures, later uses replay.  Disabled
+    block.  First use of a key runs eagerly (allocations, lazy views), second use captures, later uses replay (with many
+    distinct workspace shapes alive - a ragged corpus - a key must be seen three times before its capture is paid).  Disabled
     with LIDK_GRAPHS=0 and on the CPU test backend; under data parallelism a block's sequence is cut at the SyncBatchNorm
     all-reduce into two graphs (Engine._run_split).  A capture that fails switches the engine to eager launches."""
 
     def __init__(self, enabled: bool):
         self.enabled = enabled
         self.state = {}
+        self.eager_uses = 1        # eager runs of a key before it is captured (the engine raises it for ragged corpora)
 
     def run(self, key, fn):
         if not self.enabled:
             return fn()
         st = self.state.get(key)
         if st is None:
-            self.state[key] = [None]
+            self.state[key] = st = [None, 0]
+        if st[0] is None and st[1] < self.eager_uses:
+            st[1] += 1
             return fn()
         if st[0] is None:
             g = torch.cuda.CUDAGraph()
@@ -114,13 +118,43 @@ class _BlockParams:
                          dw=g(p + ".post_norm.weight"), db=g(p + ".post_norm.bias"))
 
 
+class _Pool:
+    """HBM behind the workspaces of one capacity class (batch, frames rounded up to a bucket).  Ragged corpora produce
+    hundreds of distinct (B, F) shapes; each gets its own ``_Work`` (a set of VIEWS with the exact M and T the kernels need)
+    carved out of the class's pool, so a new shape costs a few hundred view objects instead of ~3 GB of fresh allocations.
+    ``measure`` mode hands out meta tensors and records the bytes a workspace of the capacity shape needs."""
+
+    def __init__(self, device):
+        self.device, self.store, self.cursor, self.need, self.measure = device, {}, {}, {}, True
+
+    def take(self, shape, dtype, zero=False):
+        n = int(math.prod(shape)) if shape else 1
+        n_al = _ceil(max(n, 1), 64)
+        cur = self.cursor.get(dtype, 0)
+        self.cursor[dtype] = cur + n_al
+        if self.measure:
+            self.need[dtype] = self.cursor[dtype]
+            return torch.empty(*shape, device="meta", dtype=dtype)
+        t = self.store[dtype][cur:cur + n].view(*shape)
+        if zero:
+            t.zero_()
+        return t
+
+    def commit(self):
+        self.store = {dt: torch.empty(n, device=self.device, dtype=dt) for dt, n in self.need.items()}
+        self.measure = False
+
+    def rewind(self):
+        self.cursor = {}
+
+
 class _BlockBuf:
     """Saved activations of one block for one (B, T)."""
 
-    def __init__(self, eng: "Engine", B: int, T: int, heads: int, dh: int, ff: int, ci: int):
-        M, d, dev, dt = B * T, eng.cfg.d, eng.device, eng.act_dtype
-        e = lambda *s: torch.empty(*s, device=dev, dtype=dt)
-        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+    def __init__(self, eng: "Engine", B: int, T: int, heads: int, dh: int, ff: int, ci: int, pool: _Pool):
+        M, d, dt = B * T, eng.cfg.d, eng.act_dtype
+        e = lambda *s: pool.take(s, dt)
+        f = lambda *s: pool.take(s, torch.float32)
         inner = heads * dh
         self.mean = [f(M) for _ in range(5)]
         self.rstd = [f(M) for _ in range(5)]
@@ -136,28 +170,31 @@ class _BlockBuf:
 class _Work:
     """Everything sized by (B, F): front-end buffers, per-block buffers, backward scratch."""
 
-    def __init__(self, eng: "Engine", B: int, F_: int):
+    def __init__(self, eng: "Engine", B: int, F_: int, pool: _Pool):
         cfg = eng.cfg
-        self.B, self.F = B, F_
+        self.B, self.F, self.pool = B, F_, pool
         self.T = T = (F_ + 2 - 3) // 2 + 1
         self.M = M = B * T
         self.Mp = Mp = _ceil(M, 8)
         d, dev, dt = cfg.d, eng.device, eng.act_dtype
-        e = lambda *s: torch.empty(*s, device=dev, dtype=dt)
-        z = lambda *s: torch.zeros(*s, device=dev, dtype=dt)
-        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        pool.rewind()
+        e = lambda *s: pool.take(s, dt)
+        z = lambda *s: pool.take(s, dt, zero=True)
+        f = lambda *s: pool.take(s, torch.float32)
+        f64 = lambda *s: pool.take(s, torch.float64)
+        u8 = lambda *s: pool.take(s, torch.uint8)
         ff, ci = d * cfg.ff_mult, d * cfg.conv_expansion_factor
         self.col = e(M, 3 * cfg.n_mels)
         ff_e, ci_e = ff, ci
         self.r = e(M, cfg.n_mels)
         self.x0 = f(M, d)
         self.x0d = f(M, d)
-        self.pos_keep = torch.empty(M * d, device=dev, dtype=torch.uint8)
-        self.enc = [_BlockBuf(eng, B, T, cfg.heads, cfg.dim_head, ff_e, ci_e) for _ in range(cfg.n_blocks)]
+        self.pos_keep = u8(M * d)
+        self.enc = [_BlockBuf(eng, B, T, cfg.heads, cfg.dim_head, ff_e, ci_e, pool) for _ in range(cfg.n_blocks)]
         ff, ci = max(ff_e, 4 * d), max(ci_e, 2 * d)          # scratch must also fit the head block (ff 4d, conv 2d, k 31)
-        self.head = _BlockBuf(eng, B, T, cfg.last_heads, cfg.last_dim_head, d * 4, d * 2)
+        self.head = _BlockBuf(eng, B, T, cfg.last_heads, cfg.last_dim_head, d * 4, d * 2, pool)
         self.head_h = e(M, d)
-        self.head_keep = torch.empty(M * d, device=dev, dtype=torch.uint8)
+        self.head_keep = u8(M * d)
         self.v1p = _ceil(max(cfg.lang2vocab.values()) + 1, 8)
         self.dlT = z(M, self.v1p)
         # backward scratch (shared by all blocks)
@@ -180,8 +217,8 @@ class _Work:
             S.ds = e(M, ci)                                   # gradient at the BatchNorm+Swish output
             # BN backward sums (all ranks / this rank); element [2*ci] carries the row count, which the same all-reduce
             # turns into the global count (ranks may hold different (B, T) shapes)
-            S.sums = torch.empty(2 * ci + 1, device=dev, dtype=torch.float64)
-            S.sums_local = torch.empty(2 * ci + 1, device=dev, dtype=torch.float64)
+            S.sums = f64(2 * ci + 1)
+            S.sums_local = f64(2 * ci + 1)
             S.dsc = f(B, max(cfg.heads, cfg.last_heads), T, (T + 31) // 32 * 32)     # attention dS rows (kept for the deferred dE)
             S.lnp = [f(L.LN_BWD_BLOCKS * 2 * d) for _ in range(5)]   # LayerNorm dgamma/dbeta partial rows: post, ff2, conv, attn, ff1
             self.sets.append(S)
@@ -194,8 +231,9 @@ class _Work:
         self.stat_parts = eng.k.dwconv_stat_parts(B, T)
         self.stat_partial = f(self.stat_parts * 2 * ci)
         self.dw_partial = f(B * ci * (max(cfg.conv_kernel_size, 31) + 1))
-        self.sums = torch.empty(2 * ci + 1, device=dev, dtype=torch.float64)        # (sum x, sum x^2) [2*ci] + row count
+        self.sums = f64(2 * ci + 1)                                                 # (sum x, sum x^2) [2*ci] + row count
         self.dconv3 = f(cfg.n_mels, 3 * cfg.n_mels)
+        self.dfeat = f(M, d)
         self.logits: Dict[str, torch.Tensor] = {}
 
 
@@ -218,6 +256,7 @@ class Engine:
         self._built = False
         self.reset_parameters()
         self._work: Dict[tuple, _Work] = {}
+        self._pools: Dict[tuple, _Pool] = {}
         import os as _os
         self.graphs = _GraphCache(self._hip and _os.environ.get("LIDK_GRAPHS", "1") != "0")
         # data-parallel hooks (set by the Trainer): all-reduce of f64 BatchNorm sums, and "gradients of stage ready"
@@ -351,6 +390,7 @@ class Engine:
                             for l in self.cfg.lang2vocab}
         self._built = True
         self._work.clear()
+        self._pools.clear()
         self.graphs.clear()
         self.refresh_weights()
 
@@ -371,19 +411,42 @@ class Engine:
         self.w_conv3.copy_(c3.permute(0, 2, 1).reshape(c3.shape[0], -1))             # 19 K elements: layout glue, not math
 
     def work(self, B, F_):
-        """Workspace for a (batch, frames) shape.  Ragged training data produces many shapes, so a budget of workspaces is
-        kept (least recently used goes first; HBM is 288 GB and a cfg2 workspace is ~3 GB) and evicting one drops only the
-        hipGraphs that point into it."""
+        """Workspace for a (batch, frames) shape.  Ragged training data produces hundreds of distinct shapes, so HBM is
+        budgeted per CAPACITY CLASS (batch, frames rounded up to LIDK_FRAME_BUCKET = 64): a class owns one pool sized for its
+        largest shape (HBM is 288 GB, a cfg2 pool is ~3 GB; LIDK_MAX_WORKSPACES = 12 classes stay resident, least recently
+        used goes first) and every exact (B, F) gets a cheap set of views into it with the M and T the kernels need.  Evicting
+        a class drops its view sets and only the hipGraphs recorded against them."""
         key = (B, F_)
         w = self._work.pop(key, None)
         if w is None:
-            limit = int(_os_env("LIDK_MAX_WORKSPACES", "12"))
-            while len(self._work) >= max(limit, 1):
+            bucket = max(int(_os_env("LIDK_FRAME_BUCKET", "64")), 1)
+            ckey = (B, _ceil(F_, bucket))
+            pool = self._pools.pop(ckey, None)
+            if pool is None:
+                limit = max(int(_os_env("LIDK_MAX_WORKSPACES", "12")), 1)
+                while len(self._pools) >= limit:
+                    old_key = next(iter(self._pools))
+                    self._drop_pool(self._pools.pop(old_key))
+                pool = _Pool(self.device)
+                _Work(self, ckey[0], ckey[1], pool)            # measure the capacity shape (meta tensors, no HBM touched)
+                pool.commit()
+            self._pools[ckey] = pool
+            while len(self._work) >= 256:                      # view sets are cheap, but not free
                 old = self._work.pop(next(iter(self._work)))
-                self.graphs.drop(id(old))              # captured graphs point into the evicted workspace
-            w = _Work(self, B, F_)
+                self.graphs.drop(id(old))
+            w = _Work(self, B, F_, pool)
+            self.graphs.eager_uses = 1 if len(self._work) < 8 else 3      # ragged corpus: most shapes never come back
+        else:
+            for ckey, pool in list(self._pools.items()):       # keep the class of a reused shape at the recent end
+                if pool is w.pool:
+                    self._pools[ckey] = self._pools.pop(ckey)
+                    break
         self._work[key] = w                            # (re)insert at the most-recently-used end
         return w
+
+    def _drop_pool(self, pool):
+        for k in [k for k, w in self._work.items() if w.pool is pool]:
+            self.graphs.drop(id(self._work.pop(k)))    # captured graphs point into the evicted pool
 
     # ------------------------------------------------------------------ forward pieces
     def _front_fwd(self, w: _Work, mel, training, seed):
@@ -400,14 +463,16 @@ class Engine:
         return w.x0
 
     def _ln_gemm(self, x, P, W, out, h, mean, rstd, **epi):
-        """PreNorm + the projection that consumes it.  For the model width the row-panel kernel does both in one launch
-        (LayerNorm in the operand load; h / mean / rstd still written for backward); otherwise two launches."""
+        """PreNorm + the projection that consumes it: two launches.  LIDK_LN_GEMM=1 opts into the row-panel kernel that does
+        both in one (LayerNorm in the operand load); measured SLOWER on MI355X (LN + ff-up 41.7 vs 23.7 us, LN + QKV 20.6 vs
+        17.3 us: two 64 KB workgroups per CU hide less latency than the per-tile kernels' 16+ waves), so it is off by default
+        and kept for the record (measured and rejected)."""
         M, N = x.shape[0], W.shape[0]
         key = (M, N)
         ok = self._ln_gemm_ok.get(key)
         if ok is None:
             ok = self._ln_gemm_ok[key] = bool(
-                self._hip and _os_env("LIDK_LN_GEMM", "1") != "0" and hasattr(self.k, "ln_gemm_supported")
+                self._hip and _os_env("LIDK_LN_GEMM", "0") == "1" and hasattr(self.k, "ln_gemm_supported")
                 and self.k.ln_gemm_supported(M, N, x.shape[1], self.act_dtype))
         if ok:
             self.k.ln_gemm_nt(x, P["ln_w"], P["ln_b"], W, out, h=h, mean=mean, rstd=rstd, **epi)
@@ -716,8 +781,7 @@ class Engine:
             dy_ln = w.dh
         self.k.layernorm_bwd(dy_ln, bb.x4, bb.mean[4], bb.rstd[4], bp.post["w"], w.partial, dx=w.dxa, dxT=w.dyT,
                           dxT_scale=0.5, dgamma=bp.post["dw"], dbeta=bp.post["db"], dtype=self.act_dtype)
-        dfeat = torch.empty_like(w.dxa) if not hasattr(w, "dfeat") else w.dfeat
-        w.dfeat = dfeat
+        dfeat = w.dfeat
         feat = ctx["feat"]
         # Blocks in backward order: the head block, then the kept encoder blocks in reverse.  In deferred mode (side stream)
         # a block's graph holds its dgrad chain on the main stream and, forked beside it, the weight gradients of the

@@ -91,6 +91,59 @@ def dither_preemph(wav, coef=0.97, dither=1e-5, seed=0, noise=None, out=None):
     return out
 
 
+_RESAMPLE = {}
+
+
+def resample_taps(p: int, q: int, zeros: int = 16, beta: float = 8.6):
+    """FIR rows of the polyphase resampler y[n] = x(n*p/q): (taps float64 [q][ntaps], left).  Row r holds the weights of
+    x[base - left + j], base = (n*p)//q, for the outputs whose phase (n*p) % q is r: a Kaiser-windowed sinc with cut-off
+    min(1, q/p) of the input Nyquist and `zeros` zero crossings on each side, each row normalised to unit DC gain."""
+    import numpy as np
+    if p == q:
+        return np.ones((1, 1)), 0
+    fc = min(1.0, q / p)
+    half = zeros / fc
+    left = int(math.ceil(half))
+    ntaps = 2 * left + 1
+    j = np.arange(ntaps, dtype=np.float64)[None, :]
+    r = np.arange(q, dtype=np.float64)[:, None]
+    t = (j - left) - r / q                                   # tap position minus the (fractional) output position
+    w = np.where(np.abs(t) <= half, np.i0(beta * np.sqrt(np.clip(1.0 - (t / half) ** 2, 0.0, 1.0))) / np.i0(beta), 0.0)
+    h = fc * np.sinc(fc * t) * w
+    return h / h.sum(1, keepdims=True), left
+
+
+def speed_out_len(n: int, p: int, q: int) -> int:
+    return int(n * q / p + 0.5)
+
+
+def speed_perturb(wav, factors, n_samples=None):
+    """wav (B, L) f32 on the GPU, factors: per-utterance (p, q) with speed v = p/q (e.g. (11, 10), (1, 1), (9, 10)) ->
+    (out (B, Lout) f32, n_out (B,) int32 on the GPU, list of output lengths).  n_samples: optional int32 (B,) true lengths."""
+    import numpy as np
+    B, Lin = wav.shape
+    dev = wav.device
+    host_n = n_samples.tolist() if n_samples is not None else [Lin] * B
+    out_lens = [speed_out_len(n, p, q) for n, (p, q) in zip(host_n, factors)]
+    Lout = max(out_lens)
+    uniq = sorted(set(factors))
+    recs = []
+    for (p, q) in uniq:
+        key = (str(dev), p, q)
+        if key not in _RESAMPLE:
+            taps, left = resample_taps(p, q)
+            _RESAMPLE[key] = (torch.from_numpy(taps.astype(np.float32)).contiguous().to(dev), left)
+        t, left = _RESAMPLE[key]
+        recs.append([t.data_ptr(), (p & 0xFFFFFFFF) | (q << 32), (t.shape[1] & 0xFFFFFFFF) | (left << 32)])
+    tables = torch.tensor(recs, dtype=torch.int64, device=dev)          # {ptr; int p, q; int ntaps, left} = 24 bytes per record
+    table_of = torch.tensor([uniq.index(f) for f in factors], dtype=torch.int32, device=dev)
+    n_out = torch.tensor(out_lens, dtype=torch.int32, device=dev)
+    out = torch.empty(B, Lout, device=dev, dtype=torch.float32)
+    check(lib().lidk_speed_perturb(_p(wav), B, Lin, _p(n_samples), _p(out), Lout, _p(n_out), _p(tables), len(uniq), _p(table_of),
+                                   _stream()), "speed_perturb")
+    return out, n_out, out_lens
+
+
 def logmel(wav, pad=0, hop=160, win_length=400, n_mels=80, spans=None, top_db=80.0, out=None, n_samples=None):
     """wav (B, L) f32 -> (B, F, n_mels) f32 dB with per-utterance top_db floor and optional SpecAugment spans
     (int32 (B, mask_times, 4)).  n_samples: optional int32 (B,) true lengths; rows behind an utterance's own frames are 0."""
@@ -369,6 +422,16 @@ def lid_score(logits, scores_col, stride, blank):
     if not scores_col.is_cuda:
         raise LidkError("lid_score: CPU tensor")
     check(lib().lidk_lid_score(_p(logits), scores_col.data_ptr(), stride, B, T, V1, blank, _stream()), "lid_score")
+
+
+def ctc_greedy(logits, in_len, blank):
+    """Greedy CTC collapse on the device: logits (B, T, V1) f32, in_len (B,) int64 or None ->
+    (ids (B, T) int32, lengths (B,) int32): the kept symbols of utterance b are ids[b, :lengths[b]]."""
+    B, T, V1 = logits.shape
+    ids = torch.empty(B, T, device=logits.device, dtype=torch.int32)
+    lens = torch.empty(B, device=logits.device, dtype=torch.int32)
+    check(lib().lidk_ctc_greedy(_p(logits), _p(in_len), _p(ids), _p(lens), B, T, V1, blank, _stream()), "ctc_greedy")
+    return ids, lens
 
 
 def lid_mlp(scores, w0, b0, w2, b2, out):

@@ -343,6 +343,40 @@ def lid_score(logits, scores_col, stride, blank):
     scores_col[:, 0] = (vmax * mask).sum(-1) / (mask.sum(-1) * math.log(blank) + 1e-5)
 
 
+def speed_out_len(n, p, q):
+    return int(n * q / p + 0.5)
+
+
+def speed_perturb(wav, factors, n_samples=None):
+    from oracle.features import speed_perturb_np
+    B, Lin = wav.shape
+    lens = n_samples.tolist() if n_samples is not None else [Lin] * B
+    outs = [torch.from_numpy(speed_perturb_np(wav[b, :lens[b]].numpy(), p, q)).float() for b, (p, q) in enumerate(factors)]
+    out_lens = [o.shape[0] for o in outs]
+    out = torch.zeros(B, max(out_lens))
+    for b, o in enumerate(outs):
+        out[b, :o.shape[0]] = o
+    return out, torch.tensor(out_lens, dtype=torch.int32), out_lens
+
+
+def ctc_greedy(logits, in_len, blank):
+    B, T, V1 = logits.shape
+    arg = logits.argmax(-1)
+    ids = torch.zeros(B, T, dtype=torch.int32)
+    lens = torch.zeros(B, dtype=torch.int32)
+    for b in range(B):
+        n = T if in_len is None else int(min(T, max(0, int(in_len[b]))))
+        prev, k = blank, 0
+        for t in range(n):
+            p = int(arg[b, t])
+            if p != blank and p != prev:
+                ids[b, k] = p
+                k += 1
+            prev = p
+        lens[b] = k
+    return ids, lens
+
+
 def lid_mlp(scores, w0, b0, w2, b2, out):
     out.copy_(F.linear(F.relu(F.linear(scores, w0, b0)), w2, b2))
     return out

@@ -112,3 +112,31 @@ def test_real_backend_refuses_cpu():
     eng = Engine(make_cfg())
     with pytest.raises(lidk.LidkError):
         eng.to("cpu") and eng.forward(torch.zeros(1, 101, 80), "a", training=False)
+
+
+def test_workspace_pools_serve_many_ragged_shapes(cfg1_weights, monkeypatch):
+    """Ragged corpora: shapes of one capacity class (frames rounded up to 64) share ONE pool of HBM and get exact-size views;
+    classes are evicted least-recently-used; results do not depend on which shapes ran before."""
+    monkeypatch.setenv("LIDK_MAX_WORKSPACES", "2")
+    eng = make_engine(make_cfg(dropout=0.0, pos_dropout=0.0), cfg1_weights)
+    g = torch.Generator().manual_seed(0)
+    mels = {F_: 20.0 * torch.randn(2, F_, 80, generator=g) - 30.0 for F_ in (61, 45, 64, 101, 150, 33)}
+    first = {}
+    for F_, mel in mels.items():
+        eng.zero_grad()
+        out = eng.forward(mel, "a", training=True, keep_layers=[True, True])["a"]
+        first[F_] = out.clone()
+        eng.backward(0.01 * torch.ones_like(out))
+        first[(F_, "g")] = eng.grad.clone()
+        assert len(eng._pools) <= 2
+    assert eng.work(2, 61).pool is eng.work(2, 45).pool is eng.work(2, 64).pool          # one class: frames <= 64
+    assert eng.work(2, 61).pool is not eng.work(2, 101).pool
+    w61, w45 = eng.work(2, 61), eng.work(2, 45)
+    assert w61.col.data_ptr() == w45.col.data_ptr() and w61.x0.shape[0] == 2 * 31 and w45.x0.shape[0] == 2 * 23   # same HBM, exact views
+    for F_ in (150, 61, 33, 101, 45):                       # again, in another order, across evictions
+        eng.zero_grad()
+        eng.load_state(cfg1_weights)                        # BatchNorm running statistics back to the start
+        out = eng.forward(mels[F_], "a", training=True, keep_layers=[True, True])["a"]
+        assert torch.equal(out, first[F_]), F_
+        eng.backward(0.01 * torch.ones_like(out))
+        assert torch.allclose(eng.grad, first[(F_, "g")], rtol=1e-5, atol=1e-7), F_

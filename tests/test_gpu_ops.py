@@ -695,3 +695,57 @@ def test_ln_gemm_refuses_unsupported_shapes():
     assert not ops.ln_gemm_supported(64, 256, 256, torch.float32)
     with pytest.raises(LidkError):
         ops.ln_gemm_nt(x, torch.ones(128, device=DEV), torch.zeros(128, device=DEV), W, torch.empty(64, 256, device=DEV, dtype=torch.bfloat16))
+
+
+# ----------------------------------------------------------------------------------------------- greedy CTC decode on the device
+def test_ctc_greedy_matches_the_reference_collapse():
+    """lidk_ctc_greedy against the reference's own collapse KAT (tests/golden/metrics_kat.npz, captured from lid/tokenizer.py)
+    and against the host implementation on random logits with ragged lengths (V+1 = 41 and 4442, T up to 835)."""
+    from conftest import load_npz
+    from lid.tokenizer import CTCTokenizer
+    g = load_npz("metrics_kat.npz")
+    seqs, lens = torch.from_numpy(g["ctc_seqs"]), torch.from_numpy(g["ctc_lens"])
+    logits = torch.full((seqs.shape[0], seqs.shape[1], 7), -5.0)
+    logits.scatter_(2, seqs.unsqueeze(-1), 3.0)                              # argmax path = the KAT's symbol sequence
+    tok = CTCTokenizer([chr(ord("a") + i) for i in range(6)])
+    ids, n = ops.ctc_greedy(logits.to(DEV), lens.to(DEV), 6)
+    assert tok.ids_to_text(ids, n) == [str(s) for s in g["ctc_decoded"]]
+    torch.manual_seed(0)
+    for B, T, V1 in ((64, 151, 41), (3, 835, 41), (2, 60, 4442), (1, 1, 5)):
+        lg = torch.randn(B, T, V1)
+        lg[..., V1 - 1] += 1.5                                                 # plenty of blanks
+        lg[:, 1::3] = lg[:, 0:-1:3][:, :lg[:, 1::3].shape[1]]                  # repeated frames -> merged symbols
+        in_len = torch.randint(1, T + 1, (B,))
+        tok = CTCTokenizer([chr(0x4E00 + i) for i in range(V1 - 1)])
+        want = tok.ctc_decode(lg.argmax(-1), in_len)
+        ids, n = ops.ctc_greedy(lg.to(DEV), in_len.to(DEV), V1 - 1)
+        assert tok.ids_to_text(ids, n) == want, (B, T, V1)
+        ids, n = ops.ctc_greedy(lg.to(DEV), None, V1 - 1)
+        assert tok.ids_to_text(ids, n) == tok.ctc_decode(lg.argmax(-1)), (B, T, V1)
+
+
+# ----------------------------------------------------------------------------------------------- speed perturbation on the device
+def test_speed_perturb_matches_the_float64_restatement():
+    """lidk_speed_perturb (polyphase FIR, one launch for a batch with mixed factors and ragged lengths) against
+    oracle.features.speed_perturb_np per utterance; factor 1 is an exact copy; rows are zero behind the perturbed length."""
+    torch.manual_seed(0)
+    B, L = 6, 9000
+    wav = torch.randn(B, L)
+    lens = [9000, 7000, 8123, 9000, 5000, 6001]
+    for b, n in enumerate(lens):
+        wav[b, n:] = 0
+    factors = [(11, 10), (1, 1), (9, 10), (9, 10), (11, 10), (1, 1)]
+    out, n_out, out_lens = ops.speed_perturb(wav.to(DEV), factors, torch.tensor(lens, dtype=torch.int32, device=DEV))
+    assert n_out.tolist() == out_lens == [ops.speed_out_len(n, p, q) for n, (p, q) in zip(lens, factors)]
+    assert out.shape == (B, max(out_lens))
+    out = out.cpu()
+    for b, (p, q) in enumerate(factors):
+        ref = of.speed_perturb_np(wav[b, :lens[b]].numpy(), p, q)
+        got = out[b, :out_lens[b]].numpy()
+        err = np.abs(got - ref).max()
+        assert err <= (0.0 if p == q else 2e-5), (b, err)
+        assert float(out[b, out_lens[b]:].abs().max() if out_lens[b] < out.shape[1] else 0.0) == 0.0
+    # full rows (no length vector), every utterance the same factor: the wav_augment() form
+    out2, _, lens2 = ops.speed_perturb(wav[:2].to(DEV), [(11, 10)] * 2)
+    assert lens2 == [ops.speed_out_len(L, 11, 10)] * 2
+    np.testing.assert_allclose(out2[0].cpu().numpy(), of.speed_perturb_np(wav[0].numpy(), 11, 10), atol=2e-5)

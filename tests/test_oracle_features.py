@@ -90,3 +90,35 @@ def test_collate_layout():
     x, pct = of.collate_mel([a, b])
     assert x.shape == (2, 30, 80) and torch.equal(x[1, 21:], torch.zeros(9, 80))
     np.testing.assert_allclose(pct.numpy(), [1.0, 21 / 30], rtol=1e-6)
+
+
+def test_speed_perturbation_restatement_against_scipy_and_the_polyphase_table():
+    """oracle.features.speed_perturb_np (direct band-limited interpolation) against scipy.signal.resample_poly (independent
+    polyphase implementation, different window) and against the product's host-built polyphase table (lidk.ops.resample_taps)."""
+    from scipy.signal import resample_poly
+    from lidk.ops import resample_taps, speed_out_len
+    rng = np.random.RandomState(0)
+    t = np.arange(4000) / 16000.0
+    x = np.sin(2 * math.pi * 440 * t) + 0.5 * np.sin(2 * math.pi * 3000 * t) + 0.05 * rng.randn(4000)
+    assert np.array_equal(of.speed_perturb_np(x, 1, 1), x)
+    for p, q in ((11, 10), (9, 10)):
+        y = of.speed_perturb_np(x, p, q)
+        assert len(y) == speed_out_len(len(x), p, q) == int(len(x) * q / p + 0.5)
+        r = resample_poly(x, q, p)
+        m = min(len(r), len(y))
+        assert np.abs(r[:m] - y[:m])[100:m - 100].max() < 1e-2 and np.corrcoef(r[100:m - 100], y[100:m - 100])[0, 1] > 0.99999
+        taps, left = resample_taps(p, q)
+        assert taps.shape[0] == q and np.allclose(taps.sum(1), 1.0)
+        n = np.arange(len(y))
+        base, ph = (n * p) // q - left, (n * p) % q
+        yp = np.zeros(len(y))
+        for i in range(len(y)):
+            k = base[i] + np.arange(taps.shape[1])
+            ok = (k >= 0) & (k < len(x))
+            yp[i] = (taps[ph[i]][ok] * x[k[ok]]).sum()
+        assert np.abs(yp - y).max() < 1e-10
+    # a pure tone comes out at v times its frequency
+    tone = np.sin(2 * math.pi * 1000 * np.arange(16000) / 16000.0)
+    y = of.speed_perturb_np(tone, 11, 10)
+    spec = np.abs(np.fft.rfft(y[:8192] * np.hanning(8192)))
+    assert abs(spec.argmax() * 16000 / 8192 - 1100.0) < 4.0

@@ -113,3 +113,18 @@ def test_mel_filterbank_cross_check_against_an_independent_implementation():
         print(f"[mel fb {name} vs transformers] max abs diff {err:.2e}")
         assert err <= 2e-5, name
     assert torch.equal(oracle_fb(), product_fb())
+
+
+def test_result_file_formats(tmp_path):
+    """lid/test_supervised.py writers: the reference's TSV layouts (lid/test_supervised.py:250-288)."""
+    import csv
+    from lid.test_supervised import write_to_csv, write_to_file
+    res = str(tmp_path / "out" / "result.txt")
+    write_to_file(res, [("a.wav", "hello"), ("b.wav", "")])
+    rows = list(csv.DictReader(open(res), delimiter="\t"))
+    assert rows == [{"wav_name": "a.wav", "text": "hello"}, {"wav_name": "b.wav", "text": ""}]
+    path = write_to_csv(res, ["xy", "z"], ["xv", "z"], [[0.7, 0.2, 0.1], [0.1, 0.1, 0.8]], lang="Swahili")
+    assert path.endswith("out/Swahili.csv")
+    rows = list(csv.DictReader(open(path), delimiter="\t"))
+    assert list(rows[0]) == ["true", "pred", "Persian", "Swahili", "Vietnamese"]
+    assert rows[1]["true"] == "z" and float(rows[1]["Vietnamese"]) == 0.8

@@ -153,3 +153,31 @@ def test_data_parallel_gloo_matches_single_process(tmp_path):
         # what is left (rounding noise, different in the two layouts) becomes a unit-norm update: not comparable
         if one[k].is_floating_point() and not k.endswith(("conv.net.4.conv.bias", "conv.net.5.running_mean")):   # (the running mean tracks that bias)
             np.testing.assert_allclose(r0[k].numpy(), one[k].numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+def test_collate_with_speed_perturbation(fake_backend):
+    """`speed_shift: true` (the reference's xf confs): one factor of {0.9, 1.0, 1.1} per training utterance, lengths, frame
+    fractions and SpecAugment spans follow the PERTURBED lengths, the mel rows behind an utterance's own frames are zero."""
+    import random
+    import lid.main as launcher
+    from lid.audio_processor import SPEED_FACTORS, num_frames, speed_out_len
+    cfg = load_cfg("data.feature.speed_shift=true", "+data.synthetic.min_seconds=0.3")
+    module, sets, params = launcher.build(cfg)
+    ds = sets["train"]
+    assert ds.feat.speed_shift and not sets["val"].train
+    random.seed(5)
+    items = [ds[i] for i in range(4)]
+    wb, texts, wav_pct, text_pct, paths, langs = ds.collate_fn(items)
+    assert wb.speed is not None and all(f in SPEED_FACTORS for f in wb.speed) and len(set(wb.speed)) > 1
+    in_lens = [int(it[0].shape[-1]) for it in items]
+    assert wb.n_samples.tolist() == in_lens
+    out_lens = [speed_out_len(n, p, q) for n, (p, q) in zip(in_lens, wb.speed)]
+    frames = [num_frames(n, wb.pad) for n in out_lens]
+    np.testing.assert_allclose(wav_pct.numpy(), np.array(frames, np.float32) / max(frames), rtol=1e-6)
+    assert wb.shape == (4, max(frames), 80)
+    mel = wb.to_mel()
+    assert mel.shape == (4, max(frames), 80)
+    for b, f in enumerate(frames):
+        assert float(mel[b, f:].abs().max()) == 0.0 if f < max(frames) else True
+    wbv = sets["val"].collate_fn([sets["val"][i] for i in range(4)])[0]
+    assert wbv.speed is None                                  # no augmentation outside training
