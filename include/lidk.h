@@ -146,6 +146,11 @@ int lidk_gemm_tn(const void* X, int ldx, const void* Y, int ldy, float* C, int l
  * qkv [B*T][3*heads*dh] (T): q | k | v column blocks, head h at columns h*dh.. within each.  rel_emb [2*max_pos+1][dh] f32.
  * scores = (q.k^T + q.rel_emb[clamp(i-j)+max_pos]) * dh^-0.5 ; probs = softmax_j ; out = probs.v -> [B*T][heads*dh] (T).
  * probs [B][heads][T][ldp] (T) is saved for backward. */
+/* Sequence-length limits: the MFMA kernels take T <= 256, the LDS-resident v1 kernels T <= ~390 (dh = 64); longer sequences
+ * (12 s training utterances give T = 600, 16.7 s validation utterances T = 835) run through key-tiled kernels of the same
+ * arithmetic.  lidk_attn_max_frames = the largest T those accept for a head dimension (16 score rows of T floats must fit in
+ * LDS: 2,069 for bf16 / dh = 64 = 41 s of audio, 1,655 in f32 mode); beyond it lidk_attn_fwd / lidk_attn_bwd return LIDK_ERR_UNSUPPORTED. */
+int lidk_attn_max_frames(int dh, int dtype);
 int lidk_attn_fwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, void* out, void* probs, int ldp, int B, int T,
                   int heads, int dh, int max_pos, int dtype, void* stream);
 /* dqkv [B*T][3*heads*dh] (T) written; drel_emb += (atomic f32).  dscores: scratch of B*heads*T*ldp floats. */

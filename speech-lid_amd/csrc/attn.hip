@@ -667,6 +667,14 @@ static void att_bwd_relpos_launch(const void* qkv, const void* dsT, int ldp, flo
 #undef LIDK_COLS_LAUNCH
 
 // ------------------------------------------------------------------------------------ host side
+// key-tiled kernels for sequences whose K / V / E do not fit in LDS (attn_long.hip)
+template <typename T>
+int att_long_fwd(const void* qkv, const float* emb, void* out, void* probs, int ldp, int B, int T_, int H, int dh, int max_pos,
+                 hipStream_t s);
+template <typename T>
+int att_long_bwd(const void* qkv, const float* emb, const void* probs, int ldp, const void* dout, void* dqkv, float* demb,
+                 float* dscores, int B, int T_, int H, int dh, int max_pos, hipStream_t s);
+
 template <typename T>
 static size_t att_rows_lds(int T_, int dh) {
   size_t a = (size_t)(2 * T_ + T_ + ATT_ROWS - 1) * (dh + AttPad<T>::v) * sizeof(T);
@@ -697,12 +705,12 @@ extern "C" int lidk_attn_fwd(const void* qkv, const float* rel_emb, const void* 
   dim3 grid(cdiv(T_, ATT_ROWS), heads, B);
   if (dtype == LIDK_BF16) {
     size_t lds = att_rows_lds<bf16>(T_, dh);
-    if (lds > 160 * 1024) return LIDK_ERR_UNSUPPORTED;
+    if (lds > 160 * 1024) return att_long_fwd<bf16>(qkv, rel_emb, out, probs, ldp, B, T_, heads, dh, max_pos, s);
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attn_fwd_kernel<bf16><<<grid, 256, lds, s>>>((const bf16*)qkv, rel_emb, (bf16*)out, (bf16*)probs, g, ldp, scale);
   } else if (dtype == LIDK_F32) {
     size_t lds = att_rows_lds<float>(T_, dh);
-    if (lds > 160 * 1024) return LIDK_ERR_UNSUPPORTED;
+    if (lds > 160 * 1024) return att_long_fwd<float>(qkv, rel_emb, out, probs, ldp, B, T_, heads, dh, max_pos, s);
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attn_fwd_kernel<float><<<grid, 256, lds, s>>>((const float*)qkv, rel_emb, (float*)out, (float*)probs, g, ldp, scale);
   } else {
@@ -725,7 +733,8 @@ static int att_bwd_launch(const void* qkv, const float* rel_emb, const void* pro
                           float* drel_emb, float* dscores, AttGeom g, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)g.dh);
   size_t lds = att_rows_lds<T>(g.T, g.dh);
-  if (lds > 160 * 1024 || (size_t)2 * g.T * g.dh * sizeof(float) > 160 * 1024) return LIDK_ERR_UNSUPPORTED;
+  if (lds > 160 * 1024 || (size_t)2 * g.T * g.dh * sizeof(float) > 160 * 1024)
+    return att_long_bwd<T>(qkv, rel_emb, probs, ldp, dout, dqkv, drel_emb, dscores, g.B, g.T, g.H, g.dh, g.max_pos, s);
   dim3 grid(cdiv(g.T, ATT_ROWS), g.H, g.B);
   (void)hipFuncSetAttribute((const void*)attn_bwd_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   attn_bwd_rows_kernel<T><<<grid, 256, lds, s>>>((const T*)qkv, rel_emb, (const T*)probs, (const T*)dout, (T*)dqkv,

@@ -142,12 +142,16 @@ __global__ void colsum_partial_kernel(const T* __restrict__ x, int ldx, float* _
 template <typename ACC, typename TOUT, bool ACCUM>
 __global__ void __launch_bounds__(1024)
 colreduce_kernel(const float* __restrict__ partial, int nparts, int ncols, TOUT* __restrict__ out0, TOUT* __restrict__ out1,
-                 int split, float scale, TOUT* __restrict__ dup = nullptr) {
+                 int split, float scale, TOUT* __restrict__ dup = nullptr, double tail = 0.0) {
   // 16 columns per workgroup (32 workgroups for the 512 LayerNorm columns instead of 8): a wave reads 4 partial rows x 16
   // columns per instruction; fixed summation order -> deterministic
   __shared__ ACC red[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane >> 4;
   const int c = blockIdx.x * 16 + (lane & 15);
+  if (tail > 0.0 && blockIdx.x == 0 && threadIdx.x == 0) {       // the row count behind the sums (lidk_reduce_partials_f64)
+    out0[ncols] = (TOUT)tail;
+    if (dup) dup[ncols] = (TOUT)tail;
+  }
   ACC acc = 0;
   if (c < ncols) {
 #pragma unroll 4
@@ -177,17 +181,12 @@ extern "C" int lidk_colsum(const void* x, int ldx, int xd, float* out, float* pa
   return launch_status();
 }
 
-__global__ void write_tail_f64_kernel(double* out, double* out2, int ncols, double tail) {
-  out[ncols] = tail;
-  if (out2) out2[ncols] = tail;
-}
-
 extern "C" int lidk_reduce_partials_f64(const float* partial, int nparts, int ncols, double* out, double* out2, double tail,
                                         void* stream) {
   if (!partial || !out || nparts <= 0 || ncols <= 0) return LIDK_ERR_ARG;
   colreduce_kernel<double, double, false><<<cdiv(ncols, 16), 1024, 0, as_stream(stream)>>>(partial, nparts, ncols, out,
-                                                                                          (double*)nullptr, ncols, 1.0f, out2);
-  if (tail > 0) write_tail_f64_kernel<<<1, 1, 0, as_stream(stream)>>>(out, out2, ncols, tail);
+                                                                                          (double*)nullptr, ncols, 1.0f, out2,
+                                                                                          tail);
   return launch_status();
 }
 

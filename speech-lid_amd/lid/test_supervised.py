@@ -45,6 +45,7 @@ def write_to_csv(result_file: str, trues: List[str], preds: List[str], probs: Li
 def score_dataset(module, dataset, result_file: str, device=None) -> Dict[str, float]:
     """Transcribe + language-score every utterance of ``dataset`` (items ``(wav, text ids, path, lang)``) with ``module``
     (a LidSuperviseModule on the GPU) and write the reference's result files.  Returns {"acc": ..., "cavg": ...}."""
+    from lid.audio_processor import normalize_wav
     from lid.eer import CAvg
     device = device or next(module.model.parameters()).device
     index2lang = {v: k for k, v in module.lang2index_dict.items()}
@@ -55,7 +56,9 @@ def score_dataset(module, dataset, result_file: str, device=None) -> Dict[str, f
     module.model.eval()
     for i in range(len(dataset)):
         wav, text, path, lang = dataset[i]
-        texts, lid_asr, _ = module.infer_tensor(wav.reshape(1, -1).to(device), module.sr, None)
+        # the reference's harness normalises the waveform itself and then calls infer_tensor (pad = 0 features)
+        x = normalize_wav(wav.reshape(1, -1).to(device))
+        texts, lid_asr, _ = module.infer_tensor(x, module.sr, None)
         prob = module.score_to_prob(lid_asr[0].tolist())
         pred_lang = names[int(torch.tensor(prob).argmax())]
         correct += int(pred_lang == lang)

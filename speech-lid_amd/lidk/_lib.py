@@ -58,6 +58,7 @@ SIGNATURES = {
     "lidk_attn_bwd_relpos_supported": (_I, [_I, _I, _I]),
     "lidk_attn_bwd_relpos": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_attn_bwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lidk_attn_max_frames": (_I, [_I, _I]),
     "lidk_attn_ldp": (_I, [_I, _I, _I]),
     "lidk_selftest_tr16": (_I, [_P, _P, _P]),
     "lidk_glu_fwd": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -419,6 +419,13 @@ class Engine:
         key = (B, F_)
         w = self._work.pop(key, None)
         if w is None:
+            if self._hip and hasattr(self.k, "attn_max_frames"):
+                T = (F_ + 2 - 3) // 2 + 1
+                lim = min(self.k.attn_max_frames(self.cfg.dim_head, self.act_dtype),
+                          self.k.attn_max_frames(self.cfg.last_dim_head, self.act_dtype))
+                if T > lim:
+                    raise LidkError(f"a batch of {F_} feature frames (T = {T} after subsampling, {F_ / 100:.1f} s of audio) exceeds the "
+                                    f"attention kernels' limit of T = {lim} ({lim / 50:.0f} s): lower data.max_duration")
             bucket = max(int(_os_env("LIDK_FRAME_BUCKET", "64")), 1)
             ckey = (B, _ceil(F_, bucket))
             pool = self._pools.pop(ckey, None)

@@ -288,6 +288,11 @@ def attn_ldp(T, dh, dtype):
     return lib().lidk_attn_ldp(T, dh, dtype_code(dtype))
 
 
+def attn_max_frames(dh, dtype):
+    """Largest sequence length T (after subsampling) the attention kernels accept for this head dimension."""
+    return lib().lidk_attn_max_frames(dh, dtype_code(dtype))
+
+
 def attn_fwd(qkv, rel_emb, out, probs, B, T, heads, dh, rel_emb_T=None):
     max_pos = (rel_emb.shape[0] - 1) // 2
     check(lib().lidk_attn_fwd(_p(qkv), _p(rel_emb), _p(rel_emb_T), _p(out), _p(probs), probs.shape[-1], B, T, heads, dh,

@@ -295,6 +295,45 @@ def test_attention_fwd_bwd(dt, B, T, H, dh, maxpos, path):
         check("attn_demb_split", demb2, demb, 1e-4 * max(1.0, float(demb.abs().max())))      # float atomics: order only
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,T,H,dh,maxpos", [(1, 600, 4, 64, 512), (1, 835, 2, 64, 512), (2, 420, 8, 32, 512), (1, 1100, 1, 64, 512)])
+def test_attention_long_sequences(dt, B, T, H, dh, maxpos):
+    """Sequences beyond the LDS-resident kernels (ADVICE r1: conf max_duration 12 s -> T = 600, validation 16.7 s -> T = 835;
+    T = 1100 also exceeds the relative-position table, so offsets clamp at +-512): the key-tiled kernels against torch."""
+    inner = H * dh
+    qkv = (0.7 * torch.randn(B * T, 3 * inner, generator=g(30)))
+    emb = (0.5 * torch.randn(2 * maxpos + 1, dh, generator=g(31)))
+    qkv_r = rt(qkv, dt).requires_grad_()
+    emb_r = (rt(emb, dt) if dt == torch.bfloat16 else emb.clone()).requires_grad_()
+    out_ref, p_ref = _attn_ref(qkv_r, emb_r, B, T, H, dh)
+    dout = torch.randn(B * T, inner, generator=g(32))
+    out_ref.backward(rt(dout, dt))
+    assert T <= ops.attn_max_frames(dh, dt)
+    qd, ed = dev(qkv, dt), dev(emb)
+    ldp = ops.attn_ldp(T, dh, dt)
+    assert ldp == T                                             # not the MFMA layout
+    out = torch.empty(B * T, inner, device=DEV, dtype=dt)
+    probs = torch.zeros(B, H, T, ldp, device=DEV, dtype=dt)
+    ops.attn_fwd(qd, ed, out, probs, B, T, H, dh, rel_emb_T=dev(emb, dt))
+    check("attn_long_probs", probs, p_ref, tol(dt, 2e-6, 4e-3))
+    check("attn_long_out", out, out_ref, tol(dt, 1e-5, 1.5e-2))
+    dqkv = torch.zeros(B * T, 3 * inner, device=DEV, dtype=dt)
+    demb = torch.zeros_like(ed)
+    dsc = torch.empty(B, H, T, (T + 31) // 32 * 32, device=DEV)
+    ops.attn_bwd(qd, ed, probs, dev(dout, dt), dqkv, demb, dsc, B, T, H, dh, rel_emb_T=dev(emb, dt))
+    gs = float(qkv_r.grad.abs().max())
+    check("attn_long_dqkv", dqkv, qkv_r.grad, tol(dt, 2e-5 * max(1, gs), 3e-2 * max(1, gs)))
+    check("attn_long_demb", demb, emb_r.grad, tol(dt, 2e-4, 6e-2) * max(1.0, float(emb_r.grad.abs().max())))
+
+
+def test_attention_refuses_sequences_beyond_the_documented_limit():
+    T = ops.attn_max_frames(64, torch.bfloat16) + 1
+    qkv = torch.zeros(T, 3 * 64, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(LidkError):
+        ops.attn_fwd(qkv, torch.zeros(1025, 64, device=DEV), torch.empty(T, 64, device=DEV, dtype=torch.bfloat16),
+                     torch.empty(1, 1, T, T, device=DEV, dtype=torch.bfloat16), 1, T, 1, 64)
+
+
 def test_tr16_hardware_mapping():
     """Pins the ds_read_b64_tr_b16 lane mapping (MI355X guide, T10) that the transposed-operand kernels are written against."""
     tile = (torch.arange(8)[:, None] * 100 + torch.arange(64)[None, :]).to(torch.int16)

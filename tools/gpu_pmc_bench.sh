@@ -4,8 +4,8 @@
 mkdir -p gpurun_out && rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 export LIDK_GRAPHS=0
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_fetch.log 2>&1; echo "fetch rc=$?"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_write.log 2>&1; echo "write rc=$?"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --cavg-steps 0 --fit-epochs 0 --resident 1 > gpurun_out/pmc_fetch.log 2>&1; echo "fetch rc=$?"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --cavg-steps 0 --fit-epochs 0 --resident 1 > gpurun_out/pmc_write.log 2>&1; echo "write rc=$?"
 python3 - <<'PY'
 import csv, glob, json, collections
 out = {}
