@@ -446,7 +446,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cavg-steps", type=int, default=3000, help="extra training steps before the validation Cavg (0 = skip)")
+    ap.add_argument("--cavg-steps", type=int, default=5000, help="extra training steps before the validation Cavg (0 = skip)")
     ap.add_argument("--cavg-eval-every", type=int, default=0, help="also validate every K extra steps (exploration aid)")
     ap.add_argument("--fit-epochs", type=int, default=4, help="epochs of the Trainer.fit measurement (0 = skip)")
     ap.add_argument("--fit-workers", type=int, default=4)

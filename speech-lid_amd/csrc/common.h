@@ -29,6 +29,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the GEMM epilogues were VALU-issue bound on it
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// GELU, exact erf form (torch.nn.functional.gelu default; lid/wavlm/modules.py gelu)
+__device__ __forceinline__ float gelu_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
 // 4-wide load/store of activations held as T (float or bf16); p must be 4-element aligned.
 __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 load4(const bf16* p) {

@@ -40,6 +40,8 @@ __device__ __forceinline__ void epi_store(const Epi& e, int m, int n, float acc)
     v = v * sigmoidf_(v);
   } else if (e.act == LIDK_ACT_RELU) {
     v = fmaxf(v, 0.f);
+  } else if (e.act == LIDK_ACT_GELU) {
+    v = gelu_(v);
   } else if (e.act == LIDK_ACT_SWISH_GRAD) {
     float a = to_f(((const T*)e.aux)[(size_t)m * e.ldaux + n]);
     float s = sigmoidf_(a);
@@ -70,6 +72,8 @@ __device__ __forceinline__ void epi_store4(const Epi& e, int m, int n, int N, fl
     v.x *= sigmoidf_(v.x); v.y *= sigmoidf_(v.y); v.z *= sigmoidf_(v.z); v.w *= sigmoidf_(v.w);
   } else if (e.act == LIDK_ACT_RELU) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  } else if (e.act == LIDK_ACT_GELU) {
+    v.x = gelu_(v.x); v.y = gelu_(v.y); v.z = gelu_(v.z); v.w = gelu_(v.w);
   } else if (e.act == LIDK_ACT_SWISH_GRAD) {
     float4 a = load4((const T*)e.aux + (size_t)m * e.ldaux + n);
     float s;
@@ -222,6 +226,8 @@ __device__ __forceinline__ float4 epi_math4(const Epi& e, int m, int n, float4 v
     v.x *= sigmoidf_(v.x); v.y *= sigmoidf_(v.y); v.z *= sigmoidf_(v.z); v.w *= sigmoidf_(v.w);
   } else if (e.act == LIDK_ACT_RELU) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  } else if (e.act == LIDK_ACT_GELU) {
+    v.x = gelu_(v.x); v.y = gelu_(v.y); v.z = gelu_(v.z); v.w = gelu_(v.w);
   } else if (e.act == LIDK_ACT_SWISH_GRAD) {
     float4 a = load4((const bf16*)e.aux + (size_t)m * e.ldaux + n);
     float s;
@@ -555,7 +561,7 @@ gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, int
 // ------------------------------------------------------------------------------------ host dispatch
 extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
   if (!g || !g->A || !g->B || !g->out || g->M <= 0 || g->N <= 0 || g->K <= 0) return LIDK_ERR_ARG;
-  if ((g->K & 7) || (g->lda & 7) || (g->ldb & 7) || g->lda < g->K || g->ldb < g->K || g->ldo < g->N) return LIDK_ERR_ARG;
+  if ((g->K & 7) || (g->lda & 7) || (g->ldb & 7) || g->ldb < g->K || g->ldo < g->N) return LIDK_ERR_ARG;
   if (g->act == LIDK_ACT_SWISH_GRAD && !g->aux) return LIDK_ERR_ARG;
   int splitk = g->splitk > 1 ? g->splitk : 1;
   if (splitk > 1 && (g->bias || g->res || g->act != LIDK_ACT_NONE || !g->out_f32)) return LIDK_ERR_ARG;

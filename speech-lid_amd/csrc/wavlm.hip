@@ -1,0 +1,325 @@
+// WavLM backbone pieces that are not plain GEMM / LayerNorm launches (lid/wavlm/WavLM.py, lid/wavlm/modules.py), forward pass:
+//   * conv layer 0 of the feature extractor: Conv1d(1, C, k10, s5, no bias) + GroupNorm(C groups = per-channel statistics over
+//     time) + GELU, channel-last output.  K = 10 is far too thin for MFMA and the input is the raw waveform, so the convolution is
+//     recomputed in both passes instead of storing its f32 pre-norm output (9,599 x 512 per 3 s utterance): pass 1 reduces
+//     per-(utterance, channel) sums, pass 2 normalises + GELU and writes bf16.  (Layers 1-6 are GEMMs over strided views of the
+//     channel-last signal, see lidk_gemm_nt: lda < K.)
+//   * the grouped positional convolution's operand layout: group-major, zero-padded copies so that each group's k128 window is
+//     contiguous and the convolution is 16 GEMMs with lda = 48;
+//   * the gated relative position bias (GRU-style gate from the layer input, modules.py:519-528) and the attention core with an
+//     additive (gate x bucketed relative bias) term: one workgroup per (batch, head), K / V^T / the head's 1-D bias table in LDS,
+//     S = Q.K^T and O = P.V on v_mfma_f32_16x16x32_bf16, softmax by 16-lane shuffles.
+#include "common.h"
+
+#define W0_K 10
+#define W0_S 5
+#define W0_TC 128          // time steps per workgroup
+
+// ------------------------------------------------------------------------------------ conv layer 0
+// partial [B][nchunk][C][2]
+__global__ void __launch_bounds__(256)
+wavlm_conv0_stats_kernel(const float* __restrict__ wav, int L, const float* __restrict__ w, float* __restrict__ partial, int T0,
+                         int C) {
+  __shared__ float xs[W0_TC * W0_S + W0_K];
+  const int b = blockIdx.y, t0 = blockIdx.x * W0_TC, nt = min(W0_TC, T0 - t0);
+  const float* x = wav + (size_t)b * L + (size_t)t0 * W0_S;
+  for (int i = threadIdx.x; i < nt * W0_S + W0_K - W0_S; i += 256) xs[i] = x[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float wk[W0_K];
+#pragma unroll
+    for (int k = 0; k < W0_K; ++k) wk[k] = w[c * W0_K + k];
+    float s = 0.f, ss = 0.f;
+    for (int t = 0; t < nt; ++t) {
+      float y = 0.f;
+#pragma unroll
+      for (int k = 0; k < W0_K; ++k) y = fmaf(wk[k], xs[t * W0_S + k], y);
+      s += y; ss = fmaf(y, y, ss);
+    }
+    float* p = partial + (((size_t)b * gridDim.x + blockIdx.x) * C + c) * 2;
+    p[0] = s; p[1] = ss;
+  }
+}
+// stats [B][C][2] = (mean, rstd), biased variance (nn.GroupNorm)
+__global__ void wavlm_gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int C, int T0, float eps,
+                                         float* __restrict__ stats) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* p = partial + (((size_t)b * nchunk + k) * C + c) * 2;
+      s += (double)p[0]; ss += (double)p[1];
+    }
+    const double mu = s / T0;
+    double var = ss / T0 - mu * mu;
+    if (var < 0) var = 0;
+    stats[((size_t)b * C + c) * 2] = (float)mu;
+    stats[((size_t)b * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+// out [B*P0][C] bf16 (row pitch P0 >= T0; rows T0..P0-1 are zero)
+__global__ void __launch_bounds__(256)
+wavlm_conv0_apply_kernel(const float* __restrict__ wav, int L, const float* __restrict__ w, const float* __restrict__ stats,
+                         const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ out, int T0, int P0,
+                         int C) {
+  __shared__ float xs[W0_TC * W0_S + W0_K];
+  const int b = blockIdx.y, t0 = blockIdx.x * W0_TC;
+  const int nt = max(0, min(W0_TC, T0 - t0)), np = min(W0_TC, P0 - t0);
+  const float* x = wav + (size_t)b * L + (size_t)t0 * W0_S;
+  if (nt > 0) for (int i = threadIdx.x; i < nt * W0_S + W0_K - W0_S; i += 256) xs[i] = x[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float wk[W0_K];
+#pragma unroll
+    for (int k = 0; k < W0_K; ++k) wk[k] = w[c * W0_K + k];
+    const float mu = stats[((size_t)b * C + c) * 2], rs = stats[((size_t)b * C + c) * 2 + 1], g = gamma[c], be = beta[c];
+    bf16* o = out + ((size_t)b * P0 + t0) * C + c;
+    for (int t = 0; t < np; ++t) {
+      float v = 0.f;
+      if (t < nt) {
+        float y = 0.f;
+#pragma unroll
+        for (int k = 0; k < W0_K; ++k) y = fmaf(wk[k], xs[t * W0_S + k], y);
+        v = gelu_((y - mu) * rs * g + be);
+      }
+      o[(size_t)t * C] = (bf16)v;
+    }
+  }
+}
+
+extern "C" long lidk_wavlm_conv0_workspace(int B, int T0, int C) {
+  return ((long)B * cdiv(T0, W0_TC) * C * 2 + (long)B * C * 2) * (long)sizeof(float);
+}
+extern "C" int lidk_wavlm_conv0(const float* wav, int B, int L, const float* w, const float* gamma, const float* beta, float eps,
+                                void* out, int T0, int P0, int C, float* workspace, void* stream) {
+  if (!wav || !w || !gamma || !beta || !out || !workspace || B <= 0 || C <= 0 || T0 <= 0 || P0 < T0) return LIDK_ERR_ARG;
+  if ((long)(T0 - 1) * W0_S + W0_K > L) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  const int nchunk = cdiv(T0, W0_TC);
+  float* partial = workspace;
+  float* stats = workspace + (size_t)B * nchunk * C * 2;
+  wavlm_conv0_stats_kernel<<<dim3(nchunk, B), 256, 0, s>>>(wav, L, w, partial, T0, C);
+  wavlm_gn_finalize_kernel<<<B, 256, 0, s>>>(partial, nchunk, C, T0, eps, stats);
+  wavlm_conv0_apply_kernel<<<dim3(cdiv(P0, W0_TC), B), 256, 0, s>>>(wav, L, w, stats, gamma, beta, (bf16*)out, T0, P0, C);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ positional conv operand layout
+// x [B*T][C] f32 -> xg [G][B*Pp + slack][C/G] bf16: row (b, u) = x[b][u - pad_left] (zero outside [0, T)); rows behind B*Pp zero.
+__global__ void wavlm_posconv_prep_kernel(const float* __restrict__ x, bf16* __restrict__ xg, int B, int T_, int C, int G, int Pp,
+                                          int pad_left, long rows_total) {
+  const int cg = C / G;
+  const long n = rows_total * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long row = i / C;                         // over rows_total = B*Pp + slack
+    float v = 0.f;
+    if (row < (long)B * Pp) {
+      const int b = (int)(row / Pp), u = (int)(row % Pp) - pad_left;
+      if (u >= 0 && u < T_) v = x[((size_t)b * T_ + u) * C + c];
+    }
+    const int g = c / cg, cc = c - g * cg;
+    xg[((size_t)g * rows_total + row) * cg + cc] = (bf16)v;
+  }
+}
+extern "C" int lidk_wavlm_posconv_prep(const float* x, void* xg, int B, int T_, int C, int G, int Pp, int pad_left, long rows_total,
+                                       void* stream) {
+  if (!x || !xg || B <= 0 || T_ <= 0 || C <= 0 || G <= 0 || C % G || Pp < T_ + pad_left || rows_total < (long)B * Pp) return LIDK_ERR_ARG;
+  const long n = rows_total * C;
+  int blocks = (int)((n + 255) / 256); if (blocks > 16384) blocks = 16384;
+  wavlm_posconv_prep_kernel<<<blocks, 256, 0, as_stream(stream)>>>(x, (bf16*)xg, B, T_, C, G, Pp, pad_left, rows_total);
+  return launch_status();
+}
+// out[b][t][:] = x[b][t][:] + y[b*Pp + t][:]   (y holds Pp rows per utterance, the first T are valid)
+__global__ void wavlm_add_rows_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int T_,
+                                      int Pp, int C, long n4) {
+  const int c4 = C / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / c4; const int c = (int)(i % c4) * 4;
+    const long b = row / T_, t = row % T_;
+    float4 a = load4(x + row * C + c), d = load4(y + (b * Pp + t) * C + c);
+    a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+    store4(out + row * C + c, a);
+  }
+}
+extern "C" int lidk_wavlm_add_rows(const float* x, const float* y, float* out, int B, int T_, int Pp, int C, void* stream) {
+  if (!x || !y || !out || B <= 0 || T_ <= 0 || Pp < T_ || C <= 0 || (C & 3)) return LIDK_ERR_ARG;
+  const long n4 = (long)B * T_ * C / 4;
+  int blocks = (int)((n4 + 255) / 256); if (blocks > 16384) blocks = 16384;
+  wavlm_add_rows_kernel<<<blocks, 256, 0, as_stream(stream)>>>(x, y, out, T_, Pp, C, n4);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ gate of the relative position bias
+// modules.py:519-528: per (b, h, t): u = grep_linear(x[b][t][h*dh : (h+1)*dh]) (8 values) ; (ga, gb) = sigmoid of the sums of
+// u[0:4], u[4:8] ; gate = ga * (gb * grep_a[h] - 1) + 2.   x is the LAYER INPUT (not the projected query).
+__global__ void __launch_bounds__(256)
+wavlm_gate_kernel(const float* __restrict__ x, const float* __restrict__ wg, const float* __restrict__ bg,
+                  const float* __restrict__ grep_a, float* __restrict__ gate, int B, int T_, int H, int dh) {
+  const long n = (long)B * T_ * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int h = (int)(i % H); const long m = i / H;
+    const float* xr = x + m * (long)H * dh + (long)h * dh;
+    float u[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = bg[q];
+    for (int d = 0; d < dh; ++d) {
+      const float v = xr[d];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) u[q] = fmaf(wg[q * dh + d], v, u[q]);
+    }
+    const float ga = 1.f / (1.f + __expf(-(u[0] + u[1] + u[2] + u[3])));
+    const float gb = 1.f / (1.f + __expf(-(u[4] + u[5] + u[6] + u[7])));
+    const long b = m / T_, t = m % T_;
+    gate[(b * H + h) * T_ + t] = ga * (gb * grep_a[h] - 1.f) + 2.f;
+  }
+}
+extern "C" int lidk_wavlm_gate(const float* x, const float* wg, const float* bg, const float* grep_a, float* gate, int B, int T_,
+                               int H, int dh, void* stream) {
+  if (!x || !wg || !bg || !grep_a || !gate || B <= 0 || T_ <= 0 || H <= 0 || dh <= 0) return LIDK_ERR_ARG;
+  const long n = (long)B * T_ * H;
+  int blocks = (int)((n + 255) / 256); if (blocks > 16384) blocks = 16384;
+  wavlm_gate_kernel<<<blocks, 256, 0, as_stream(stream)>>>(x, wg, bg, grep_a, gate, B, T_, H, dh);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ attention with gated relative bias (forward)
+// scores[i][j] = scale * q_i.k_j + gate[b][h][i] * rb[h][j - i] ; probs = softmax_j ; out = probs.v
+// qkv [B*T][3*H*DH] bf16 (q | k | v column blocks, head h at columns h*DH); rb [H][2*RB-1] f32, entry r + RB - 1 for offset r = j - i.
+#define WA_KPAD 8
+template <int DH>
+__global__ void __launch_bounds__(1024)
+wavlm_attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ gate, const float* __restrict__ rb,
+                      bf16* __restrict__ out, int T_, int H, int RB, float scale, int NJ) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int Tp = NJ * 16, Tp32 = (Tp + 31) / 32 * 32, LDK = DH + WA_KPAD, LDV = Tp32 + WA_KPAD;
+  bf16* Ks = reinterpret_cast<bf16*>(smem);                      // [Tp][LDK]
+  bf16* Vt = Ks + (size_t)Tp * LDK;                              // [DH][LDV]
+  float* rbs = reinterpret_cast<float*>(Vt + (size_t)DH * LDV);  // [2*Tp]: rbs[r + Tp]
+  bf16* Pw = reinterpret_cast<bf16*>(rbs + 2 * Tp);              // [nw][16][LDV]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, inner = H * DH, ld = 3 * inner;
+  const bf16* base = qkv + (size_t)b * T_ * ld + h * DH;
+  for (int idx = threadIdx.x; idx < Tp * (DH / 8); idx += blockDim.x) {            // K rows, 16 B per access
+    const int j = idx / (DH / 8), c8 = (idx % (DH / 8)) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (j < T_) v = *reinterpret_cast<const uint4*>(base + (size_t)j * ld + inner + c8);
+    *reinterpret_cast<uint4*>(&Ks[j * LDK + c8]) = v;
+  }
+  for (int idx = threadIdx.x; idx < Tp32 * DH; idx += blockDim.x) {                 // V transposed
+    const int j = idx / DH, d = idx % DH;
+    Vt[d * LDV + j] = j < T_ ? base[(size_t)j * ld + 2 * inner + d] : (bf16)0.f;
+  }
+  for (int idx = threadIdx.x; idx < 2 * Tp; idx += blockDim.x) {
+    const int r = idx - Tp;
+    rbs[idx] = (r > -T_ && r < T_) ? rb[(size_t)h * (2 * RB - 1) + r + RB - 1] : 0.f;
+  }
+  __syncthreads();
+  bf16* P = Pw + (size_t)wave * 16 * LDV;
+  const float* grow = gate + ((size_t)b * H + h) * T_;
+  for (int qb = wave; qb * 16 < T_; qb += nw) {
+    const int i0 = qb * 16;
+    bf16x8 aq[DH / 32];
+#pragma unroll
+    for (int kk = 0; kk < DH / 32; ++kk)
+      aq[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)min(i0 + fr, T_ - 1) * ld + kk * 32 + fq * 8);
+    float gi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gi[r] = grow[min(i0 + 4 * fq + r, T_ - 1)];
+    // ---- S tiles: lane holds rows i0 + 4*fq + r (r = 0..3), key column jt*16 + fr
+    f32x4 S[16];                                          // NJ <= 16
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int jt = 0; jt < 16; ++jt) {
+      if (jt < NJ) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DH / 32; ++kk) {
+          const bf16x8 bk = *reinterpret_cast<const bf16x8*>(&Ks[(jt * 16 + fr) * LDK + kk * 32 + fq * 8]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[kk], bk, acc, 0, 0, 0);
+        }
+        const int j = jt * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = i0 + 4 * fq + r;
+          float s = acc[r] * scale + gi[r] * rbs[j - i + Tp];
+          if (j >= T_) s = -INFINITY;
+          acc[r] = s;
+          mx[r] = fmaxf(mx[r], s);
+        }
+        S[jt] = acc;
+      }
+    }
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      for (int o = 1; o < 16; o <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+    }
+#pragma unroll
+    for (int jt = 0; jt < 16; ++jt) {
+      if (jt < NJ) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float e = __expf(S[jt][r] - mx[r]); S[jt][r] = e; sum[r] += e; }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      for (int o = 1; o < 16; o <<= 1) sum[r] += __shfl_xor(sum[r], o, 64);
+      sum[r] = 1.f / sum[r];
+    }
+    // ---- P (bf16) -> this wave's LDS tile [16][LDV], zero padded to Tp32
+#pragma unroll
+    for (int jt = 0; jt < 16; ++jt) {
+      if (jt < NJ) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[(4 * fq + r) * LDV + jt * 16 + fr] = (bf16)(S[jt][r] * sum[r]);
+      }
+    }
+    if (Tp32 > Tp) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[(4 * fq + r) * LDV + Tp + fr] = (bf16)0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- O = P.V : A = P rows (queries, k = keys), B = V^T rows (d, k = keys)
+    f32x4 O[DH / 16];
+#pragma unroll
+    for (int nt = 0; nt < DH / 16; ++nt) O[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < Tp32 / 32; ++kt) {
+      const bf16x8 ap = *reinterpret_cast<const bf16x8*>(&P[fr * LDV + kt * 32 + fq * 8]);
+#pragma unroll
+      for (int nt = 0; nt < DH / 16; ++nt) {
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(&Vt[(nt * 16 + fr) * LDV + kt * 32 + fq * 8]);
+        O[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, bv, O[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < DH / 16; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * fq + r;
+        if (i < T_) out[((size_t)b * T_ + i) * inner + h * DH + nt * 16 + fr] = (bf16)O[nt][r];
+      }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+static size_t wavlm_attn_lds(int NJ, int DH, int nw) {
+  const int Tp = NJ * 16, Tp32 = (Tp + 31) / 32 * 32;
+  return (size_t)Tp * (DH + WA_KPAD) * 2 + (size_t)DH * (Tp32 + WA_KPAD) * 2 + (size_t)2 * Tp * 4 + (size_t)nw * 16 * (Tp32 + WA_KPAD) * 2;
+}
+extern "C" int lidk_wavlm_attn_max_frames(int dh) { return dh == 64 ? 256 : 0; }
+extern "C" int lidk_wavlm_attn_fwd(const void* qkv, const float* gate, const float* rb, void* out, int B, int T_, int H, int dh,
+                                   int RB, void* stream) {
+  if (!qkv || !gate || !rb || !out || B <= 0 || T_ <= 0 || H <= 0 || RB < T_) return LIDK_ERR_ARG;
+  if (dh != 64 || T_ > 256) return LIDK_ERR_UNSUPPORTED;
+  const int NJ = cdiv(T_, 16);
+  int nw = NJ < 16 ? NJ : 16;
+  while (nw > 1 && wavlm_attn_lds(NJ, 64, nw) > 160 * 1024) --nw;
+  const size_t lds = wavlm_attn_lds(NJ, 64, nw);
+  if (lds > 160 * 1024) return LIDK_ERR_UNSUPPORTED;
+  (void)hipFuncSetAttribute((const void*)wavlm_attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  wavlm_attn_fwd_kernel<64><<<B * H, 64 * nw, lds, as_stream(stream)>>>((const bf16*)qkv, gate, rb, (bf16*)out, T_, H, RB,
+                                                                        1.0f / sqrtf(64.0f), NJ);
+  return launch_status();
+}

@@ -5,7 +5,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_SWISH, ACT_RELU, ACT_SWISH_GRAD = 0, 1, 2, 3
+ACT_NONE, ACT_SWISH, ACT_RELU, ACT_SWISH_GRAD, ACT_GELU = 0, 1, 2, 3, 4
 LN_PARTIAL_BLOCKS = 256
 LN_BWD_BLOCKS = 1024
 BN_PARTIAL_BLOCKS = 1024
@@ -79,6 +79,13 @@ SIGNATURES = {
     "lidk_ctc_workspace_bytes": (_L, [_I, _I, _I, _I]),
     "lidk_ctc_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "lidk_lid_score": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "lidk_wavlm_conv0_workspace": (_L, [_I, _I, _I]),
+    "lidk_wavlm_conv0": (_I, [_P, _I, _I, _P, _P, _P, _F, _P, _I, _I, _I, _P, _P]),
+    "lidk_wavlm_posconv_prep": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _L, _P]),
+    "lidk_wavlm_add_rows": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "lidk_wavlm_gate": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "lidk_wavlm_attn_max_frames": (_I, [_I]),
+    "lidk_wavlm_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lidk_ctc_greedy": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "lidk_lid_mlp": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_novograd_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P]),

@@ -446,6 +446,45 @@ def lid_mlp(scores, w0, b0, w2, b2, out):
     return out
 
 
+# ----------------------------------------------------------------------------------------------- WavLM backbone (forward)
+def wavlm_conv0(wav, w, gamma, beta, out, T0, P0, eps=1e-5):
+    """wav (B, L) f32 -> out (B*P0 [+slack], C) bf16: Conv1d(1, C, k10, s5) + GroupNorm(C, C) + GELU, channel-last."""
+    B, Lw = wav.shape
+    Cc = w.shape[0]
+    ws = torch.empty(max(lib().lidk_wavlm_conv0_workspace(B, T0, Cc) // 4, 1), device=wav.device, dtype=torch.float32)
+    check(lib().lidk_wavlm_conv0(_p(wav), B, Lw, _p(w), _p(gamma), _p(beta), eps, _p(out), T0, P0, Cc, _p(ws), _stream()),
+          "wavlm_conv0")
+    return out
+
+
+def wavlm_posconv_prep(x, xg, B, T, G, Pp, pad_left):
+    """x (B*T, C) f32 -> xg (G, rows_total, C/G) bf16 zero-padded group-major copy."""
+    check(lib().lidk_wavlm_posconv_prep(_p(x), _p(xg), B, T, x.shape[1], G, Pp, pad_left, xg.shape[1], _stream()),
+          "wavlm_posconv_prep")
+    return xg
+
+
+def wavlm_add_rows(x, y, out, B, T, Pp):
+    check(lib().lidk_wavlm_add_rows(_p(x), _p(y), _p(out), B, T, Pp, x.shape[1], _stream()), "wavlm_add_rows")
+    return out
+
+
+def wavlm_gate(x, wg, bg, grep_a, gate, B, T, H, dh):
+    check(lib().lidk_wavlm_gate(_p(x), _p(wg), _p(bg), _p(grep_a), _p(gate), B, T, H, dh, _stream()), "wavlm_gate")
+    return gate
+
+
+def wavlm_attn_max_frames(dh):
+    return lib().lidk_wavlm_attn_max_frames(dh)
+
+
+def wavlm_attn_fwd(qkv, gate, rb, out, B, T, H, dh):
+    """rb (H, 2*RB-1) f32: the head's bias as a function of the offset j - i (entry r + RB - 1)."""
+    RB = (rb.shape[1] + 1) // 2
+    check(lib().lidk_wavlm_attn_fwd(_p(qkv), _p(gate), _p(rb), _p(out), B, T, H, dh, RB, _stream()), "wavlm_attn_fwd")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- optimizer
 def novograd_step(params, grads, exp_avg, exp_avg_sq, work, n_tensors, lr, betas, eps, weight_decay, grad_averaging,
                   max_norm, scratch, total_norm):

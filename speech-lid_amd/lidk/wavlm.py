@@ -1,0 +1,216 @@
+"""WavLM backbone on the lidk kernels - forward pass (reference lid/wavlm/WavLM.py, lid/wavlm/modules.py).
+
+``WavLMBackbone`` holds the backbone's parameters (names and shapes of the reference ``WavLM.state_dict()``, so public
+WavLM-Base(+) checkpoints load as they are), keeps bf16 GEMM operands prepared once, and maps a batch of raw 16 kHz waveforms
+``(B, L)`` to the transformer output ``(B, T, d)`` exactly as ``WavLM.extract_features(source, padding_mask, mask=False)``
+does (the reference never passes the padding mask into the encoder, WavLM.py:390-394).  No torch layers, no autograd: the
+reference trains its LID heads on top of a FROZEN backbone for the first epochs (``freeze_encoder_epoch`` /
+``freeze_tranformer_epoch``, lid/LidModule_ASR.py:24-26,243-258), which is the regime this forward-only path serves;
+fine-tuning the backbone itself (its backward pass) is not built yet.
+
+MI355X-first design of the pieces:
+  * activations are channel-last ``[rows][C]``; the strided Conv1d layers 1-6 of the feature extractor are GEMMs over strided
+    VIEWS of the previous layer's output (row t = the kW*C contiguous values from input row stride*t: ``lda = stride*C < K``),
+    no im2col, GELU in the epilogue.  Per-utterance row pitches are chosen P_l = 2*P_{l+1} so one launch covers the batch;
+  * layer 0 (k10 s5 on the raw waveform + per-channel GroupNorm over time + GELU) is recomputed in two passes instead of
+    storing its f32 pre-norm output (lidk_wavlm_conv0);
+  * the grouped positional convolution (k128, 16 groups) runs as 16 GEMMs with lda = 48 over a group-major zero-padded copy;
+  * q/k/v projections are one fused [3d, d] GEMM; the bucketed relative position bias is a per-head 1-D table over the offset
+    j - i (built once from the layer-0 embedding), gated per (batch, head, query) by a GRU-style gate of the layer input and
+    added inside the MFMA attention kernel (lidk_wavlm_attn_fwd).
+"""
+import math
+from typing import Dict, List
+
+import torch
+
+from . import _lib as L
+from . import ops
+from ._lib import LidkError
+
+
+def conv_out_len(n: int, k: int, s: int) -> int:
+    return (n - k) // s + 1
+
+
+def relative_buckets(rel: torch.Tensor, num_buckets: int, max_distance: int) -> torch.Tensor:
+    """Bucket of a relative position (memory - context), bidirectional (lid/wavlm/modules.py:409-433)."""
+    nb = num_buckets // 2
+    out = (rel > 0).long() * nb
+    n = rel.abs()
+    max_exact = nb // 2
+    is_small = n < max_exact
+    large = max_exact + (torch.log(n.float().clamp_min(1) / max_exact) / math.log(max_distance / max_exact)
+                         * (nb - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    return out + torch.where(is_small, n, large)
+
+
+class WavLMBackbone:
+    RB = 1024                       # the bias table covers offsets |j - i| < RB
+
+    def __init__(self, cfg: Dict):
+        self.cfg = dict(cfg)
+        self.layers_spec = eval(cfg.get("conv_feature_layers", "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"))
+        self.C = self.layers_spec[0][0]
+        if any(c != self.C for c, _, _ in self.layers_spec) or self.layers_spec[0][1:] != (10, 5):
+            raise NotImplementedError("lidk WavLM: conv feature extractor of the (C,10,5) + (C,k,s)* form with one width")
+        if cfg.get("extractor_mode", "default") != "default" or cfg.get("conv_bias", False) or cfg.get("layer_norm_first", False):
+            raise NotImplementedError("lidk WavLM: extractor_mode=default, conv_bias=False, layer_norm_first=False (WavLM-Base/Base+)")
+        if not (cfg.get("relative_position_embedding", False) and cfg.get("gru_rel_pos", False)):
+            raise NotImplementedError("lidk WavLM: relative_position_embedding + gru_rel_pos (every released WavLM checkpoint)")
+        self.d = cfg.get("encoder_embed_dim", 768)
+        self.ffn = cfg.get("encoder_ffn_embed_dim", 3072)
+        self.H = cfg.get("encoder_attention_heads", 12)
+        self.dh = self.d // self.H
+        self.n_layers = cfg.get("encoder_layers", 12)
+        self.kpos, self.gpos = cfg.get("conv_pos", 128), cfg.get("conv_pos_groups", 16)
+        self.params: Dict[str, torch.Tensor] = {}
+        self.device = torch.device("cpu")
+        self._prepared = False
+        self._ws: Dict[tuple, dict] = {}
+
+    # ------------------------------------------------------------------ parameters
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        self.params = {k: v.detach().clone().float() for k, v in sd.items()}
+        self._prepared = False
+
+    def state_dict(self):
+        return dict(self.params)
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self._prepared = False
+        self._ws.clear()
+        return self
+
+    def _prepare(self):
+        if self.device.type != "cuda":
+            raise LidkError("WavLMBackbone: the HIP path runs on the GPU only (no CPU fallback)")
+        p, dev, bf = self.params, self.device, torch.bfloat16
+        g = lambda n: p[n].to(dev).contiguous()
+        fe = "feature_extractor.conv_layers."
+        W = {"conv0_w": g(fe + "0.0.weight").reshape(self.C, 10), "gn_w": g(fe + "0.2.weight"), "gn_b": g(fe + "0.2.bias"), "conv": []}
+        for i in range(1, len(self.layers_spec)):
+            w = g(f"{fe}{i}.0.weight")                                        # [Co][Ci][kW] -> [Co][kW*Ci], k-major
+            W["conv"].append(w.permute(0, 2, 1).reshape(w.shape[0], -1).to(bf).contiguous())
+        W["ln0_w"], W["ln0_b"] = g("layer_norm.weight"), g("layer_norm.bias")
+        W["proj_w"], W["proj_b"] = g("post_extract_proj.weight").to(bf), g("post_extract_proj.bias")
+        wv, wg = g("encoder.pos_conv.0.weight_v"), g("encoder.pos_conv.0.weight_g")
+        w = torch._weight_norm(wv, wg, 2)                                       # weight_norm(dim=2): per kernel position
+        cg = self.d // self.gpos
+        W["pos_w"] = [w[i * cg:(i + 1) * cg].permute(0, 2, 1).reshape(cg, -1).to(bf).contiguous() for i in range(self.gpos)]
+        W["pos_b"] = g("encoder.pos_conv.0.bias")
+        W["enc_ln_w"], W["enc_ln_b"] = g("encoder.layer_norm.weight"), g("encoder.layer_norm.bias")
+        emb = g("encoder.layers.0.self_attn.relative_attention_bias.weight")      # [buckets][H], shared by every layer
+        r = torch.arange(-(self.RB - 1), self.RB, device=dev)
+        bucket = relative_buckets(r, self.cfg.get("num_buckets", 320), self.cfg.get("max_distance", 800))
+        W["rb"] = emb[bucket].t().contiguous()                                   # [H][2*RB-1], entry r + RB - 1
+        W["layers"] = []
+        for i in range(self.n_layers):
+            q = f"encoder.layers.{i}."
+            a = q + "self_attn."
+            W["layers"].append(dict(
+                wqkv=torch.cat([g(a + "q_proj.weight"), g(a + "k_proj.weight"), g(a + "v_proj.weight")]).to(bf).contiguous(),
+                bqkv=torch.cat([g(a + "q_proj.bias"), g(a + "k_proj.bias"), g(a + "v_proj.bias")]).contiguous(),
+                wo=g(a + "out_proj.weight").to(bf), bo=g(a + "out_proj.bias"),
+                wg=g(a + "grep_linear.weight"), bg=g(a + "grep_linear.bias"), grep_a=g(a + "grep_a").reshape(-1).contiguous(),
+                ln1_w=g(q + "self_attn_layer_norm.weight"), ln1_b=g(q + "self_attn_layer_norm.bias"),
+                w1=g(q + "fc1.weight").to(bf), b1=g(q + "fc1.bias"), w2=g(q + "fc2.weight").to(bf), b2=g(q + "fc2.bias"),
+                ln2_w=g(q + "final_layer_norm.weight"), ln2_b=g(q + "final_layer_norm.bias")))
+        self.W = W
+        self._prepared = True
+
+    # ------------------------------------------------------------------ geometry
+    def frame_counts(self, n_samples: int) -> List[int]:
+        t, out = n_samples, []
+        for _, k, s in self.layers_spec:
+            t = conv_out_len(t, k, s)
+            out.append(t)
+        return out
+
+    def _workspace(self, B: int, Lw: int):
+        key = (B, Lw)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        T = self.frame_counts(Lw)
+        if T[-1] < 1:
+            raise LidkError(f"WavLM: {Lw} samples are too few for the feature extractor")
+        if T[-1] > ops.wavlm_attn_max_frames(self.dh):
+            raise LidkError(f"WavLM: {T[-1]} frames ({Lw / 16000:.1f} s) exceed the attention kernel's limit of "
+                            f"{ops.wavlm_attn_max_frames(self.dh)} frames (dh = {self.dh})")
+        n = len(T)
+        # row pitches with P_l = stride_{l+1} * P_{l+1}, large enough for every layer's valid rows
+        mult = [1] * n
+        for l in range(n - 2, -1, -1):
+            mult[l] = mult[l + 1] * self.layers_spec[l + 1][2]
+        P_last = max(-(-T[l] // mult[l]) for l in range(n))
+        P = [P_last * m for m in mult]
+        dev, bf = self.device, torch.bfloat16
+        bufs = [torch.zeros(B * P[l] + 8, self.C, device=dev, dtype=(bf if l < n - 1 else torch.float32)) for l in range(n)]
+        Tn, M, d = T[-1], B * T[-1], self.d
+        Pp = Tn + self.kpos
+        ws = dict(T=T, P=P, bufs=bufs, M=M, Tn=Tn, Pp=Pp,
+                  xc=torch.empty(M, self.C, device=dev), h0=torch.empty(M, self.C, device=dev, dtype=bf),
+                  x=torch.empty(M, d, device=dev), xb=torch.empty(M, d, device=dev, dtype=bf),
+                  x1=torch.empty(M, d, device=dev), x1b=torch.empty(M, d, device=dev, dtype=bf), y=torch.empty(M, d, device=dev),
+                  xg=torch.empty(self.gpos, B * Pp + self.kpos, d // self.gpos, device=dev, dtype=bf),
+                  pc=torch.empty(B * Pp, d, device=dev), qkv=torch.empty(M, 3 * d, device=dev, dtype=bf),
+                  o=torch.empty(M, d, device=dev, dtype=bf), hm=torch.empty(M, self.ffn, device=dev, dtype=bf),
+                  gate=torch.empty(B, self.H, Tn, device=dev))
+        if len(self._ws) > 8:
+            self._ws.clear()
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, wav: torch.Tensor, taps: Dict[str, torch.Tensor] = None) -> torch.Tensor:
+        """wav (B, L) f32 on the GPU -> (B, T, d) f32.  ``taps`` (tests): receives copies of the stage outputs."""
+        if not wav.is_cuda or wav.dtype != torch.float32:
+            raise LidkError("WavLMBackbone.forward needs a float32 GPU tensor (B, L)")
+        if not self._prepared:
+            self._prepare()
+        wav = wav.contiguous()
+        B, Lw = wav.shape
+        ws, W, k = self._workspace(B, Lw), self.W, ops
+        T, P, bufs, C, d = ws["T"], ws["P"], ws["bufs"], self.C, self.d
+        k.wavlm_conv0(wav, W["conv0_w"], W["gn_w"], W["gn_b"], bufs[0], T[0], P[0])
+        for l in range(1, len(T)):
+            _, kw, st = self.layers_spec[l]
+            A = bufs[l - 1].as_strided((B * P[l], kw * C), (st * C, 1))          # strided view: the convolution is this GEMM
+            k.gemm_nt(A, W["conv"][l - 1], bufs[l][:B * P[l]], act=L.ACT_GELU)
+        Tn, M, Pp = ws["Tn"], ws["M"], ws["Pp"]
+        last = bufs[-1][:B * P[-1]]
+        k.scale_cast_2d(last.view(B, P[-1] * C), ws["xc"].view(B, Tn * C), B, Tn * C)       # drop the pitch padding rows
+        if taps is not None:
+            taps["conv"] = ws["xc"].view(B, Tn, C).clone()
+        k.layernorm_fwd(ws["xc"], W["ln0_w"], W["ln0_b"], yT=ws["h0"])
+        k.gemm_nt(ws["h0"], W["proj_w"], ws["x"], bias=W["proj_b"])
+        if taps is not None:
+            taps["proj"] = ws["x"].view(B, Tn, d).clone()
+        # positional convolution + residual + LayerNorm
+        cg = d // self.gpos
+        k.wavlm_posconv_prep(ws["x"], ws["xg"], B, Tn, self.gpos, Pp, self.kpos // 2)
+        for g in range(self.gpos):
+            A = ws["xg"][g].as_strided((B * Pp, self.kpos * cg), (cg, 1))
+            k.gemm_nt(A, W["pos_w"][g], ws["pc"][:, g * cg:(g + 1) * cg], bias=W["pos_b"][g * cg:(g + 1) * cg].contiguous(),
+                      act=L.ACT_GELU)
+        k.wavlm_add_rows(ws["x"], ws["pc"], ws["y"], B, Tn, Pp)
+        k.layernorm_fwd(ws["y"], W["enc_ln_w"], W["enc_ln_b"], yT=ws["xb"], y32=ws["x"])
+        if taps is not None:
+            taps["enc_in"] = ws["x"].view(B, Tn, d).clone()
+        for i, Lw_ in enumerate(W["layers"]):
+            k.gemm_nt(ws["xb"], Lw_["wqkv"], ws["qkv"], bias=Lw_["bqkv"])
+            k.wavlm_gate(ws["x"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], ws["gate"], B, Tn, self.H, self.dh)
+            if taps is not None and i == 0:
+                taps["gate0"] = ws["gate"].clone()
+            k.wavlm_attn_fwd(ws["qkv"], ws["gate"], W["rb"], ws["o"], B, Tn, self.H, self.dh)
+            k.gemm_nt(ws["o"], Lw_["wo"], ws["y"], bias=Lw_["bo"], res=ws["x"])
+            k.layernorm_fwd(ws["y"], Lw_["ln1_w"], Lw_["ln1_b"], yT=ws["x1b"], y32=ws["x1"])
+            k.gemm_nt(ws["x1b"], Lw_["w1"], ws["hm"], bias=Lw_["b1"], act=L.ACT_GELU)
+            k.gemm_nt(ws["hm"], Lw_["w2"], ws["y"], bias=Lw_["b2"], res=ws["x1"])
+            k.layernorm_fwd(ws["y"], Lw_["ln2_w"], Lw_["ln2_b"], yT=ws["xb"], y32=ws["x"])
+            if taps is not None:
+                taps[f"layer{i}"] = ws["x"].view(B, Tn, d).clone()
+        return ws["x"].view(B, Tn, d)

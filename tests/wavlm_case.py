@@ -1,0 +1,76 @@
+"""WavLM-Base+ width (conv extractor 512 ch, d = 768, 12 heads x 64, FFN 3072, bucketed relative position bias with GRU gating,
+pos-conv k128 g16 - the values of the public WavLM-Base+ config) at reduced depth, as a pure function of seeds.
+``oracle/gen_golden_wavlm.py`` feeds the REFERENCE's lid/wavlm/WavLM.py + lid/WavLMMutiLangModel.py with it in the build
+container and stores stage outputs in tests/golden/wavlm_fwd.npz; the GPU tests run the HIP backbone on the same weights.
+The weights (25 M at 2 layers) are never stored: both sides rebuild them from the seed."""
+import math
+
+import torch
+
+CFG = dict(encoder_layers=2, encoder_embed_dim=768, encoder_ffn_embed_dim=3072, encoder_attention_heads=12,
+           conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2", conv_pos=128, conv_pos_groups=16,
+           relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True, layer_norm_first=False,
+           extractor_mode="default", conv_bias=False, mask_prob=0.0, mask_channel_prob=0.0)
+L2V = {"a": 30, "b": 40, "c": 50}
+L2I = {"a": 0, "b": 1, "c": 2}
+HEAD = dict(dim_head=32, num_head=8, linear_dim=768, hidden_dim=32)
+B, SAMPLES = 3, 16000                      # 1 s utterances -> 49 frames
+
+
+def _seed(name: str) -> int:
+    return (sum((i + 1) * ord(c) for i, c in enumerate(name)) * 2654435761) % (2 ** 31)
+
+
+def backbone_shapes(layers: int):
+    s = {"mask_emb": (768,), "feature_extractor.conv_layers.0.0.weight": (512, 1, 10),
+         "feature_extractor.conv_layers.0.2.weight": (512,), "feature_extractor.conv_layers.0.2.bias": (512,)}
+    for i in range(1, 7):
+        s[f"feature_extractor.conv_layers.{i}.0.weight"] = (512, 512, 3 if i < 5 else 2)
+    s.update({"post_extract_proj.weight": (768, 512), "post_extract_proj.bias": (768,), "encoder.pos_conv.0.bias": (768,),
+              "encoder.pos_conv.0.weight_g": (1, 1, 128), "encoder.pos_conv.0.weight_v": (768, 48, 128)})
+    for i in range(layers):
+        p = f"encoder.layers.{i}."
+        s[p + "self_attn.grep_a"] = (1, 12, 1, 1)
+        if i == 0:
+            s[p + "self_attn.relative_attention_bias.weight"] = (320, 12)
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            s[p + f"self_attn.{n}.weight"], s[p + f"self_attn.{n}.bias"] = (768, 768), (768,)
+        s[p + "self_attn.grep_linear.weight"], s[p + "self_attn.grep_linear.bias"] = (8, 64), (8,)
+        s[p + "self_attn_layer_norm.weight"], s[p + "self_attn_layer_norm.bias"] = (768,), (768,)
+        s[p + "fc1.weight"], s[p + "fc1.bias"], s[p + "fc2.weight"], s[p + "fc2.bias"] = (3072, 768), (3072,), (768, 3072), (768,)
+        s[p + "final_layer_norm.weight"], s[p + "final_layer_norm.bias"] = (768,), (768,)
+    s.update({"encoder.layer_norm.weight": (768,), "encoder.layer_norm.bias": (768,), "layer_norm.weight": (512,),
+              "layer_norm.bias": (512,)})
+    return s
+
+
+def backbone_weights(layers: int = CFG["encoder_layers"]):
+    """name -> CPU f32 tensor for lid/wavlm/WavLM.py's state_dict: every tensor drawn from its own seeded generator, scaled so
+    that activations stay O(1) through the stack (fan-in scaling; norm scales near 1, biases small but non-zero)."""
+    out = {}
+    for name, shape in backbone_shapes(layers).items():
+        g = torch.Generator().manual_seed(_seed(name))
+        if name.endswith(("norm.weight", "conv_layers.0.2.weight")):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith("grep_a"):
+            t = 1.0 + 0.2 * torch.randn(shape, generator=g)
+        elif name.endswith("weight_g"):
+            t = 0.5 + 0.5 * torch.rand(shape, generator=g)
+        elif name.endswith("relative_attention_bias.weight"):
+            t = 0.5 * torch.randn(shape, generator=g)
+        elif len(shape) >= 2:
+            fan_in = math.prod(shape[1:])
+            t = torch.randn(shape, generator=g) * (1.6 / math.sqrt(fan_in))
+        else:
+            t = 0.05 * torch.randn(shape, generator=g)
+        out[name] = t
+    return out
+
+
+def waveforms():
+    g = torch.Generator().manual_seed(2024)
+    t = torch.arange(SAMPLES) / 16000.0
+    x = 0.3 * torch.randn(B, SAMPLES, generator=g)
+    for b in range(B):
+        x[b] += 0.5 * torch.sin(2 * math.pi * (220.0 * (b + 1)) * t)
+    return x
