@@ -262,6 +262,11 @@ int lidk_wavlm_posconv_prep(const float* x, void* xg, int B, int T, int C, int G
                             void* stream);
 /* out[b][t] = x[b][t] + y[b*Pp + t]  (y has Pp rows per utterance, the first T valid): the pos-conv residual (WavLM.py:607). */
 int lidk_wavlm_add_rows(const float* x, const float* y, float* out, int B, int T, int Pp, int C, void* stream);
+/* Span masking of the projected features in training (WavLM.apply_mask, WavLM.py:300-337), in place on x [B*T][C] f32:
+ * rows with time_mask [B][T] != 0 become mask_emb [C]; then columns with chan_mask [B][C] != 0 become 0.  Either mask may be NULL.
+ * The spans themselves are drawn on the host in the reference's numpy draw order (lidk/wavlm.py span_mask). */
+int lidk_wavlm_apply_mask(float* x, const unsigned char* time_mask, const unsigned char* chan_mask, const float* mask_emb, int B,
+                          int T, int C, void* stream);
 /* Gate of the relative position bias (modules.py:519-528): gate [B][H][T] from the layer input x [B*T][H*dh] f32,
  * grep_linear wg [8][dh], bg [8], grep_a [H]. */
 int lidk_wavlm_gate(const float* x, const float* wg, const float* bg, const float* grep_a, float* gate, int B, int T, int H, int dh,

@@ -150,6 +150,28 @@ extern "C" int lidk_wavlm_add_rows(const float* x, const float* y, float* out, i
   return launch_status();
 }
 
+// ------------------------------------------------------------------------------------ span masking (training)
+// WavLM.apply_mask (WavLM.py:300-337): x[b][t][:] = mask_emb where time_mask[b][t]; then x[b][:][c] = 0 where chan_mask[b][c].
+__global__ void wavlm_apply_mask_kernel(float* __restrict__ x, const unsigned char* __restrict__ tmask,
+                                        const unsigned char* __restrict__ cmask, const float* __restrict__ mask_emb, int T_, int C,
+                                        long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); const long row = i / C; const long b = row / T_;
+    float v = x[i];
+    if (tmask && tmask[row]) v = mask_emb[c];
+    if (cmask && cmask[b * C + c]) v = 0.f;
+    x[i] = v;
+  }
+}
+extern "C" int lidk_wavlm_apply_mask(float* x, const unsigned char* time_mask, const unsigned char* chan_mask, const float* mask_emb,
+                                     int B, int T_, int C, void* stream) {
+  if (!x || (time_mask && !mask_emb) || B <= 0 || T_ <= 0 || C <= 0) return LIDK_ERR_ARG;
+  const long n = (long)B * T_ * C;
+  int blocks = (int)((n + 255) / 256); if (blocks > 16384) blocks = 16384;
+  wavlm_apply_mask_kernel<<<blocks, 256, 0, as_stream(stream)>>>(x, time_mask, chan_mask, mask_emb, T_, C, n);
+  return launch_status();
+}
+
 // ------------------------------------------------------------------------------------ gate of the relative position bias
 // modules.py:519-528: per (b, h, t): u = grep_linear(x[b][t][h*dh : (h+1)*dh]) (8 values) ; (ga, gb) = sigmoid of the sums of
 // u[0:4], u[4:8] ; gate = ga * (gb * grep_a[h] - 1) + 2.   x is the LAYER INPUT (not the projected query).

@@ -97,48 +97,24 @@ def char_error_rate(preds: List[str], refs: List[str]) -> torch.Tensor:
     return torch.tensor(errs / max(total, 1), dtype=torch.float32)
 
 
-class ConformerMutiLangModel(nn.Module):
-    def __init__(self, num_layers: int = 1, lang2vocab: Dict = None, lang2index: Dict = None, hidden_dim: int = 32,
-                 use_cer: bool = True, conformer_linear: bool = False, dropout: float = 0.0, linear_dim: int = 144,
-                 n_blocks: int = 14, n_mels: int = 80, encoder_dim: int = 144, dim_head=64, last_dim_head: int = 32, heads=4,
-                 ff_mult=4, conv_expansion_factor=2, conv_kernel_size=31, attn_dropout=0.0, ff_dropout=0.0, conv_dropout=0.0,
-                 double_swish=False, sub_sampling: int = 2, compute_dtype=torch.bfloat16, **_ignored):
-        super().__init__()
-        if not conformer_linear:
-            raise NotImplementedError("LSTM heads (conformer_linear=False) are outside the lidk hot path (SURVEY 2 #3)")
-        if sub_sampling != 2 or double_swish or attn_dropout or ff_dropout or conv_dropout:
-            raise NotImplementedError("lidk builds the configuration the lid confs select: sub_sampling=2, Swish, and zero "
-                                      "attention/ff/conv dropout (SURVEY 2 #2)")
-        if linear_dim != encoder_dim:
-            raise ValueError("linear_dim must equal encoder_dim")
-        self.cfg = ConformerCfg(lang2vocab=dict(lang2vocab), lang2index=dict(lang2index), n_blocks=n_blocks, n_mels=n_mels,
-                                encoder_dim=encoder_dim, dim_head=dim_head, heads=heads, ff_mult=ff_mult,
-                                conv_expansion_factor=conv_expansion_factor, conv_kernel_size=conv_kernel_size,
-                                last_dim_head=last_dim_head, hidden_dim=hidden_dim, dropout=dropout)
-        self.lidk_engine = Engine(self.cfg, act_dtype=compute_dtype)
-        self.use_stochastic_depth = self.cfg.use_stochastic_depth
-        self.stochastic_depth_p = self.cfg.stochastic_depth_p
-        self.forced_masks: Optional[Dict[str, torch.Tensor]] = None       # parity tests only
+class _EngineBoundModel(nn.Module):
+    """nn.Module whose Parameters are views into a lidk Engine's flat arena (shared by the Conformer and WavLM LID models):
+    naming skeleton, device moves, state-dict loading, gradient publication and the LangDiscriminator."""
+
+    def _bind_engine(self, engine: Engine):
+        self.lidk_engine = engine
         self._owner: Dict[str, tuple] = {}
-        eng = self.lidk_engine
-        for s in eng.specs:
+        for s in engine.specs:
             *path, leaf = s.name.split(".")
             mod = _child(self, path)
-            mod.register_parameter(leaf, nn.Parameter(eng.pview(s.name)))
+            mod.register_parameter(leaf, nn.Parameter(engine.pview(s.name)))
             self._owner[s.name] = (mod, leaf)
-        for name, t in eng.buffers.items():
+        for name, t in engine.buffers.items():
             *path, leaf = name.split(".")
             mod = _child(self, path)
             mod.register_buffer(leaf, t)
             self._owner[name] = (mod, leaf)
         self._tag_params()
-        inner = self.model
-        inner.lang2vocab = self.cfg.lang2vocab
-        inner.conformer_linear = True
-        inner.loss_fns = {k: nn.CTCLoss(blank=v, reduction="none", zero_infinity=True) for k, v in lang2vocab.items()}
-        inner.wer_fn = char_error_rate
-        self.lang_discriminator.lang2vocab, self.lang_discriminator.lang2index = self.cfg.lang2vocab, self.cfg.lang2index
-        self.lang_discriminator.classes = len(lang2vocab)
         self._anchor = None
 
     # ------------------------------------------------------------------ arena <-> Parameter binding
@@ -161,7 +137,11 @@ class ConformerMutiLangModel(nn.Module):
             self.lidk_engine.to(probe.device)
             self._tag_params()
             self._anchor = None
+            self._moved(probe.device)
         return self
+
+    def _moved(self, device):
+        pass
 
     def set_compute_dtype(self, dtype):
         """bf16 (production) or f32 (parity mode); must be chosen before the model is moved to the GPU."""
@@ -188,6 +168,50 @@ class ConformerMutiLangModel(nn.Module):
             s = eng.specs[tid]
             mod, leaf = self._owner[s.name]
             mod._parameters[leaf].grad = eng.gview(s.name)
+
+    def lang_discriminator_forward(self, logits: Dict[str, torch.Tensor]):
+        """LangDiscriminator.forward (lid/ConformerLangModel.py:383-395): per-language CTC-path confidence, then the MLP."""
+        cfg, eng = self.cfg, self.lidk_engine
+        first = next(iter(logits.values()))
+        scores = torch.zeros(first.shape[0], len(cfg.lang2vocab), device=first.device, dtype=torch.float32)
+        for lang, lg in logits.items():
+            eng.k.lid_score(lg.contiguous(), scores[:, cfg.lang2index[lang]:], len(cfg.lang2vocab), cfg.lang2vocab[lang])
+        pv = eng.pview
+        lin = torch.empty_like(scores)
+        eng.k.lid_mlp(scores, pv("lang_discriminator.linear.0.weight"), pv("lang_discriminator.linear.0.bias"),
+                      pv("lang_discriminator.linear.2.weight"), pv("lang_discriminator.linear.2.bias"), lin)
+        return scores, lin
+
+
+class ConformerMutiLangModel(_EngineBoundModel):
+    def __init__(self, num_layers: int = 1, lang2vocab: Dict = None, lang2index: Dict = None, hidden_dim: int = 32,
+                 use_cer: bool = True, conformer_linear: bool = False, dropout: float = 0.0, linear_dim: int = 144,
+                 n_blocks: int = 14, n_mels: int = 80, encoder_dim: int = 144, dim_head=64, last_dim_head: int = 32, heads=4,
+                 ff_mult=4, conv_expansion_factor=2, conv_kernel_size=31, attn_dropout=0.0, ff_dropout=0.0, conv_dropout=0.0,
+                 double_swish=False, sub_sampling: int = 2, compute_dtype=torch.bfloat16, **_ignored):
+        super().__init__()
+        if not conformer_linear:
+            raise NotImplementedError("LSTM heads (conformer_linear=False) are outside the lidk hot path (SURVEY 2 #3)")
+        if sub_sampling != 2 or double_swish or attn_dropout or ff_dropout or conv_dropout:
+            raise NotImplementedError("lidk builds the configuration the lid confs select: sub_sampling=2, Swish, and zero "
+                                      "attention/ff/conv dropout (SURVEY 2 #2)")
+        if linear_dim != encoder_dim:
+            raise ValueError("linear_dim must equal encoder_dim")
+        self.cfg = ConformerCfg(lang2vocab=dict(lang2vocab), lang2index=dict(lang2index), n_blocks=n_blocks, n_mels=n_mels,
+                                encoder_dim=encoder_dim, dim_head=dim_head, heads=heads, ff_mult=ff_mult,
+                                conv_expansion_factor=conv_expansion_factor, conv_kernel_size=conv_kernel_size,
+                                last_dim_head=last_dim_head, hidden_dim=hidden_dim, dropout=dropout)
+        self._bind_engine(Engine(self.cfg, act_dtype=compute_dtype))
+        self.use_stochastic_depth = self.cfg.use_stochastic_depth
+        self.stochastic_depth_p = self.cfg.stochastic_depth_p
+        self.forced_masks: Optional[Dict[str, torch.Tensor]] = None       # parity tests only
+        inner = self.model
+        inner.lang2vocab = self.cfg.lang2vocab
+        inner.conformer_linear = True
+        inner.loss_fns = {k: nn.CTCLoss(blank=v, reduction="none", zero_infinity=True) for k, v in lang2vocab.items()}
+        inner.wer_fn = char_error_rate
+        self.lang_discriminator.lang2vocab, self.lang_discriminator.lang2index = self.cfg.lang2vocab, self.cfg.lang2index
+        self.lang_discriminator.classes = len(lang2vocab)
 
     # ------------------------------------------------------------------ forward
     def _layer_keep(self) -> List[bool]:
@@ -228,19 +252,6 @@ class ConformerMutiLangModel(nn.Module):
         if lang is not None:
             return out, (None, None)
         return out, self.lang_discriminator_forward(out)
-
-    def lang_discriminator_forward(self, logits: Dict[str, torch.Tensor]):
-        """LangDiscriminator.forward (lid/ConformerLangModel.py:383-395): per-language CTC-path confidence, then the MLP."""
-        cfg, eng = self.cfg, self.lidk_engine
-        first = next(iter(logits.values()))
-        scores = torch.zeros(first.shape[0], len(cfg.lang2vocab), device=first.device, dtype=torch.float32)
-        for lang, lg in logits.items():
-            eng.k.lid_score(lg.contiguous(), scores[:, cfg.lang2index[lang]:], len(cfg.lang2vocab), cfg.lang2vocab[lang])
-        pv = eng.pview
-        lin = torch.empty_like(scores)
-        eng.k.lid_mlp(scores, pv("lang_discriminator.linear.0.weight"), pv("lang_discriminator.linear.0.bias"),
-                      pv("lang_discriminator.linear.2.weight"), pv("lang_discriminator.linear.2.bias"), lin)
-        return scores, lin
 
     # ------------------------------------------------------------------ reference helper surface
     def freeze_feature_extractor(self):

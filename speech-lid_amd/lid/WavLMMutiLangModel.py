@@ -1,0 +1,160 @@
+"""WavLMMutiLangModel - the reference's WavLM-backbone LID model surface (lid/WavLMMutiLangModel.py:19-284) on the lidk kernels.
+
+  DataProcessor (16 kHz pass-through) -> WavLMMutiModel: WavLM backbone (lid/wavlm/WavLM.py) -> per-language ConformerLinear
+  heads (one ConformerBlock dim = linear_dim, heads num_head x dim_head, + Linear to V+1) -> LangDiscriminator.
+
+Kept: constructor keywords, ``forward(x: list of 1-D waveforms, sample_rate, lang) -> ({lang: logits (B, T, V+1)},
+(lid_asr, lid_linear))``, attribute paths (``model.model.featurizer``, ``model.model.last_projects[lang]``, ``loss_fns``,
+``wer_fn``, ``lang_discriminator``), ``freeze_* / unfreeze_*`` and the ``state_dict`` names: ``model.featurizer.model.<WavLM
+key>``, ``model.last_projects.<lang>.block.*`` / ``.linear.*``, ``lang_discriminator.linear.{0,2}.*`` (the reference's
+torchaudio ``data_processor.resampler*.kernel`` buffers are ignored on load and not written).
+
+What runs: the backbone FORWARD on hand-written HIP (lidk/wavlm.py) without autograd, the heads forward + backward on the lidk
+Engine (``front="features"``).  This is the reference's training regime while the backbone is frozen
+(``freeze_encoder_epoch`` / ``freeze_tranformer_epoch``, lid/LidModule_ASR.py:243-258) and its inference path; un-freezing the
+backbone raises: its backward pass is not built.
+"""
+import logging
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from lid.ConformerLangModel import CtcLossFn, _child, _EngineBoundModel, _EngineFn, char_error_rate  # noqa: F401
+from lidk.engine import Engine
+from lidk.layout import ConformerCfg
+from lidk.wavlm import WavLMBackbone
+from lidk._lib import LidkError
+
+
+class WavLMMutiLangModel(_EngineBoundModel):
+    def __init__(self, pt_path: str = None, feature_selection: str = "hidden_states", dropout: float = 0.0, linear_dim: int = 768,
+                 mask: bool = True, num_layers: int = 1, lang2vocab: Dict = None, lang2index: Dict = None, hidden_dim: int = 128,
+                 conformer_linear: bool = False, double_swish: bool = False, use_pre_train: bool = True,
+                 mask_channel_prob: float = 0, mask_prob: float = 0.0, conformer_pure: bool = False, use_mask: bool = False,
+                 dim_head: int = 32, num_head: int = 8, compute_dtype=torch.bfloat16, wavlm_cfg: Optional[Dict] = None, **_ignored):
+        super().__init__()
+        if not conformer_linear:
+            raise NotImplementedError("LSTM heads (conformer_linear=False) are outside the lidk path (SURVEY 2 #3)")
+        if num_layers != 1 or double_swish or use_mask or conformer_pure:
+            raise NotImplementedError("lidk WavLM LID model: one ConformerBlock per head, Swish, use_mask=False, conformer_pure=False")
+        if pt_path is not None:
+            ckpt = torch.load(pt_path, map_location="cpu", weights_only=False)       # {"cfg": dict, "model": state_dict}
+            cfg, weights = dict(ckpt["cfg"]), (ckpt["model"] if use_pre_train else None)
+        elif wavlm_cfg is not None:                                                   # tests / synthetic runs: no checkpoint file
+            cfg, weights = dict(wavlm_cfg), None
+        else:
+            raise ValueError("WavLMMutiLangModel needs pt_path (a WavLM checkpoint with 'cfg' and 'model') or wavlm_cfg")
+        cfg["mask_prob"] = mask_prob if mask else 0.0
+        cfg["mask_channel_prob"] = mask_channel_prob if mask else 0.0
+        self.backbone = WavLMBackbone(cfg)
+        if self.backbone.d != linear_dim:
+            raise ValueError(f"linear_dim {linear_dim} must equal the backbone width {self.backbone.d}")
+        self.cfg = ConformerCfg(lang2vocab=dict(lang2vocab), lang2index=dict(lang2index), n_blocks=0, encoder_dim=linear_dim,
+                                last_heads=num_head, last_dim_head=dim_head, hidden_dim=hidden_dim, dropout=dropout,
+                                pos_dropout=0.0, use_stochastic_depth=False, front="features")
+        self._bind_engine(Engine(self.cfg, act_dtype=compute_dtype))
+        # backbone parameters: reference names under model.featurizer.model.*, frozen (no gradient path exists for them)
+        self._bb_names: List[str] = []
+        sd = weights if weights is not None else self._random_backbone(cfg)
+        for name, t in sd.items():
+            *path, leaf = ("model.featurizer.model." + name).split(".")
+            _child(self, path).register_parameter(leaf, nn.Parameter(t.detach().clone().float(), requires_grad=False))
+            self._bb_names.append(name)
+        self._sync_backbone()
+        inner = self.model
+        inner.lang2vocab, inner.conformer_linear = self.cfg.lang2vocab, True
+        inner.loss_fns = {k: nn.CTCLoss(blank=v, reduction="none", zero_infinity=True) for k, v in lang2vocab.items()}
+        inner.wer_fn = char_error_rate
+        self.lang_discriminator.lang2vocab, self.lang_discriminator.lang2index = self.cfg.lang2vocab, self.cfg.lang2index
+        self.lang_discriminator.classes = len(lang2vocab)
+        self.forced_masks = None
+        self._backbone_frozen = {"extractor": True, "encoder": True}
+
+    @staticmethod
+    def _random_backbone(cfg):
+        """Seeded stand-in weights of the right names and shapes when no checkpoint is given (synthetic runs, tests)."""
+        from lidk.wavlm import WavLMBackbone as _B
+        shapes = _B.param_shapes(cfg)
+        g = torch.Generator().manual_seed(0)
+        out = {}
+        for name, shape in shapes.items():
+            if name.endswith(("norm.weight", "conv_layers.0.2.weight", "grep_a", "weight_g")):
+                out[name] = torch.ones(shape)
+            elif len(shape) >= 2:
+                fan_in = 1
+                for s in shape[1:]:
+                    fan_in *= s
+                out[name] = torch.randn(shape, generator=g) * (1.4 / fan_in ** 0.5)
+            else:
+                out[name] = torch.zeros(shape)
+        return out
+
+    def _backbone_params(self) -> Dict[str, torch.Tensor]:
+        params = dict(self.named_parameters())
+        return {n: params["model.featurizer.model." + n].data for n in self._bb_names}
+
+    def _sync_backbone(self):
+        self.backbone.load_state_dict(self._backbone_params())
+
+    def _moved(self, device):
+        for n in self._bb_names:                                   # the frozen backbone's parameters follow the model
+            *path, leaf = ("model.featurizer.model." + n).split(".")
+            mod = _child(self, path)
+            mod._parameters[leaf].data = mod._parameters[leaf].data.to(device)
+        self.backbone.to(device)
+        self._sync_backbone()
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = {k: v for k, v in state_dict.items() if not k.startswith("data_processor.")}      # torchaudio resampler buffers
+        res = super().load_state_dict(sd, strict=strict, assign=False)
+        self._sync_backbone()
+        return res
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, sample_rate: int = 16000, lang: str = None):
+        if sample_rate != 16000:
+            raise NotImplementedError("resampling (22.05/44.1 kHz) is outside the lidk path (SURVEY 2 #3)")
+        wavs = list(x) if isinstance(x, (list, tuple)) else [w for w in x]
+        n_samples = [int(w.shape[-1]) for w in wavs]
+        wav = torch.nn.utils.rnn.pad_sequence([w.reshape(-1) for w in wavs], batch_first=True).float()
+        if not wav.is_cuda:
+            raise LidkError("WavLMMutiLangModel.forward: waveforms must be on the GPU (no CPU fallback)")
+        with torch.no_grad():
+            feats = self.backbone.forward(wav.contiguous(), mask=self.training, n_samples=n_samples)
+        eng = self.lidk_engine
+        if self.training and torch.is_grad_enabled() and lang is not None:
+            if self._anchor is None or self._anchor.device != feats.device:
+                self._anchor = torch.zeros(1, device=feats.device, requires_grad=True)
+            logits = _EngineFn.apply(self._anchor, feats, self, lang, [], self.forced_masks)
+            return {lang: logits}, (None, None)
+        out = eng.forward(feats, lang, self.training, None, self.forced_masks)
+        out = {k: v.clone() for k, v in out.items()}
+        if lang is not None:
+            return out, (None, None)
+        return out, self.lang_discriminator_forward(out)
+
+    # ------------------------------------------------------------------ reference helper surface
+    def freeze_feature_extractor(self):
+        self._backbone_frozen["extractor"] = True
+
+    def freeze_tranformer_encoder(self):
+        self._backbone_frozen["encoder"] = True
+
+    def _unfreeze(self, what):
+        raise NotImplementedError(
+            f"un-freezing the WavLM {what} needs the backbone's backward pass, which this build does not have yet (forward-only "
+            "HIP path, SURVEY 8f N1): keep freeze_encoder_epoch / freeze_tranformer_epoch at or above trainer.total_epoch")
+
+    def unfreeze_feature_extractor(self):
+        self._unfreeze("feature extractor")
+
+    def unfreeze_tranformer_encoder(self):
+        self._unfreeze("transformer encoder")
+
+    def keep_last_lang_model_train(self, lang):
+        raise NotImplementedError("keep_train_lang (freezing all heads but one) is not built")
+
+    def reset_param(self):
+        logging.info("reset parameters...")
+        self.lidk_engine.reset_parameters()

@@ -83,6 +83,7 @@ SIGNATURES = {
     "lidk_wavlm_conv0": (_I, [_P, _I, _I, _P, _P, _P, _F, _P, _I, _I, _I, _P, _P]),
     "lidk_wavlm_posconv_prep": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _L, _P]),
     "lidk_wavlm_add_rows": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "lidk_wavlm_apply_mask": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_wavlm_gate": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "lidk_wavlm_attn_max_frames": (_I, [_I]),
     "lidk_wavlm_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

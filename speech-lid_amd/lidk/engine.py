@@ -173,7 +173,7 @@ class _Work:
     def __init__(self, eng: "Engine", B: int, F_: int, pool: _Pool):
         cfg = eng.cfg
         self.B, self.F, self.pool = B, F_, pool
-        self.T = T = (F_ + 2 - 3) // 2 + 1
+        self.T = T = eng.frames_to_steps(F_)
         self.M = M = B * T
         self.Mp = Mp = _ceil(M, 8)
         d, dev, dt = cfg.d, eng.device, eng.act_dtype
@@ -373,7 +373,9 @@ class Engine:
                 skip.add(kv.name)
                 continue
             add(s.name, s.offset, s.shape[0], s.shape[1])
-        c3 = self.by_name["model.featurizer.sub_sampling.sub_sampling.0.weight"]
+        c3 = self.by_name.get("model.featurizer.sub_sampling.sub_sampling.0.weight")
+        if c3 is None:
+            c3 = Spec("none", (8, 1, 1), "conv3")                   # features front: no subsampling conv (placeholder operand)
         self._c3_off, off = off, off + _ceil(c3.shape[0] * 3 * c3.shape[1], ALIGN)
         self.wT = torch.zeros(off, device=self.device, dtype=self.act_dtype)
         self.mats, self.mat_tiles = self.k.build_cast_table(mats, self.device)
@@ -407,8 +409,9 @@ class Engine:
                 self._lang_tables[lang] = self.k.build_cast_table(rows, self.device)
             mats, tiles = self._lang_tables[lang]
             self.k.cast_weights(self.flat, self.wT, mats, tiles)
-        c3 = self.pview("model.featurizer.sub_sampling.sub_sampling.0.weight")       # [Co][Ci][3] -> [Co][k*Ci+ci]
-        self.w_conv3.copy_(c3.permute(0, 2, 1).reshape(c3.shape[0], -1))             # 19 K elements: layout glue, not math
+        if self.cfg.front == "subsample":
+            c3 = self.pview("model.featurizer.sub_sampling.sub_sampling.0.weight")       # [Co][Ci][3] -> [Co][k*Ci+ci]
+            self.w_conv3.copy_(c3.permute(0, 2, 1).reshape(c3.shape[0], -1))             # 19 K elements: layout glue, not math
 
     def work(self, B, F_):
         """Workspace for a (batch, frames) shape.  Ragged training data produces hundreds of distinct shapes, so HBM is
@@ -420,7 +423,7 @@ class Engine:
         w = self._work.pop(key, None)
         if w is None:
             if self._hip and hasattr(self.k, "attn_max_frames"):
-                T = (F_ + 2 - 3) // 2 + 1
+                T = self.frames_to_steps(F_)
                 lim = min(self.k.attn_max_frames(self.cfg.dim_head, self.act_dtype),
                           self.k.attn_max_frames(self.cfg.last_dim_head, self.act_dtype))
                 if T > lim:
@@ -455,9 +458,17 @@ class Engine:
         for k in [k for k, w in self._work.items() if w.pool is pool]:
             self.graphs.drop(id(self._work.pop(k)))    # captured graphs point into the evicted pool
 
+    def frames_to_steps(self, F_: int) -> int:
+        """Sequence length the blocks see for an input of F_ frames: Conv1d(k3, s2, p1) subsampling, or the input itself when
+        the engine is fed the features of a frozen backbone."""
+        return (F_ + 2 - 3) // 2 + 1 if self.cfg.front == "subsample" else F_
+
     # ------------------------------------------------------------------ forward pieces
     def _front_fwd(self, w: _Work, mel, training, seed):
         cfg = self.cfg
+        if cfg.front != "subsample":                 # backbone features (B, T, d): the residual stream starts from them; copied
+            self.k.scale_cast(mel.view(w.M, cfg.d), w.x0, 1.0)       # into the workspace so captured graphs see one address
+            return w.x0
         fz = "model.featurizer.sub_sampling"
         self.k.im2col_k3s2(mel, w.col, w.T)
         self.k.gemm_nt(w.col, self.w_conv3, w.r, bias=self.pview(fz + ".sub_sampling.0.bias"), act=L.ACT_RELU)
@@ -583,8 +594,9 @@ class Engine:
             raise LidkError(f"Engine.forward got a tensor on {mel.device}: the HIP path has no CPU fallback")
         mel = mel.contiguous()
         B, F_, nm = mel.shape
-        if nm != self.cfg.n_mels:
-            raise LidkError(f"expected {self.cfg.n_mels} mel bins, got {nm}")
+        want = self.cfg.n_mels if self.cfg.front == "subsample" else self.cfg.d
+        if nm != want:
+            raise LidkError(f"expected {want} input channels, got {nm}")
         w = self.work(B, F_)
         self._forced_masks = masks or {}
         self.step_count += 1
@@ -828,6 +840,8 @@ class Engine:
             if self.on_stage_grads_ready:
                 self.on_stage_grads_ready(prev[4])
         dy = dfeat                                   # f32 gradient at the first block's input (after pos-enc dropout)
+        if cfg.front != "subsample":                 # frozen backbone: nothing upstream takes a gradient
+            return
         # front end: x0 = sqrt(d) * (r @ Wl^T + b) [dropout]; r = relu(col @ Wc^T + bc)
         fz = "model.featurizer.sub_sampling"
         if cfg.pos_dropout > 0:
@@ -870,6 +884,8 @@ class Engine:
 
     def stage_range(self, stage: str):
         a, b = self.stages[stage]
+        if a == b:
+            return 0, 0
         lo = self.specs[a].offset
         hi = self.specs[b - 1].offset + _ceil(self.specs[b - 1].numel, ALIGN)
         return lo, hi

@@ -35,6 +35,10 @@ class ConformerCfg:
     max_pos_emb: int = 512
     stochastic_depth_p: float = 0.7
     use_stochastic_depth: bool = True
+    # "subsample": log-mel input through Conv1dSubSampling2 (the Conformer LID model).  "features": the input already is the
+    # (B, T, d) feature sequence of a frozen backbone (WavLM), no front-end parameters and no encoder blocks of its own
+    # (lid/WavLMMutiLangModel.py:185-284: featurizer -> per-language ConformerLinear heads).
+    front: str = "subsample"
 
     @property
     def d(self):
@@ -96,12 +100,15 @@ def model_specs(cfg: ConformerCfg):
         specs.extend(items)
         stages[stage] = (a, len(specs))
 
-    add("front", [Spec(f"{fz}.sub_sampling.sub_sampling.0.weight", (cfg.n_mels, cfg.n_mels, 3), "conv3"),
-                  Spec(f"{fz}.sub_sampling.sub_sampling.0.bias", (cfg.n_mels,), "vec"),
-                  Spec(f"{fz}.sub_sampling.linear.weight", (d, cfg.n_mels), "w"),
-                  Spec(f"{fz}.sub_sampling.linear.bias", (d,), "vec"),
-                  Spec(f"{fz}.linear.weight", (d, cfg.n_mels), "w"),          # never used by forward
-                  Spec(f"{fz}.linear.bias", (d,), "vec")])
+    if cfg.front == "subsample":
+        add("front", [Spec(f"{fz}.sub_sampling.sub_sampling.0.weight", (cfg.n_mels, cfg.n_mels, 3), "conv3"),
+                      Spec(f"{fz}.sub_sampling.sub_sampling.0.bias", (cfg.n_mels,), "vec"),
+                      Spec(f"{fz}.sub_sampling.linear.weight", (d, cfg.n_mels), "w"),
+                      Spec(f"{fz}.sub_sampling.linear.bias", (d,), "vec"),
+                      Spec(f"{fz}.linear.weight", (d, cfg.n_mels), "w"),          # never used by forward
+                      Spec(f"{fz}.linear.bias", (d,), "vec")])
+    else:
+        stages["front"] = (0, 0)
     buffers = []
     for i in range(cfg.n_blocks):
         p = f"{fz}.encoders.{i}"
@@ -166,9 +173,10 @@ def init_values(cfg: ConformerCfg) -> Dict[str, torch.Tensor]:
         for n in (".attn.norm", ".ff1.fn.norm", ".ff2.fn.norm", ".post_norm"):
             ones_zeros(p + n, d)
 
-    conv(fz + ".sub_sampling.sub_sampling.0", cfg.n_mels, cfg.n_mels, 3)
-    lin(fz + ".sub_sampling.linear", d, cfg.n_mels)
-    lin(fz + ".linear", d, cfg.n_mels)
+    if cfg.front == "subsample":
+        conv(fz + ".sub_sampling.sub_sampling.0", cfg.n_mels, cfg.n_mels, 3)
+        lin(fz + ".sub_sampling.linear", d, cfg.n_mels)
+        lin(fz + ".linear", d, cfg.n_mels)
     for i in range(cfg.n_blocks):
         block(f"{fz}.encoders.{i}", cfg.heads, cfg.dim_head, cfg.ff_mult, cfg.conv_expansion_factor, cfg.conv_kernel_size)
     for lang, v in cfg.lang2vocab.items():

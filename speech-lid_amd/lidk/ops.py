@@ -469,6 +469,13 @@ def wavlm_add_rows(x, y, out, B, T, Pp):
     return out
 
 
+def wavlm_apply_mask(x, time_mask, chan_mask, mask_emb, B, T):
+    """x (B*T, C) f32 in place; time_mask (B, T) uint8 or None; chan_mask (B, C) uint8 or None."""
+    check(lib().lidk_wavlm_apply_mask(_p(x), _p(time_mask), _p(chan_mask), _p(mask_emb), B, T, x.shape[1], _stream()),
+          "wavlm_apply_mask")
+    return x
+
+
 def wavlm_gate(x, wg, bg, grep_a, gate, B, T, H, dh):
     check(lib().lidk_wavlm_gate(_p(x), _p(wg), _p(bg), _p(grep_a), _p(gate), B, T, H, dh, _stream()), "wavlm_gate")
     return gate

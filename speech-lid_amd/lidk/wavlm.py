@@ -46,6 +46,40 @@ def relative_buckets(rel: torch.Tensor, num_buckets: int, max_distance: int) -> 
     return out + torch.where(is_small, n, large)
 
 
+def span_mask(shape, padding_mask, mask_prob: float, mask_length: int, min_masks: int = 0, rng=None):
+    """Random spans to mask, the "static" overlapping form of the reference's compute_mask_indices (lid/wavlm/WavLM.py:35-158)
+    with the same numpy draw order, so a seeded run masks the same positions: one rounding draw for the span count (per row
+    when a padding mask is given), ``choice`` of span starts without replacement, spans of ``mask_length``, and every row
+    thinned to the shortest row's count.  shape = (rows, size); padding_mask (rows, size) bool tensor or None -> bool ndarray."""
+    import numpy as np
+    rng = np.random if rng is None else rng
+    bsz, all_sz = shape
+    mask = np.full((bsz, all_sz), False)
+    all_num = max(min_masks, int(mask_prob * all_sz / float(mask_length) + rng.rand()))
+    rows = []
+    for i in range(bsz):
+        if padding_mask is not None:
+            sz = all_sz - int(padding_mask[i].long().sum().item())
+            num = max(min_masks, int(mask_prob * sz / float(mask_length) + rng.rand()))
+        else:
+            sz, num = all_sz, all_num
+        lengths = np.full(num, mask_length)
+        if sum(lengths) == 0:
+            lengths[0] = min(mask_length, sz - 1)
+        min_len = min(lengths)
+        if sz - min_len <= num:
+            min_len = sz - num - 1
+        starts = rng.choice(sz - min_len, num, replace=False)
+        idc = np.asarray([starts[j] + off for j in range(len(starts)) for off in range(lengths[j])])
+        rows.append(np.unique(idc[idc < sz]))
+    keep = min(len(r) for r in rows)
+    for i, r in enumerate(rows):
+        if len(r) > keep:
+            r = rng.choice(r, keep, replace=False)
+        mask[i, r] = True
+    return mask
+
+
 class WavLMBackbone:
     RB = 1024                       # the bias table covers offsets |j - i| < RB
 
@@ -71,6 +105,35 @@ class WavLMBackbone:
         self._ws: Dict[tuple, dict] = {}
 
     # ------------------------------------------------------------------ parameters
+    @staticmethod
+    def param_shapes(cfg: Dict) -> Dict[str, tuple]:
+        """Names and shapes of lid/wavlm/WavLM.py's ``state_dict()`` for a config (conv_bias=False, extractor_mode=default,
+        relative position embedding owned by layer 0)."""
+        spec = eval(cfg.get("conv_feature_layers", "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"))
+        C, d = spec[0][0], cfg.get("encoder_embed_dim", 768)
+        ffn, H = cfg.get("encoder_ffn_embed_dim", 3072), cfg.get("encoder_attention_heads", 12)
+        kpos, gpos = cfg.get("conv_pos", 128), cfg.get("conv_pos_groups", 16)
+        s = {"mask_emb": (d,), "feature_extractor.conv_layers.0.0.weight": (C, 1, spec[0][1]),
+             "feature_extractor.conv_layers.0.2.weight": (C,), "feature_extractor.conv_layers.0.2.bias": (C,)}
+        for i in range(1, len(spec)):
+            s[f"feature_extractor.conv_layers.{i}.0.weight"] = (C, C, spec[i][1])
+        s.update({"post_extract_proj.weight": (d, C), "post_extract_proj.bias": (d,), "encoder.pos_conv.0.bias": (d,),
+                  "encoder.pos_conv.0.weight_g": (1, 1, kpos), "encoder.pos_conv.0.weight_v": (d, d // gpos, kpos)})
+        for i in range(cfg.get("encoder_layers", 12)):
+            p = f"encoder.layers.{i}."
+            s[p + "self_attn.grep_a"] = (1, H, 1, 1)
+            if i == 0:
+                s[p + "self_attn.relative_attention_bias.weight"] = (cfg.get("num_buckets", 320), H)
+            for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                s[p + f"self_attn.{n}.weight"], s[p + f"self_attn.{n}.bias"] = (d, d), (d,)
+            s[p + "self_attn.grep_linear.weight"], s[p + "self_attn.grep_linear.bias"] = (8, d // H), (8,)
+            s[p + "self_attn_layer_norm.weight"], s[p + "self_attn_layer_norm.bias"] = (d,), (d,)
+            s[p + "fc1.weight"], s[p + "fc1.bias"], s[p + "fc2.weight"], s[p + "fc2.bias"] = (ffn, d), (ffn,), (d, ffn), (d,)
+            s[p + "final_layer_norm.weight"], s[p + "final_layer_norm.bias"] = (d,), (d,)
+        s.update({"encoder.layer_norm.weight": (d,), "encoder.layer_norm.bias": (d,), "layer_norm.weight": (C,),
+                  "layer_norm.bias": (C,)})
+        return s
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         self.params = {k: v.detach().clone().float() for k, v in sd.items()}
         self._prepared = False
@@ -164,9 +227,33 @@ class WavLMBackbone:
         self._ws[key] = ws
         return ws
 
+    def _apply_mask(self, ws, B, Tn, Lw, n_samples):
+        cfg, dev = self.cfg, self.device
+        pad = None
+        if n_samples is not None and min(n_samples) < Lw:          # WavLM.forward_padding_mask: a frame is padding if all of
+            per = Lw // Tn                                          # its Lw // T samples are (the remainder samples are dropped)
+            pm = torch.ones(B, Lw, dtype=torch.bool)
+            for i, n in enumerate(n_samples):
+                pm[i, :n] = False
+            pad = pm[:, :per * Tn].view(B, Tn, per).all(-1)
+        tmask = cmask = None
+        if cfg.get("mask_prob", 0.0) > 0:
+            m = span_mask((B, Tn), pad, cfg["mask_prob"], cfg.get("mask_length", 10), min_masks=2)
+            tmask = torch.from_numpy(m).to(torch.uint8).to(dev)
+        if cfg.get("mask_channel_prob", 0.0) > 0:
+            m = span_mask((B, self.d), None, cfg["mask_channel_prob"], cfg.get("mask_channel_length", 10))
+            cmask = torch.from_numpy(m).to(torch.uint8).to(dev)
+        if "mask_emb" not in self.W:
+            self.W["mask_emb"] = self.params["mask_emb"].to(dev).contiguous()
+        ops.wavlm_apply_mask(ws["x"], tmask, cmask, self.W["mask_emb"], B, Tn)
+
     # ------------------------------------------------------------------ forward
-    def forward(self, wav: torch.Tensor, taps: Dict[str, torch.Tensor] = None) -> torch.Tensor:
-        """wav (B, L) f32 on the GPU -> (B, T, d) f32.  ``taps`` (tests): receives copies of the stage outputs."""
+    def forward(self, wav: torch.Tensor, taps: Dict[str, torch.Tensor] = None, mask: bool = False,
+                n_samples: List[int] = None) -> torch.Tensor:
+        """wav (B, L) f32 on the GPU -> (B, T, d) f32.  ``taps`` (tests): receives copies of the stage outputs.
+        mask=True (training, WavLM.apply_mask): spans of the projected features are replaced by ``mask_emb`` / zeroed channels
+        with cfg mask_prob / mask_channel_prob; n_samples (true lengths of a zero-padded batch) only shapes the padding mask
+        those spans avoid - like the reference, the encoder itself never sees a padding mask."""
         if not wav.is_cuda or wav.dtype != torch.float32:
             raise LidkError("WavLMBackbone.forward needs a float32 GPU tensor (B, L)")
         if not self._prepared:
@@ -189,6 +276,8 @@ class WavLMBackbone:
         k.gemm_nt(ws["h0"], W["proj_w"], ws["x"], bias=W["proj_b"])
         if taps is not None:
             taps["proj"] = ws["x"].view(B, Tn, d).clone()
+        if mask and (self.cfg.get("mask_prob", 0.0) > 0 or self.cfg.get("mask_channel_prob", 0.0) > 0):
+            self._apply_mask(ws, B, Tn, Lw, n_samples)
         # positional convolution + residual + LayerNorm
         cg = d // self.gpos
         k.wavlm_posconv_prep(ws["x"], ws["xg"], B, Tn, self.gpos, Pp, self.kpos // 2)

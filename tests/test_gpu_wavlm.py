@@ -101,16 +101,137 @@ def test_backbone_forward_stages_against_the_reference():
     out = bb.forward(wc.waveforms().to(DEV), taps)
     torch.cuda.synchronize()
     assert out.shape == (wc.B, 49, 768) and bb.frame_counts(wc.SAMPLES) == [3199, 1599, 799, 399, 199, 99, 49]
-    tol = {"conv": 4e-2, "proj": 6e-2, "enc_in": 5e-2, "gate0": 2e-2, "layer0": 6e-2, "layer1": 8e-2}
-    for key, t in tol.items():
+    # bf16 operands through 7 conv layers + 2 transformer layers: max-abs within 1.5 % of the stage's largest value,
+    # relative L2 error within 1 %
+    report, bad = [], []
+    for key in ("conv", "proj", "enc_in", "gate0", "layer0", "layer1"):
         ref = torch.from_numpy(g[key])
         got = taps[key].float().cpu()
         err, scale = float((got - ref).abs().max()), float(ref.abs().max())
         rel = float((got - ref).norm() / ref.norm())
-        print(f"[wavlm stage {key}] max_abs_err={err:.3e} (max |ref| {scale:.2f}) rel_l2={rel:.3e}")
-        assert err <= t and rel <= 1.5e-2, key
+        report.append(f"{key}: max_abs_err={err:.3e} (max |ref| {scale:.2f}) rel_l2={rel:.3e}")
+        if err > 1.5e-2 * scale or rel > 1e-2:
+            bad.append(key)
+    print("[wavlm stages] " + " | ".join(report))
+    assert not bad, (bad, report)
     ref = torch.from_numpy(g["features"])
-    assert float((out.cpu() - ref).abs().max()) <= 8e-2
+    assert float((out.cpu() - ref).abs().max()) <= 1.5e-2 * float(ref.abs().max())
     # a second call with another batch shape reuses nothing stale
     out2 = bb.forward(wc.waveforms()[:1, :12000].contiguous().to(DEV))
     assert out2.shape == (1, 37, 768) and bool(torch.isfinite(out2).all())
+
+
+def _model(dt=torch.bfloat16, dropout=0.0):
+    from lid.WavLMMutiLangModel import WavLMMutiLangModel
+    m = WavLMMutiLangModel(dropout=dropout, linear_dim=768, mask=False, lang2vocab=wc.L2V, lang2index=wc.L2I,
+                           hidden_dim=wc.HEAD["hidden_dim"], conformer_linear=True, dim_head=wc.HEAD["dim_head"],
+                           num_head=wc.HEAD["num_head"], wavlm_cfg=wc.CFG, compute_dtype=dt)
+    sd = {"model.featurizer.model." + k: v for k, v in wc.backbone_weights().items()}
+    sd.update(wc.head_weights())
+    sd["data_processor.resampler22k.kernel"] = torch.zeros(1, 1, 3)          # a reference checkpoint carries these: ignored
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+def test_full_model_eval_against_the_reference():
+    """WavLMMutiLangModel.forward (backbone + all three ConformerLinear heads at d = 768 + LangDiscriminator) against the
+    reference model's outputs on the same weights (tests/golden/wavlm_model.npz)."""
+    g = load_npz("wavlm_model.npz")
+    m = _model().eval()
+    wav = wc.waveforms().to(DEV)
+    with torch.no_grad():
+        logits, (lid_asr, lid_linear) = m([wav[i] for i in range(wav.shape[0])], 16000, None)
+        one, pair = m([wav[i] for i in range(wav.shape[0])], 16000, "b")
+    assert pair == (None, None) and torch.equal(one["b"], logits["b"])
+    for lang in wc.L2V:
+        ref = torch.from_numpy(g["logits_" + lang])
+        err, scale = float((logits[lang].cpu() - ref).abs().max()), float(ref.abs().max())
+        print(f"[wavlm model logits {lang}] max_abs_err={err:.3e} (max |ref| {scale:.2f})")
+        assert logits[lang].shape == ref.shape and err <= 3e-2 * max(1.0, scale)
+    e_asr = float((lid_asr.cpu() - torch.from_numpy(g["lid_asr"])).abs().max())
+    e_lin = float((lid_linear.cpu() - torch.from_numpy(g["lid_linear"])).abs().max())
+    print(f"[wavlm model] lid_asr err {e_asr:.3e} lid_linear err {e_lin:.3e}")
+    assert e_asr <= 2e-2 and e_lin <= 2e-2
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_head_training_step_on_frozen_backbone_against_the_reference(dt):
+    """One training-mode step of head 'b' (ConformerBlock d = 768, 8 x 32 heads, ff 3072, depthwise conv over 1536 channels,
+    BatchNorm batch statistics) on the backbone's features: logits, CTC loss and every head gradient against the reference's
+    autograd (norm + seeded sample per tensor).  f32 mode isolates the head (backbone stays bf16 in both)."""
+    g = load_npz("wavlm_model.npz")
+    m = _model(dt)
+    wav = wc.waveforms().to(DEV)
+    eng = m.lidk_engine
+    with torch.no_grad():
+        feats = m.backbone.forward(wav).clone()
+    eng.zero_grad()
+    out = eng.forward(feats, "b", training=True, keep_layers=[])["b"]
+    ref = torch.from_numpy(g["train_logits_b"])
+    scale = float(ref.abs().max())
+    lerr = float((out.cpu() - ref).abs().max())
+    texts = wc.texts().to(DEV)
+    B, T, V1 = out.shape
+    per = torch.empty(B, device=DEV)
+    dl = torch.empty(B, T, V1, device=DEV)
+    ws = torch.empty(ops.ctc_workspace_bytes(B, T, V1, texts.shape[1]) // 4 + 1, device=DEV)
+    ops.ctc_loss(out.contiguous(), texts, torch.full((B,), T, device=DEV, dtype=torch.long),
+                 torch.full((B,), texts.shape[1], device=DEV, dtype=torch.long), per, dl, ws, 40, grad_scale=1.0 / B)
+    loss, ref_loss = float(per.mean()), float(g["train_loss"])
+    print(f"[wavlm head step {dt}] logits err {lerr:.3e} (max |ref| {scale:.2f}); loss {loss:.4f} vs {ref_loss:.4f}")
+    assert lerr <= 4e-2 * max(1.0, scale) and abs(loss - ref_loss) <= 2e-2 * ref_loss
+    eng.backward(dl)
+    torch.cuda.synchronize()
+    big = float(g["grad_norms"].max())
+    worst_cos, worst_n, bad = 1.0, 0.0, []
+    for name, ref_norm in zip(g["grad_names"], g["grad_norms"]):
+        name = str(name)
+        got = eng.gview(name).reshape(-1)
+        if ref_norm < 1e-6 * big:
+            continue
+        idx = (torch.randperm(got.numel(), generator=torch.Generator().manual_seed(wc._seed(name)))[:2048].sort().values
+               if got.numel() > 2048 else torch.arange(got.numel()))
+        gs, rs = got[idx.to(DEV)].cpu().double(), torch.from_numpy(g["gs::" + name]).double()
+        cos = float((gs @ rs) / (gs.norm() * rs.norm() + 1e-300))
+        nrel = abs(float(got.double().norm()) - ref_norm) / ref_norm
+        worst_cos, worst_n = min(worst_cos, cos), max(worst_n, nrel)
+        if cos < 0.99 or nrel > 0.08:
+            bad.append((name, round(cos, 5), round(nrel, 4)))
+    print(f"[wavlm head step {dt}] {len(g['grad_names'])} gradient tensors: worst sampled cosine {worst_cos:.5f}, worst norm rel err {worst_n:.3e}")
+    assert not bad, bad[:8]
+
+
+def test_trainer_fit_wavlm_frozen_backbone(tmp_path, monkeypatch):
+    """`supervised: false` through the launcher: LidModule + WavLMMutiLangModel (2-layer backbone to keep it quick), raw-waveform
+    batches, GPU normalisation / dither / pre-emphasis, span masking, head training with Adam + TriStage, validation, checkpoint."""
+    import os
+    from conftest import PKG
+    from ccml import seed_everything
+    from ccml.callbacks.ckpt_callback import CkptCallback
+    from ccml.trainer import Trainer
+    from lid import hydra_lite
+    import lid.main as launcher
+    monkeypatch.chdir(tmp_path)
+    seed_everything(0)
+    cfg = hydra_lite.load_config(os.path.join(PKG, "lid", "conf"), "synthetic_wavlm",
+                                 ["model.wavlm_cfg.encoder_layers=2", "data.synthetic.items_per_lang=16", "data.synthetic.seconds=1.0",
+                                  "data.synthetic.text_len=8", "+data.synthetic.min_seconds=0.6", "data.sampler_common.train_batch_size=8",
+                                  "module.optimizer_param.lr=0.001", "trainer.total_epoch=3"])
+    module, sets, params = launcher.build(cfg)
+    assert type(module).__name__ == "LidModule" and isinstance(sets["train"].collate_fn([sets["train"][0]])[0], list)
+    losses = []
+    orig = module.train_loop_end
+
+    def spy(outputs):
+        losses.append(float(torch.stack([o["loss"].float() for o in outputs]).mean()))
+        return orig(outputs)
+
+    module.train_loop_end = spy
+    trainer = Trainer(callbacks=[CkptCallback(file_name_metric=["epoch", "val_loss"], save_topk=1)], loggers=[], **dict(cfg["trainer"]))
+    bb0 = module.model.state_dict()["model.featurizer.model.encoder.layers.0.fc1.weight"].clone()
+    trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=params)
+    print("wavlm epoch losses", losses, module.last_val)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] and np.isfinite(module.last_val["val_loss"])
+    sd = torch.load("ckpt/last.pt", weights_only=False)["model"]
+    assert torch.equal(sd["model.featurizer.model.encoder.layers.0.fc1.weight"].cpu(), bb0.cpu())      # frozen
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())

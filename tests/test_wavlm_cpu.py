@@ -1,0 +1,57 @@
+"""Host-side parts of the WavLM path (no GPU): the span-mask draw against the reference's compute_mask_indices (KATs captured under
+fixed numpy seeds in tests/golden/wavlm_model.npz), state-dict naming, LidModule construction from the reference's YAML keys."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz
+import wavlm_case as wc
+
+
+def test_span_mask_matches_reference_compute_mask_indices():
+    from lidk.wavlm import span_mask
+    g = load_npz("wavlm_model.npz")
+    for case in range(3):
+        rows, size, prob, length, mm, seed = g[f"mask{case}_args"]
+        np.random.seed(int(seed))
+        got = span_mask((int(rows), int(size)), None, float(prob), int(length), min_masks=int(mm))
+        assert np.array_equal(got, g[f"mask{case}"]), case
+    pm = torch.zeros(3, 49, dtype=torch.bool)
+    pm[1, 40:] = True
+    np.random.seed(9)
+    got = span_mask((3, 49), pm, 0.3, 5, min_masks=2)
+    assert np.array_equal(got, g["mask_pad"]) and not got[1, 40:].any()
+
+
+def test_relative_bucket_table_matches_reference_bias():
+    from lidk.wavlm import relative_buckets
+    g = load_npz("wavlm_fwd.npz")
+    emb = wc.backbone_weights()["encoder.layers.0.self_attn.relative_attention_bias.weight"]
+    T = g["pos_bias0"].shape[-1]
+    i, j = torch.arange(T)[:, None], torch.arange(T)[None, :]
+    table = emb[relative_buckets(j - i, 320, 800)].permute(2, 0, 1)
+    assert float((table - torch.from_numpy(g["pos_bias0"])).abs().max()) == 0.0
+
+
+def test_wavlm_model_state_dict_names_and_module_surface():
+    from lid.LidModule_ASR import LidModule
+    from lid.tokenizer import CTCTokenizer
+    from lidk.wavlm import WavLMBackbone
+    toks = {k: CTCTokenizer([chr(0x4E00 + i) for i in range(v)]) for k, v in wc.L2V.items()}
+    mod = LidModule(optimizer_name="adam", optimizer_param={"lr": 1e-4, "weight_decay": 1e-6}, scheduler="tristage", interval=50,
+                    freeze_tranformer_epoch=1, freeze_encoder_epoch=100, froze_wav2vec_model_epoch=-1, use_wav2vec=False,
+                    conformer_linear=True, extrme_mode=True, sr=16000, dropout=0.1, linear_dim=768, mask=True, num_layers=1,
+                    hidden_dim=32, model_name="x", feature_selection="last_hidden_state", use_pre_train=True, mask_channel_prob=0.15,
+                    double_swish=False, mask_prob=0.15, use_mask=False, dim_head=32, num_head=8, lang2vocab=wc.L2V,
+                    lang2index_dict=wc.L2I, tokenizer_dict=toks, wavlm_cfg=wc.CFG)
+    sd = mod.model.state_dict()
+    want = {"model.featurizer.model." + k for k in WavLMBackbone.param_shapes(wc.CFG)} | set(wc.head_weights())
+    assert set(sd) == want
+    assert mod.model.backbone.cfg["mask_prob"] == 0.15 and mod.model.backbone.cfg["mask_channel_prob"] == 0.15
+    assert set(WavLMBackbone.param_shapes(wc.CFG)) == set(wc.backbone_shapes(2))
+    trainable = [n for n, p in mod.model.named_parameters() if p.requires_grad]
+    assert trainable and not any(n.startswith("model.featurizer.") for n in trainable)          # frozen backbone
+    with pytest.raises(NotImplementedError):
+        mod.model.unfreeze_tranformer_encoder()
+    with pytest.raises(NotImplementedError):
+        LidModule(lang2vocab=wc.L2V, lang2index_dict=wc.L2I, tokenizer_dict=toks, use_wav2vec=True, conformer_linear=True)

@@ -74,3 +74,47 @@ def waveforms():
     for b in range(B):
         x[b] += 0.5 * torch.sin(2 * math.pi * (220.0 * (b + 1)) * t)
     return x
+
+
+def head_cfg(**kw):
+    from lidk.layout import ConformerCfg
+    base = dict(lang2vocab=dict(L2V), lang2index=dict(L2I), n_blocks=0, encoder_dim=768, last_heads=HEAD["num_head"],
+                last_dim_head=HEAD["dim_head"], hidden_dim=HEAD["hidden_dim"], dropout=0.0, pos_dropout=0.0,
+                use_stochastic_depth=False, front="features")
+    base.update(kw)
+    return ConformerCfg(**base)
+
+
+def head_weights():
+    """name -> tensor for the per-language ConformerLinear heads + LangDiscriminator of WavLMMutiLangModel (reference state_dict
+    names: model.last_projects.<lang>.block.*, .linear.*, lang_discriminator.linear.*), seeded per tensor name; BatchNorm
+    running statistics non-trivial."""
+    from lidk.layout import model_specs
+    specs, buffers, _, _ = model_specs(head_cfg())
+    out = {}
+    for s in specs:
+        g = torch.Generator().manual_seed(_seed(s.name))
+        shape = tuple(s.shape)
+        if s.name.endswith(("norm.weight", ".conv.net.0.weight", ".conv.net.5.weight")):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif s.name.endswith("rel_pos_emb.weight"):
+            t = 0.3 * torch.randn(shape, generator=g)
+        elif len(shape) >= 2:
+            t = torch.randn(shape, generator=g) * (1.0 / math.sqrt(math.prod(shape[1:])))
+        else:
+            t = 0.05 * torch.randn(shape, generator=g)
+        out[s.name] = t
+    for name, shape, dt in buffers:
+        g = torch.Generator().manual_seed(_seed(name))
+        if name.endswith("running_mean"):
+            out[name] = 0.2 * torch.randn(shape, generator=g)
+        elif name.endswith("running_var"):
+            out[name] = 0.5 + torch.rand(shape, generator=g)
+        else:
+            out[name] = torch.zeros(shape, dtype=dt)
+    return out
+
+
+def texts():
+    g = torch.Generator().manual_seed(77)
+    return torch.randint(0, 40, (B, 10), generator=g)
