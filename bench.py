@@ -65,7 +65,13 @@ def build(args, rank, world, device):
           f"data.synthetic.val_items_per_lang={args.val_items}", "data.synthetic.test_items_per_lang=2",
           "module.interval=1000000", "trainer.log_interval=1000000", f"model.n_blocks={args.blocks}",
           f"module.optimizer_param.lr={args.lr}"]
-    cfg = hydra_lite.load_config(os.path.join(ROOT, "speech-lid_amd", "lid", "conf"), "synthetic_cfg2", ov)
+    global N_LANGS
+    if args.model == "wavlm":
+        ov = [o for o in ov if not o.startswith(("model.n_blocks", "trainer.total_epoch", "module.optimizer_param.lr"))] + ["trainer.total_epoch=1000",
+              f"model.wavlm_cfg.encoder_layers={args.blocks}", "data.synthetic.seconds=3.0"]
+    cfg = hydra_lite.load_config(os.path.join(ROOT, "speech-lid_amd", "lid", "conf"),
+                                 "synthetic_cfg2" if args.model == "conformer" else "synthetic_wavlm", ov)
+    N_LANGS = len(cfg["data"]["langs"])
     module, sets, params = launcher.build(cfg, rank, world)
     module.model.use_stochastic_depth = bool(args.stochastic_depth)
     trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
@@ -111,7 +117,7 @@ def resident_batches(ds, rank, world, device, batch, resident):
             base = k * per_lang
             idx = [base + ((r * world + rank) * batch + j) % per_lang for j in range(batch)]
             b = list(ds.collate_fn([ds[i] for i in idx]))
-            b[0] = b[0].to(device)
+            b[0] = [w.to(device) for w in b[0]] if isinstance(b[0], list) else b[0].to(device)
             for j in (1, 2, 3, 5):
                 b[j] = b[j].to(device)
             out.append(b)
@@ -210,6 +216,53 @@ def cpu_baseline(module, ds, steps, warm, batch, threads, cpu_model, budget_s=40
                       f"fp32 torch-CPU oracle with torch.set_num_threads({threads}) = every core this process may use"}
 
 
+def cpu_baseline_wavlm(module, ds, steps, warm, batch, threads, cpu_model):
+    """The CPU oracle (oracle/wavlm.py + oracle/conformer.py, pinned to the reference) running the frozen-backbone training step:
+    waveform normalisation, backbone forward without gradients, head forward + backward under autograd, Adam on the head."""
+    from oracle import conformer as oc
+    from oracle import features as of
+    from oracle import wavlm as ow
+    torch.set_num_threads(threads)
+    cfg, wcfg = module.model.cfg, module.model.backbone.cfg
+    hcfg = oc.ModelCfg(lang2vocab=cfg.lang2vocab, lang2index=cfg.lang2index, n_blocks=0, encoder_dim=cfg.d,
+                       last_dim_head=cfg.last_dim_head, last_heads=cfg.last_heads, dropout=0.0, hidden_dim=cfg.hidden_dim)
+    sd = {k: v.detach().cpu().clone() for k, v in module.model.state_dict().items()}
+    bb = {k[len("model.featurizer.model."):]: v for k, v in sd.items() if k.startswith("model.featurizer.model.")}
+    heads = {k: v for k, v in sd.items() if not k.startswith("model.featurizer.")}
+    names = [k for k, v in heads.items() if v.is_floating_point() and "running_" not in k]
+    per_lang = len(ds) // N_LANGS
+    times = []
+    for step in range(steps + warm):
+        k = step % N_LANGS
+        lang = list(cfg.lang2vocab)[k]
+        items = [ds[k * per_lang + j % per_lang] for j in range(batch)]
+        t0 = time.time()
+        wav = of.normalize_wav(torch.stack([it[0] for it in items]))
+        with torch.no_grad():
+            feat = ow.backbone(wav, bb, wcfg)
+        p = {n: heads[n].requires_grad_(True) for n in names if f".{lang}." in n}
+        opts = oc.RunOpts(training=True)
+        logits = oc.head(feat, {**heads, **p}, hcfg, lang, opts)
+        texts = torch.stack([it[1] for it in items])
+        loss = oc.ctc_loss(logits, texts, torch.ones(batch), torch.ones(batch), blank=cfg.lang2vocab[lang])
+        loss.backward()
+        with torch.no_grad():
+            for n, t in p.items():                            # plain SGD stands in for Adam's few element-wise passes
+                t -= 1e-4 * t.grad
+                t.grad = None
+                t.requires_grad_(False)
+            heads.update(opts.bn_buffers)
+        if step >= warm:
+            times.append(time.time() - t0)
+        log(f"cpu baseline (wavlm) step {step + 1}/{steps + warm}: {time.time() - t0:.2f} s")
+    times.sort()
+    t = times[len(times) // 2]
+    return {"value": round(batch * SECONDS / t, 2), "unit": "audio-seconds/sec", "cores": threads, "cpu_model": cpu_model,
+            "kind": "port",
+            "sample": f"median of {len(times)} steps of batch {batch} (3 s utterances) after {warm} warm-up, {t:.2f} s/step, fp32 "
+                      f"torch-CPU oracle (backbone forward without gradients + head forward/backward), {threads} threads"}
+
+
 def _pmc_traffic(kernel_prefix):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (tools/gpu_pmc_bench.sh on this same
     command): FETCH_SIZE and WRITE_SIZE are in KB; FETCH_SIZE counts 64 B per 128-B request on gfx950 and is doubled, as
@@ -256,7 +309,8 @@ def roofline(trainer, batches, step_fn):
 
     def timed_nt(A, B, out, *a, M=None, N=None, K=None, **kw):
         m, kk, n = (A.shape[0] if M is None else M), (A.shape[1] if K is None else K), (B.shape[0] if N is None else N)
-        nbytes = m * kk * esz(A) + n * kk * esz(B) + m * n * esz(out)
+        a_cols = min(kk, A.stride(0))                 # a strided-view convolution operand: each input value is read once
+        nbytes = m * a_cols * esz(A) + n * kk * esz(B) + m * n * esz(out)
         for key in ("out2", "aux", "res"):
             if kw.get(key) is not None:
                 nbytes += m * n * esz(kw[key])
@@ -276,7 +330,8 @@ def roofline(trainer, batches, step_fn):
 
     graphs_on = eng.graphs.enabled
     eng.graphs.enabled = False
-    batches[0][0]._mel = batches[0][0]._mel_ready = None        # drop a prefetched copy: this step computes its own features
+    if hasattr(batches[0][0], "_mel"):
+        batches[0][0]._mel = batches[0][0]._mel_ready = None    # drop a prefetched copy: this step computes its own features
     k.gemm_nt, k.gemm_tn, WaveBatch._compute_mel = timed_nt, timed_tn, timed_mel
     try:
         step_fn(0, batches[0])
@@ -300,6 +355,17 @@ def roofline(trainer, batches, step_fn):
     ms2, fl2, by2, n2 = tot("tn")
     ms3, _, by3, n3 = tot("feat")
     gbs = by / (ms * 1e-3) / 1e9
+    tfs = fl / (ms * 1e-3) / 1e12
+    if fl / max(by, 1) > MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):          # above the machine balance: MFMA-bound
+        return {"bound": "mfma", "achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tfs / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "traffic_source": None,
+                "kernel": "gemm_nt (gemm_nt_bf16_direct_kernel, 64x64 tiles: strided-view convolutions, projections, FFN)",
+                "launches_per_step": n, "avg_launch_us": round(ms * 1e3 / n, 2), "kernel_ms_per_step": round(ms, 3),
+                "flops_per_launch": round(fl / n), "algorithmic_bytes_per_launch": round(by / n),
+                "flop_per_byte": round(fl / max(by, 1), 1), "event_bracket_overhead_us": round(ovh * 1e3, 2),
+                "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
+                "wgrad_kernel": {"kernel": "gemm_tn_bf16_kernel<64,64>", "launches_per_step": n2,
+                                 "avg_launch_us": round(ms2 * 1e3 / max(n2, 1), 2)} if n2 else None}
     traffic, src = _pmc_traffic("gemm_nt_bf16_")
     traffic2, _ = _pmc_traffic("gemm_tn_bf16_kernel")
     feat = None
@@ -433,6 +499,8 @@ def fit_throughput(args, cfg, module, sets, params, device):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--model", choices=["conformer", "wavlm"], default="conformer",
+                    help="conformer = BASELINE configs[1] (the headline); wavlm = configs[3]: WavLM-base backbone (frozen) + heads")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -451,6 +519,8 @@ def main():
     ap.add_argument("--fit-epochs", type=int, default=4, help="epochs of the Trainer.fit measurement (0 = skip)")
     ap.add_argument("--fit-workers", type=int, default=4)
     args = ap.parse_args()
+    if args.model == "wavlm":                    # secondary line: no Cavg phase (random frozen backbone), no fit leg
+        args.cavg_steps, args.fit_epochs = 0, 0
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -537,16 +607,27 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_model, usable = host_info()
         log(f"cpu baseline on {usable} cores ({cpu_model})")
-        cpu = cpu_baseline(module, ds, args.cpu_steps, 2, args.cpu_batch, usable, cpu_model)
+        if args.model == "wavlm":
+            cpu = cpu_baseline_wavlm(module, ds, max(args.cpu_steps // 2, 3), 1, min(args.cpu_batch, 8), usable, cpu_model)
+        else:
+            cpu = cpu_baseline(module, ds, args.cpu_steps, 2, args.cpu_batch, usable, cpu_model)
     if rank == 0:
         audio_s = world * args.batch * SECONDS * args.steps
         med = sorted(chunk_ms)[len(chunk_ms) // 2]
-        line = {"metric": "audio-seconds/sec LID training, Conformer d256", "value": round(audio_s / elapsed, 1),
+        if args.model == "wavlm":
+            metric = "audio-seconds/sec LID training, WavLM-base backbone (frozen) + Conformer heads"
+            workload = (f"WavLMMutiLangModel: WavLM-base width backbone ({args.blocks} transformer layers, conv extractor on raw "
+                        f"3 s@16 kHz waveforms, forward only = frozen, span masking on) + {N_LANGS} Conformer CTC heads d768 "
+                        f"(forward + backward), Adam, batch={args.batch}/GPU")
+        else:
+            metric = "audio-seconds/sec LID training, Conformer d256"
+            workload = (f"ConformerLangModel {args.blocks}-layer d256, 14-lang CTC heads, log-mel 80-bin, 3 s@16 kHz, "
+                        f"batch={args.batch}/GPU, Novograd+clip, features on GPU")
+        line = {"metric": metric, "value": round(audio_s / elapsed, 1),
                 "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": f"ConformerLangModel {args.blocks}-layer d256, 14-lang CTC heads, log-mel 80-bin, "
-                                       f"3 s@16 kHz, batch={args.batch}/GPU, Novograd+clip, features on GPU",
+                "config": {"workload": workload,
                            "global_batch": world * args.batch, "utterance_seconds": SECONDS,
                            "parallelism": f"dp{world}", "stochastic_depth": bool(args.stochastic_depth),
                            "grad_payload": trainer.grad_compress if world > 1 else None},

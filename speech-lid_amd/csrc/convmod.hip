@@ -424,18 +424,19 @@ extern "C" int lidk_bn_swish_fwd(const void* c, const float* mean, const float* 
 // ------------------------------------------------------------------------------------ BatchNorm + Swish backward
 
 // Column reduction over M rows of (dz, dz*xhat): a thread owns 4 consecutive channels (8/16-byte loads) and every
-// (256 / (C/4))-th row of its workgroup's row set; row-lanes are combined through LDS.  C % 4 == 0, C <= 1024.
+// (256 / (Cs/4))-th row of its workgroup's row set; row-lanes are combined through LDS.  One launch covers a slab of Cs <= 1024
+// channels starting at c0 (wider layers - the d = 768 heads have 1,536 conv channels - take one launch per slab).
 template <typename T>
 __global__ void __launch_bounds__(256)
 bn_swish_bwd_reduce_kernel(const T* __restrict__ ds, const T* __restrict__ c, const float* __restrict__ mean,
                            const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                           float* __restrict__ partial, int M, int C) {
+                           float* __restrict__ partial, int M, int C, int c0, int Cs) {
   __shared__ float red[256][8];
-  const int groups = C / 4, rl_n = 256 / groups;          // channel groups, row lanes
+  const int groups = Cs / 4, rl_n = 256 / groups;         // channel groups, row lanes
   const int cg = threadIdx.x % groups, rl = threadIdx.x / groups;
   float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
   if (rl < rl_n) {
-    const int ch = cg * 4;
+    const int ch = c0 + cg * 4;
     const float4 mu = load4(mean + ch), rs = load4(rstd + ch), g = load4(gamma + ch), b = load4(beta + ch);
     auto row = [&](float4 x, float4 d) __attribute__((always_inline)) {
       float xh, dz;
@@ -463,18 +464,22 @@ bn_swish_bwd_reduce_kernel(const T* __restrict__ ds, const T* __restrict__ c, co
       for (int q = 0; q < 4; ++q) { s0[q] += red[r * groups + cg][q]; s1[q] += red[r * groups + cg][4 + q]; }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      partial[((size_t)blockIdx.x * 2 + 0) * C + cg * 4 + q] = s0[q];
-      partial[((size_t)blockIdx.x * 2 + 1) * C + cg * 4 + q] = s1[q];
+      partial[((size_t)blockIdx.x * 2 + 0) * C + c0 + cg * 4 + q] = s0[q];
+      partial[((size_t)blockIdx.x * 2 + 1) * C + c0 + cg * 4 + q] = s1[q];
     }
   }
 }
 extern "C" int lidk_bn_swish_bwd_reduce(const void* ds, const void* c, const float* mean, const float* rstd,
                                         const float* gamma, const float* beta, float* partial, int M, int C, int dtype,
                                         void* stream) {
-  if (!ds || !c || !mean || !rstd || !gamma || !beta || !partial || M <= 0 || C <= 0 || (C & 3) || C > 1024) return LIDK_ERR_ARG;
-  // always LIDK_BN_PARTIAL_BLOCKS partial rows; blocks beyond M write zeros
-  LIDK_DISPATCH(dtype, bn_swish_bwd_reduce_kernel<T><<<LIDK_BN_PARTIAL_BLOCKS, 256, 0, as_stream(stream)>>>(
-                           (const T*)ds, (const T*)c, mean, rstd, gamma, beta, partial, M, C));
+  if (!ds || !c || !mean || !rstd || !gamma || !beta || !partial || M <= 0 || C <= 0 || (C & 3)) return LIDK_ERR_ARG;
+  // always LIDK_BN_PARTIAL_BLOCKS partial rows; blocks beyond M write zeros.  Channel slabs of <= 1024 (a multiple of 4 each).
+  const int nslab = cdiv(C, 1024), per = cdiv(cdiv(C, nslab), 4) * 4;
+  for (int c0 = 0; c0 < C; c0 += per) {
+    const int Cs = C - c0 < per ? C - c0 : per;
+    LIDK_DISPATCH(dtype, bn_swish_bwd_reduce_kernel<T><<<LIDK_BN_PARTIAL_BLOCKS, 256, 0, as_stream(stream)>>>(
+                             (const T*)ds, (const T*)c, mean, rstd, gamma, beta, partial, M, C, c0, Cs));
+  }
   return launch_status();
 }
 

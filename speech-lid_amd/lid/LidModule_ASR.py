@@ -144,9 +144,11 @@ class LidModule(CCMLModule):
 
     def train_loop(self, batch):
         out = self.common_loop(batch)
+        # host-sync policy (as in LidSuperviseModule): the reference reads loss.item() every step; here the running averages are
+        # refreshed every `interval` steps, so the host keeps issuing work ahead of the GPU in between
         if self.trainer.current_step % self.interval == self.interval - 1:
             logging.info("wer %.4f | predict: %s | label: %s", out["wer"], out["predict_texts"][0], out["label_texts"][0])
-        self._log_running(out, "tr_wer", "train")
+            self._log_running(out, "tr_wer", "train")
         return {"loss": out["loss"], "wer": out["wer"]}
 
     def before_train_loop(self, value):

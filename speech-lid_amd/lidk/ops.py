@@ -447,11 +447,15 @@ def lid_mlp(scores, w0, b0, w2, b2, out):
 
 
 # ----------------------------------------------------------------------------------------------- WavLM backbone (forward)
-def wavlm_conv0(wav, w, gamma, beta, out, T0, P0, eps=1e-5):
+def wavlm_conv0_workspace(B, T0, C):
+    return max(lib().lidk_wavlm_conv0_workspace(B, T0, C) // 4, 1)
+
+
+def wavlm_conv0(wav, w, gamma, beta, out, T0, P0, eps=1e-5, workspace=None):
     """wav (B, L) f32 -> out (B*P0 [+slack], C) bf16: Conv1d(1, C, k10, s5) + GroupNorm(C, C) + GELU, channel-last."""
     B, Lw = wav.shape
     Cc = w.shape[0]
-    ws = torch.empty(max(lib().lidk_wavlm_conv0_workspace(B, T0, Cc) // 4, 1), device=wav.device, dtype=torch.float32)
+    ws = workspace if workspace is not None else torch.empty(wavlm_conv0_workspace(B, T0, Cc), device=wav.device, dtype=torch.float32)
     check(lib().lidk_wavlm_conv0(_p(wav), B, Lw, _p(w), _p(gamma), _p(beta), eps, _p(out), T0, P0, Cc, _p(ws), _stream()),
           "wavlm_conv0")
     return out

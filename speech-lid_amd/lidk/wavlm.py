@@ -103,6 +103,11 @@ class WavLMBackbone:
         self.device = torch.device("cpu")
         self._prepared = False
         self._ws: Dict[tuple, dict] = {}
+        import os
+        from .engine import _GraphCache
+        # the forward is a fixed launch sequence per (batch, samples) shape over static buffers: replayed from hipGraphs
+        # (first use of a shape runs eagerly, the second is captured), like the engine's block sequences
+        self.graphs = _GraphCache(os.environ.get("LIDK_GRAPHS", "1") != "0")
 
     # ------------------------------------------------------------------ parameters
     @staticmethod
@@ -145,6 +150,7 @@ class WavLMBackbone:
         self.device = torch.device(device)
         self._prepared = False
         self._ws.clear()
+        self.graphs.clear()
         return self
 
     def _prepare(self):
@@ -214,7 +220,9 @@ class WavLMBackbone:
         bufs = [torch.zeros(B * P[l] + 8, self.C, device=dev, dtype=(bf if l < n - 1 else torch.float32)) for l in range(n)]
         Tn, M, d = T[-1], B * T[-1], self.d
         Pp = Tn + self.kpos
-        ws = dict(T=T, P=P, bufs=bufs, M=M, Tn=Tn, Pp=Pp,
+        ws = dict(T=T, P=P, bufs=bufs, M=M, Tn=Tn, Pp=Pp, wav=torch.empty(B, Lw, device=dev),
+                  c0ws=torch.empty(ops.wavlm_conv0_workspace(B, T[0], self.C), device=dev),
+                  tmask=torch.zeros(B, Tn, device=dev, dtype=torch.uint8), cmask=torch.zeros(B, d, device=dev, dtype=torch.uint8),
                   xc=torch.empty(M, self.C, device=dev), h0=torch.empty(M, self.C, device=dev, dtype=bf),
                   x=torch.empty(M, d, device=dev), xb=torch.empty(M, d, device=dev, dtype=bf),
                   x1=torch.empty(M, d, device=dev), x1b=torch.empty(M, d, device=dev, dtype=bf), y=torch.empty(M, d, device=dev),
@@ -224,6 +232,7 @@ class WavLMBackbone:
                   gate=torch.empty(B, self.H, Tn, device=dev))
         if len(self._ws) > 8:
             self._ws.clear()
+            self.graphs.clear()
         self._ws[key] = ws
         return ws
 
@@ -239,30 +248,22 @@ class WavLMBackbone:
         tmask = cmask = None
         if cfg.get("mask_prob", 0.0) > 0:
             m = span_mask((B, Tn), pad, cfg["mask_prob"], cfg.get("mask_length", 10), min_masks=2)
-            tmask = torch.from_numpy(m).to(torch.uint8).to(dev)
+            tmask = ws["tmask"]
+            tmask.copy_(torch.from_numpy(m.view("uint8")), non_blocking=True)
         if cfg.get("mask_channel_prob", 0.0) > 0:
             m = span_mask((B, self.d), None, cfg["mask_channel_prob"], cfg.get("mask_channel_length", 10))
-            cmask = torch.from_numpy(m).to(torch.uint8).to(dev)
+            cmask = ws["cmask"]
+            cmask.copy_(torch.from_numpy(m.view("uint8")), non_blocking=True)
         if "mask_emb" not in self.W:
             self.W["mask_emb"] = self.params["mask_emb"].to(dev).contiguous()
         ops.wavlm_apply_mask(ws["x"], tmask, cmask, self.W["mask_emb"], B, Tn)
 
-    # ------------------------------------------------------------------ forward
-    def forward(self, wav: torch.Tensor, taps: Dict[str, torch.Tensor] = None, mask: bool = False,
-                n_samples: List[int] = None) -> torch.Tensor:
-        """wav (B, L) f32 on the GPU -> (B, T, d) f32.  ``taps`` (tests): receives copies of the stage outputs.
-        mask=True (training, WavLM.apply_mask): spans of the projected features are replaced by ``mask_emb`` / zeroed channels
-        with cfg mask_prob / mask_channel_prob; n_samples (true lengths of a zero-padded batch) only shapes the padding mask
-        those spans avoid - like the reference, the encoder itself never sees a padding mask."""
-        if not wav.is_cuda or wav.dtype != torch.float32:
-            raise LidkError("WavLMBackbone.forward needs a float32 GPU tensor (B, L)")
-        if not self._prepared:
-            self._prepare()
-        wav = wav.contiguous()
-        B, Lw = wav.shape
-        ws, W, k = self._workspace(B, Lw), self.W, ops
+
+    def _fwd_pre(self, ws, B, taps):
+        """Feature extractor, LayerNorm, post_extract_proj -> ws["x"] (B*T, d) f32."""
+        W, k, wav = self.W, ops, ws["wav"]
         T, P, bufs, C, d = ws["T"], ws["P"], ws["bufs"], self.C, self.d
-        k.wavlm_conv0(wav, W["conv0_w"], W["gn_w"], W["gn_b"], bufs[0], T[0], P[0])
+        k.wavlm_conv0(wav, W["conv0_w"], W["gn_w"], W["gn_b"], bufs[0], T[0], P[0], workspace=ws["c0ws"])
         for l in range(1, len(T)):
             _, kw, st = self.layers_spec[l]
             A = bufs[l - 1].as_strided((B * P[l], kw * C), (st * C, 1))          # strided view: the convolution is this GEMM
@@ -276,8 +277,11 @@ class WavLMBackbone:
         k.gemm_nt(ws["h0"], W["proj_w"], ws["x"], bias=W["proj_b"])
         if taps is not None:
             taps["proj"] = ws["x"].view(B, Tn, d).clone()
-        if mask and (self.cfg.get("mask_prob", 0.0) > 0 or self.cfg.get("mask_channel_prob", 0.0) > 0):
-            self._apply_mask(ws, B, Tn, Lw, n_samples)
+
+    def _fwd_post(self, ws, B, taps):
+        """Positional convolution + LayerNorm, transformer layers -> ws["x"]."""
+        W, k = self.W, ops
+        Tn, M, Pp, d = ws["Tn"], ws["M"], ws["Pp"], self.d
         # positional convolution + residual + LayerNorm
         cg = d // self.gpos
         k.wavlm_posconv_prep(ws["x"], ws["xg"], B, Tn, self.gpos, Pp, self.kpos // 2)
@@ -302,4 +306,32 @@ class WavLMBackbone:
             k.layernorm_fwd(ws["y"], Lw_["ln2_w"], Lw_["ln2_b"], yT=ws["xb"], y32=ws["x"])
             if taps is not None:
                 taps[f"layer{i}"] = ws["x"].view(B, Tn, d).clone()
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, wav: torch.Tensor, taps: Dict[str, torch.Tensor] = None, mask: bool = False,
+                n_samples: List[int] = None) -> torch.Tensor:
+        """wav (B, L) f32 on the GPU -> (B, T, d) f32.  ``taps`` (tests): receives copies of the stage outputs.
+        mask=True (training, WavLM.apply_mask): spans of the projected features are replaced by ``mask_emb`` / zeroed channels
+        with cfg mask_prob / mask_channel_prob; n_samples (true lengths of a zero-padded batch) only shapes the padding mask
+        those spans avoid - like the reference, the encoder itself never sees a padding mask."""
+        if not wav.is_cuda or wav.dtype != torch.float32:
+            raise LidkError("WavLMBackbone.forward needs a float32 GPU tensor (B, L)")
+        if not self._prepared:
+            self._prepare()
+        wav = wav.contiguous()
+        B, Lw = wav.shape
+        ws = self._workspace(B, Lw)
+        Tn, d = ws["Tn"], self.d
+        ws["wav"].copy_(wav)                                  # static input buffer: captured launches see one address
+        masking = mask and (self.cfg.get("mask_prob", 0.0) > 0 or self.cfg.get("mask_channel_prob", 0.0) > 0)
+        if taps is not None:                                  # tests: eager, with copies of the stage outputs
+            self._fwd_pre(ws, B, taps)
+            if masking:
+                self._apply_mask(ws, B, Tn, Lw, n_samples)
+            self._fwd_post(ws, B, taps)
+        else:
+            self.graphs.run(("pre", B, Lw), lambda: self._fwd_pre(ws, B, None))
+            if masking:
+                self._apply_mask(ws, B, Tn, Lw, n_samples)     # host-drawn spans -> two small H2D copies + one launch
+            self.graphs.run(("post", B, Lw), lambda: self._fwd_post(ws, B, None))
         return ws["x"].view(B, Tn, d)
