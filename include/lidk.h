@@ -207,6 +207,12 @@ int lidk_dwconv_bwd_weight(const void* dc, const void* g, float* dw, float* db, 
  * with unbiased var; num_batches_tracked += 1. */
 int lidk_bn_train_stats(const double* sums, double count, float* mean, float* rstd, float* running_mean,
                         float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int C, void* stream);
+/* The same statistics straight from the depthwise conv's partial rows (partial [nparts][2][C] f32, as lidk_glu_dwconv_fwd
+ * writes them): column reduction in f64 + lidk_bn_train_stats in ONE launch.  Single-process training only - with data
+ * parallelism the SyncBatchNorm all-reduce needs the reduced sums in between. */
+int lidk_bn_train_stats_from_partials(const float* partial, int nparts, double count, float* mean, float* rstd,
+                                      float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, int C,
+                                      void* stream);
 int lidk_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* rstd, float eps, int C,
                        void* stream);
 /* s = swish(gamma*(c-mean)*rstd + beta) */
@@ -282,7 +288,8 @@ int lidk_wavlm_attn_fwd(const void* qkv, const float* gate, const float* rb, voi
  * ccml/trainer.py:541-543 clip_grad_norm_(max_norm) + ccml/optim/novograd.py:75-145 (amsgrad=False, luc=False).
  * work [n_work][3] int64 = (tensor id, element offset into the flat arenas, length <= LIDK_OPT_CHUNK); items of one tensor
  * are contiguous and tensors appear in ascending id order.  Only tensors present in `work` are touched ("grad is None" for
- * the rest).  exp_avg_sq [n_tensors]; scratch >= n_work + n_tensors + 8 floats.  total_norm_out [1] (pre-clip norm). */
+ * the rest).  exp_avg_sq [n_tensors]; scratch >= n_work + n_tensors + 8 floats.  total_norm_out [1] (pre-clip norm).
+ * The gradients of the touched tensors are consumed: they are ZERO on return (what optimizer.zero_grad() would do next). */
 #define LIDK_OPT_CHUNK 8192
 int lidk_novograd_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* work, int n_work,
                        int n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,

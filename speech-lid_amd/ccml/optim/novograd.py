@@ -41,6 +41,7 @@ class Novograd(Optimizer):
         elif None not in engines:
             raise ValueError("parameters of several lidk engines in one optimizer")
         self.fused_clip = self._engine is not None
+        self.zeroes_grads = self._engine is not None       # the fused launch leaves the gradients it consumed at zero
 
     # ------------------------------------------------------------------ fused path
     def _fused_step(self, max_norm: float):

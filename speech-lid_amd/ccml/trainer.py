@@ -278,10 +278,10 @@ class Trainer:
         return self.ccml_module.test_loop_end(outputs)
 
     # ------------------------------------------------------------------ the data-parallel step
-    def _zero_grad(self):
+    def _zero_grad(self, after_step: bool = False):
         self.optimizer.zero_grad(set_to_none=True)
-        if self.engine is not None:
-            self.engine.zero_grad()
+        if self.engine is not None and not (after_step and getattr(self.optimizer, "zeroes_grads", False)):
+            self.engine.zero_grad()            # (the fused Novograd launch already zeroed what it consumed)
 
     def _optimizer_step(self):
         self._wait_comm()
@@ -293,7 +293,7 @@ class Trainer:
             self.optimizer.step()
             if self.engine is not None:
                 self.engine.refresh_weights()
-        self._zero_grad()
+        self._zero_grad(after_step=True)
 
     def _scheduler_step(self, interval: str, metric=None):
         if self.lr_scheduler is None or self.sche_interval != interval:

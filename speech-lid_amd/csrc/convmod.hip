@@ -375,6 +375,37 @@ __global__ void bn_train_stats_kernel(const double* __restrict__ sums, double co
   if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
   if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * (count / (count > 1 ? count - 1 : 1)));
 }
+// Single-process form: column-reduce the depthwise conv's partial rows AND finish the statistics in one launch (under data
+// parallelism the all-reduce sits between the two, so lidk_reduce_partials_f64 + lidk_bn_train_stats stay separate there).
+__global__ void bn_train_stats_from_partials_kernel(const float* __restrict__ partial, int nparts, double count,
+                                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
+                                                    float* __restrict__ rvar, int64_t* __restrict__ nbt, float momentum, float eps,
+                                                    int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    s += (double)partial[(size_t)p * 2 * C + c];
+    ss += (double)partial[(size_t)p * 2 * C + C + c];
+  }
+  const double mu = s / count;
+  double var = ss / count - mu * mu;
+  if (var < 0) var = 0;
+  mean[c] = (float)mu;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * (count / (count > 1 ? count - 1 : 1)));
+}
+extern "C" int lidk_bn_train_stats_from_partials(const float* partial, int nparts, double count, float* mean, float* rstd,
+                                                 float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                                                 float eps, int C, void* stream) {
+  if (!partial || !mean || !rstd || nparts <= 0 || count <= 0 || C <= 0) return LIDK_ERR_ARG;
+  bn_train_stats_from_partials_kernel<<<cdiv(C, 64), 64, 0, as_stream(stream)>>>(partial, nparts, count, mean, rstd, running_mean,
+                                                                                running_var, nbt, momentum, eps, C);
+  return launch_status();
+}
+
 extern "C" int lidk_bn_train_stats(const double* sums, double count, float* mean, float* rstd, float* running_mean,
                                    float* running_var, int64_t* nbt, float momentum, float eps, int C, void* stream) {
   if (!sums || !mean || !rstd || C <= 0) return LIDK_ERR_ARG;

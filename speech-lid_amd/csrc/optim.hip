@@ -98,6 +98,7 @@ novograd_apply_kernel(float* __restrict__ params, float* __restrict__ grads, flo
     float m = beta1 * exp_avg[off + i] + g;
     exp_avg[off + i] = m;
     params[off + i] = p - lr * m;
+    grads[off + i] = 0.f;                      // consumed: the next step accumulates into zeros (no separate 186 MB memset)
   }
 }
 

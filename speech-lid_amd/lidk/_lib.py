@@ -70,6 +70,7 @@ SIGNATURES = {
     "lidk_dwconv_stat_parts": (_I, [_I, _I]),
     "lidk_dwconv_bwd_input": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_dwconv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lidk_bn_train_stats_from_partials": (_I, [_P, _I, _D, _P, _P, _P, _P, _P, _F, _F, _I, _P]),
     "lidk_bn_train_stats": (_I, [_P, _D, _P, _P, _P, _P, _P, _F, _F, _I, _P]),
     "lidk_bn_eval_stats": (_I, [_P, _P, _P, _P, _F, _I, _P]),
     "lidk_bn_swish_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -519,11 +519,15 @@ class Engine:
             pad_left = K // 2
             if training:                   # GLU fused into the depthwise conv's tile load; g is kept for the weight gradient
                 self.k.glu_dwconv_fwd(bb.y, dw2d, C["dwb"], bb.g, bb.c, w.stat_partial, B, T, pad_left)
-                self.k.reduce_partials_f64(w.stat_partial, w.stat_parts, 2 * ci, w.sums[:2 * ci + 1], tail=M)
+                if not self._fused_bn_stats():
+                    self.k.reduce_partials_f64(w.stat_partial, w.stat_parts, 2 * ci, w.sums[:2 * ci + 1], tail=M)
             else:
                 self.k.glu_dwconv_fwd(bb.y, dw2d, C["dwb"], None, bb.c, None, B, T, pad_left)
         if part in ("all", "b"):
-            if training:
+            if training and self._fused_bn_stats():        # single process: partial rows -> statistics in one launch
+                self.k.bn_train_stats_from_partials(w.stat_partial, w.stat_parts, M, bb.bn_mean, bb.bn_rstd, C["rm"], C["rv"],
+                                                    C["nbt"])
+            elif training:
                 # count 0: read the (all-reduced) row count from w.sums[2*ci]
                 self.k.bn_train_stats(w.sums[:2 * ci + 1], 0, bb.bn_mean, bb.bn_rstd, C["rm"], C["rv"], C["nbt"])
             else:
@@ -532,6 +536,9 @@ class Engine:
             self.k.gemm_nt(bb.s, C["w2"][0], bb.x3, bias=C["b2"], res=bb.x2)
             self._ff_fwd(bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.x4, bb.mean[3], bb.rstd[3])
         return bb.x4
+
+    def _fused_bn_stats(self) -> bool:
+        return self.stat_allreduce is None and hasattr(self.k, "bn_train_stats_from_partials")
 
     def _run_split(self, key, fn, collective):
         """``fn(part)`` issues a block's launches; they are replayed from captured hipGraphs.  Under data parallelism the

@@ -380,6 +380,14 @@ def bn_train_stats(sums, count, mean, rstd, running_mean, running_var, nbt, mome
                                     momentum, eps, Cc, _stream()), "bn_train_stats")
 
 
+def bn_train_stats_from_partials(partial, nparts, count, mean, rstd, running_mean, running_var, nbt, momentum=0.1, eps=1e-5):
+    """Partial rows (nparts, 2, C) f32 -> batch statistics + running statistics in one launch (no data parallelism)."""
+    Cc = mean.shape[0]
+    check(lib().lidk_bn_train_stats_from_partials(_p(partial), nparts, float(count), _p(mean), _p(rstd), _p(running_mean),
+                                                  _p(running_var), _p(nbt), momentum, eps, Cc, _stream()),
+          "bn_train_stats_from_partials")
+
+
 def bn_eval_stats(running_mean, running_var, mean, rstd, eps=1e-5):
     check(lib().lidk_bn_eval_stats(_p(running_mean), _p(running_var), _p(mean), _p(rstd), eps, mean.shape[0], _stream()),
           "bn_eval_stats")

@@ -401,6 +401,7 @@ def novograd_step(params, grads, exp_avg, exp_avg_sq, work, n_tensors, lr, betas
             g = g * (1 - betas[0])
         exp_avg[a:b] = betas[0] * exp_avg[a:b] + g
         params[a:b] -= lr * exp_avg[a:b]
+        grads[a:b] = 0                                # consumed, like the HIP launch
 
 
 # ------------------------------------------------------------------------------------------------ feature path (via the oracle)
