@@ -24,7 +24,8 @@ extern "C" {
 #define LIDK_ERR_UNSUPPORTED (-3)
 
 enum { LIDK_F32 = 0, LIDK_BF16 = 1 };
-enum { LIDK_ACT_NONE = 0, LIDK_ACT_SWISH = 1, LIDK_ACT_RELU = 2, LIDK_ACT_SWISH_GRAD = 3, LIDK_ACT_GELU = 4 };   /* GELU: exact erf form */
+enum { LIDK_ACT_NONE = 0, LIDK_ACT_SWISH = 1, LIDK_ACT_RELU = 2, LIDK_ACT_SWISH_GRAD = 3, LIDK_ACT_GELU = 4,   /* GELU: exact erf form; */
+       LIDK_ACT_GELU_GRAD = 5 };                                                                  /* out2 = pre-activation as for SWISH */
 
 #define LIDK_N_FFT 512
 #define LIDK_N_FREQ 257
@@ -105,7 +106,7 @@ int lidk_layernorm_param_grads(const float* partial, int M, int C, float* dgamma
  * Replaces every nn.Linear / 1x1 nn.Conv1d on the path (lid/conformer.py:98-100,163-166,192,199,334; lid/ConformerLangModel.py:350)
  * and their autograd (dgrad / wgrad run through the same kernel on transposed operands).
  * v = acc (+bias[n]);  act: SWISH -> out2 = v (pre-activation, T, optional), v = v*sigmoid(v);  RELU -> max(v,0);
- * SWISH_GRAD -> v *= swish'(aux[m][n]);  v *= alpha;  v += res[m][n] (f32, optional);
+ * GELU -> out2 = v (optional), v = gelu(v);  SWISH_GRAD / GELU_GRAD -> v *= act'(aux[m][n]);  v *= alpha;  v += res[m][n] (f32, optional);
  * out (T, or f32 when out_f32) = v; with splitk > 1 the K range is split over grid.z and out (f32) is accumulated atomically
  * (out must be pre-zeroed or hold the running gradient; bias/res/act must be unset).  K % 8 == 0, lda/ldb % 8 == 0.
  * lda may be SMALLER than K: rows of A then overlap, which is how a strided Conv1d over a channel-last [T][C] signal is a GEMM
@@ -281,6 +282,25 @@ int lidk_wavlm_gate(const float* x, const float* wg, const float* bg, const floa
  * out = softmax_j(q_i.k_j / sqrt(dh) + gate[b][h][i] * rb[h][j - i + RB - 1]) . v ; qkv [B*T][3*H*dh] bf16 (q | k | v blocks),
  * rb [H][2*RB-1] f32 (the head's bias as a function of the offset j - i, RB >= T), out [B*T][H*dh] bf16.  dh = 64, T <= 256. */
 int lidk_wavlm_attn_max_frames(int dh);
+/* Training path of the same attention.  lidk_wavlm_attn_probs stores the probabilities probs [B][H][T][ldp] bf16 (ldp =
+ * lidk_wavlm_attn_ldp(T), pad columns zero) for the backward pass; lidk_wavlm_attn_bwd: dqkv [B*T][3*H*dh] bf16 (dq | dk | dv),
+ * dgate [B][H][T] f32 (written), drb [H][2*RB-1] f32 (ACCUMULATED: the bias table's gradient, to be scattered into the bucket
+ * embedding by the caller), dscores [B][H][T][T] f32 scratch.  Two-pass VALU form (row pass, column pass). */
+int lidk_wavlm_attn_ldp(int T);
+int lidk_wavlm_attn_probs(const void* qkv, const float* gate, const float* rb, void* probs, int B, int T, int H, int dh, int RB,
+                          void* stream);
+int lidk_wavlm_attn_bwd(const void* qkv, const void* probs, const void* dout, const float* gate, const float* rb, void* dqkv,
+                        float* dgate, float* drb, float* dscores, int B, int T, int H, int dh, int RB, void* stream);
+/* Backward of lidk_wavlm_gate: dx [B*T][H*dh] f32 += the gate's contribution to the layer-input gradient; dwg [8][dh], dbg [8],
+ * dgrep_a [H] are ACCUMULATED. */
+int lidk_wavlm_gate_bwd(const float* x, const float* wg, const float* bg, const float* grep_a, const float* dgate, float* dx,
+                        float* dwg, float* dbg, float* dgrep_a, int B, int T, int H, int dh, void* stream);
+/* Operand of the positional convolution's backward: dpc [rows_total][C] bf16, row (b, t < T) = dy[b][t] * gelu'(pre[b*Pp + t]),
+ * zero in the pitch padding and the slack rows (so they add nothing to the weight gradient).  dpg (optional) [G][rows_total][C/G]
+ * bf16 receives the same values group-major at row b*Pp + goff + t: the operand of the data gradient; rows it never writes must
+ * be zero from allocation. */
+int lidk_wavlm_posconv_dprep(const float* dy, const void* pre, void* dpc, void* dpg, int B, int T, int Pp, int C, int G, int goff,
+                             long rows_total, void* stream);
 int lidk_wavlm_attn_fwd(const void* qkv, const float* gate, const float* rb, void* out, int B, int T, int H, int dh, int RB,
                         void* stream);
 

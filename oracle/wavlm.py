@@ -2,8 +2,9 @@
 
 Weights are a flat ``{name: tensor}`` dict with the reference's ``WavLM.state_dict()`` names (lid/wavlm/WavLM.py) so a public
 WavLM checkpoint drives this code directly.  Pinned by tests/golden/wavlm_fwd.npz / wavlm_model.npz, which
-oracle/gen_golden_wavlm.py wrote from the imported reference (tests/test_oracle_wavlm.py).  Eval-mode semantics (no dropout, no
-span masking); like the reference the encoder never sees a padding mask (WavLM.py:390-394).
+oracle/gen_golden_wavlm.py wrote from the imported reference (tests/test_oracle_wavlm.py); autograd through it is pinned by
+wavlm_finetune.npz / wavlm_frozen_masked.npz (the reference's own training-mode gradients).  No dropout; span masks are an input;
+like the reference the encoder never sees a padding mask (WavLM.py:390-394).
 """
 import math
 from typing import Dict, List
@@ -60,8 +61,10 @@ def attention(x, sd, p, H, pos_bias):
     return F.linear(o, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
 
 
-def backbone(wav, sd, cfg: Dict, taps: Dict = None):
-    """WavLM.extract_features(source, padding_mask, mask=False)[0] (WavLM.py:339-406): (B, L) -> (B, T, d)."""
+def backbone(wav, sd, cfg: Dict, taps: Dict = None, masks=None):
+    """WavLM.extract_features(source, padding_mask, mask)[0] (WavLM.py:339-406): (B, L) -> (B, T, d).  masks = (time (B, T) bool
+    or None, channel (B, d) bool or None): the spans WavLM.apply_mask (WavLM.py:300-337) drew, applied to the projected features -
+    masked frames become ``mask_emb``, then masked channels are zeroed over all frames."""
     H, n_layers = cfg.get("encoder_attention_heads", 12), cfg.get("encoder_layers", 12)
     feats = feature_extractor(wav, sd).transpose(1, 2)
     if taps is not None:
@@ -71,6 +74,12 @@ def backbone(wav, sd, cfg: Dict, taps: Dict = None):
     x = F.linear(x, sd["post_extract_proj.weight"], sd["post_extract_proj.bias"])
     if taps is not None:
         taps["proj"] = x
+    if masks is not None:
+        tm, cm = masks
+        if tm is not None:
+            x = torch.where(torch.as_tensor(tm)[:, :, None], sd["mask_emb"].to(x.dtype)[None, None, :], x)
+        if cm is not None:
+            x = x.masked_fill(torch.as_tensor(cm)[:, None, :], 0.0)
     d = x.shape[-1]
     k, groups = cfg.get("conv_pos", 128), cfg.get("conv_pos_groups", 16)
     w = torch._weight_norm(sd["encoder.pos_conv.0.weight_v"], sd["encoder.pos_conv.0.weight_g"], 2)
@@ -93,12 +102,12 @@ def backbone(wav, sd, cfg: Dict, taps: Dict = None):
     return x
 
 
-def model_forward(wavs: List[torch.Tensor], sd_backbone, sd_heads, wcfg: Dict, hcfg: "oc.ModelCfg", lang=None, opts=None):
+def model_forward(wavs: List[torch.Tensor], sd_backbone, sd_heads, wcfg: Dict, hcfg: "oc.ModelCfg", lang=None, opts=None, masks=None):
     """WavLMMutiLangModel.forward at 16 kHz (lid/WavLMMutiLangModel.py:71-77,262-284): backbone -> ConformerLinear heads ->
     LangDiscriminator.  sd_heads uses the reference names model.last_projects.<lang>.* / lang_discriminator.*."""
     opts = opts or oc.RunOpts()
     wav = torch.nn.utils.rnn.pad_sequence(list(wavs), batch_first=True)
-    feat = backbone(wav, sd_backbone, wcfg)
+    feat = backbone(wav, sd_backbone, wcfg, masks=masks)
     if lang is not None:
         return {lang: oc.head(feat, sd_heads, hcfg, lang, opts)}, (None, None)
     res = {l: oc.head(feat, sd_heads, hcfg, l, opts) for l in hcfg.lang2vocab}

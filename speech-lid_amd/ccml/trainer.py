@@ -147,9 +147,12 @@ class Trainer:
         inv_world = 1.0 / self.world_size
 
         def exchange(buf):
+            nonlocal payload
             if payload is None:
                 self._all_reduce_mean(buf)
                 return
+            if payload.numel() < buf.numel():     # (a backbone's gradient arena is longer than any engine stage)
+                payload = torch.empty(buf.numel(), device=self.device, dtype=torch.bfloat16)
             pl = payload[:buf.numel()]            # one payload buffer: exchanges are serialised on the communication stream
             engine.k.scale_cast(buf, pl, inv_world)
             dist.all_reduce(pl)
@@ -167,7 +170,18 @@ class Trainer:
             else:
                 exchange(buf)
 
+        def on_buffer(buf):                     # gradients that live outside the engine's arena (an un-frozen WavLM encoder)
+            if not self._sync_grads:
+                return
+            if use_side_stream:
+                self._comm_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._comm_stream):
+                    exchange(buf)
+            else:
+                exchange(buf)
+
         engine.on_stage_grads_ready = on_ready
+        self._dp_buffer_hook = on_buffer
         dist.broadcast(engine.flat, src=0)                 # DDP ctor semantics: rank 0's parameters and buffers win
         for b in engine.buffers.values():
             dist.broadcast(b, src=0)
@@ -191,6 +205,14 @@ class Trainer:
         if ddp:
             if self.engine is not None:
                 self._attach_native_dp(self.engine)
+                if hasattr(model, "on_backbone_grads_ready"):        # parameters outside the engine arena (WavLM backbone):
+                    with torch.no_grad():                            # DDP constructor semantics for them too, and their
+                        for name, p in model.named_parameters():    # gradient arena joins the exchange when it is ready
+                            if getattr(p, "_lidk_engine", None) is None:
+                                dist.broadcast(p.data, src=0)
+                    if hasattr(model, "_sync_backbone"):
+                        model._sync_backbone()
+                    model.on_backbone_grads_ready = self._dp_buffer_hook
             else:
                 if self.sync_bn and self.device.type == "cuda":
                     model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)

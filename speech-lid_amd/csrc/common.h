@@ -31,6 +31,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 
 // GELU, exact erf form (torch.nn.functional.gelu default; lid/wavlm/modules.py gelu)
 __device__ __forceinline__ float gelu_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// d/dx gelu(x) = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_grad_(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
 
 // 4-wide load/store of activations held as T (float or bf16); p must be 4-element aligned.
 __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -377,18 +377,30 @@ __global__ void bn_train_stats_kernel(const double* __restrict__ sums, double co
 }
 // Single-process form: column-reduce the depthwise conv's partial rows AND finish the statistics in one launch (under data
 // parallelism the all-reduce sits between the two, so lidk_reduce_partials_f64 + lidk_bn_train_stats stay separate there).
-__global__ void bn_train_stats_from_partials_kernel(const float* __restrict__ partial, int nparts, double count,
-                                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
-                                                    float* __restrict__ rvar, int64_t* __restrict__ nbt, float momentum, float eps,
-                                                    int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
+__global__ void __launch_bounds__(1024)
+bn_train_stats_from_partials_kernel(const float* __restrict__ partial, int nparts, double count,
+                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
+                                    float* __restrict__ rvar, int64_t* __restrict__ nbt, float momentum, float eps,
+                                    int C) {
+  // 64 channels x 16 part-lanes per workgroup: each lane strides over the partial rows (independent coalesced loads), the 16
+  // lane sums are folded in fixed order through LDS -> deterministic.
+  __shared__ double red[2][16][64];
+  const int lane = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  if (c == 0 && pl == 0 && nbt) *nbt += 1;
   double s = 0.0, ss = 0.0;
-  for (int p = 0; p < nparts; ++p) {
-    s += (double)partial[(size_t)p * 2 * C + c];
-    ss += (double)partial[(size_t)p * 2 * C + C + c];
-  }
+  if (c < C)
+    for (int p = pl; p < nparts; p += 16) {
+      s += (double)partial[(size_t)p * 2 * C + c];
+      ss += (double)partial[(size_t)p * 2 * C + C + c];
+    }
+  red[0][pl][lane] = s;
+  red[1][pl][lane] = ss;
+  __syncthreads();
+  if (pl != 0 || c >= C) return;
+  s = 0.0; ss = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { s += red[0][i][lane]; ss += red[1][i][lane]; }
   const double mu = s / count;
   double var = ss / count - mu * mu;
   if (var < 0) var = 0;
@@ -401,7 +413,7 @@ extern "C" int lidk_bn_train_stats_from_partials(const float* partial, int npart
                                                  float* running_mean, float* running_var, int64_t* nbt, float momentum,
                                                  float eps, int C, void* stream) {
   if (!partial || !mean || !rstd || nparts <= 0 || count <= 0 || C <= 0) return LIDK_ERR_ARG;
-  bn_train_stats_from_partials_kernel<<<cdiv(C, 64), 64, 0, as_stream(stream)>>>(partial, nparts, count, mean, rstd, running_mean,
+  bn_train_stats_from_partials_kernel<<<cdiv(C, 64), 1024, 0, as_stream(stream)>>>(partial, nparts, count, mean, rstd, running_mean,
                                                                                 running_var, nbt, momentum, eps, C);
   return launch_status();
 }

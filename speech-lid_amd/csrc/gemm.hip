@@ -41,11 +41,14 @@ __device__ __forceinline__ void epi_store(const Epi& e, int m, int n, float acc)
   } else if (e.act == LIDK_ACT_RELU) {
     v = fmaxf(v, 0.f);
   } else if (e.act == LIDK_ACT_GELU) {
+    if (e.out2) ((T*)e.out2)[(size_t)m * e.ldo2 + n] = from_f<T>(v);
     v = gelu_(v);
   } else if (e.act == LIDK_ACT_SWISH_GRAD) {
     float a = to_f(((const T*)e.aux)[(size_t)m * e.ldaux + n]);
     float s = sigmoidf_(a);
     v *= s * (1.f + a * (1.f - s));
+  } else if (e.act == LIDK_ACT_GELU_GRAD) {
+    v *= gelu_grad_(to_f(((const T*)e.aux)[(size_t)m * e.ldaux + n]));
   }
   v *= e.alpha;
   if (e.res) v += e.res[(size_t)m * e.ldres + n];
@@ -73,7 +76,11 @@ __device__ __forceinline__ void epi_store4(const Epi& e, int m, int n, int N, fl
   } else if (e.act == LIDK_ACT_RELU) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
   } else if (e.act == LIDK_ACT_GELU) {
+    if (e.out2) store4((T*)e.out2 + (size_t)m * e.ldo2 + n, v);
     v.x = gelu_(v.x); v.y = gelu_(v.y); v.z = gelu_(v.z); v.w = gelu_(v.w);
+  } else if (e.act == LIDK_ACT_GELU_GRAD) {
+    float4 a = load4((const T*)e.aux + (size_t)m * e.ldaux + n);
+    v.x *= gelu_grad_(a.x); v.y *= gelu_grad_(a.y); v.z *= gelu_grad_(a.z); v.w *= gelu_grad_(a.w);
   } else if (e.act == LIDK_ACT_SWISH_GRAD) {
     float4 a = load4((const T*)e.aux + (size_t)m * e.ldaux + n);
     float s;
@@ -227,7 +234,11 @@ __device__ __forceinline__ float4 epi_math4(const Epi& e, int m, int n, float4 v
   } else if (e.act == LIDK_ACT_RELU) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
   } else if (e.act == LIDK_ACT_GELU) {
+    *pre = v;
     v.x = gelu_(v.x); v.y = gelu_(v.y); v.z = gelu_(v.z); v.w = gelu_(v.w);
+  } else if (e.act == LIDK_ACT_GELU_GRAD) {
+    float4 a = load4((const bf16*)e.aux + (size_t)m * e.ldaux + n);
+    v.x *= gelu_grad_(a.x); v.y *= gelu_grad_(a.y); v.z *= gelu_grad_(a.z); v.w *= gelu_grad_(a.w);
   } else if (e.act == LIDK_ACT_SWISH_GRAD) {
     float4 a = load4((const bf16*)e.aux + (size_t)m * e.ldaux + n);
     float s;
@@ -365,7 +376,7 @@ gemm_nt_bf16_direct_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
           float4 p0, p1;
           float4 v0 = epi_math4(e, m, n, a0, &p0);
           float4 v1 = epi_math4(e, m, n + 4, a1, &p1);
-          if (e.act == LIDK_ACT_SWISH && e.out2) st16(e, (bf16*)e.out2 + (size_t)m * e.ldo2 + n, pack8(p0, p1));
+          if ((e.act == LIDK_ACT_SWISH || e.act == LIDK_ACT_GELU) && e.out2) st16(e, (bf16*)e.out2 + (size_t)m * e.ldo2 + n, pack8(p0, p1));
           st16(e, (bf16*)e.out + (size_t)m * e.ldo + n, pack8(v0, v1));
         } else {
           epi_store4<bf16>(e, m, n, N, a0);
@@ -562,7 +573,7 @@ gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, int
 extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
   if (!g || !g->A || !g->B || !g->out || g->M <= 0 || g->N <= 0 || g->K <= 0) return LIDK_ERR_ARG;
   if ((g->K & 7) || (g->lda & 7) || (g->ldb & 7) || g->ldb < g->K || g->ldo < g->N) return LIDK_ERR_ARG;
-  if (g->act == LIDK_ACT_SWISH_GRAD && !g->aux) return LIDK_ERR_ARG;
+  if ((g->act == LIDK_ACT_SWISH_GRAD || g->act == LIDK_ACT_GELU_GRAD) && !g->aux) return LIDK_ERR_ARG;
   int splitk = g->splitk > 1 ? g->splitk : 1;
   if (splitk > 1 && (g->bias || g->res || g->act != LIDK_ACT_NONE || !g->out_f32)) return LIDK_ERR_ARG;
   static const int dbg = getenv("LIDK_GEMM_DBG") ? atoi(getenv("LIDK_GEMM_DBG")) : 0;
@@ -818,7 +829,7 @@ gemm_tn_f32_kernel(const float* __restrict__ X, int ldx, const float* __restrict
 extern "C" int lidk_gemm_tn(const void* X, int ldx, const void* Y, int ldy, float* C, int ldc, float* colsum, int M, int N1,
                             int N2, float alpha, int splitk, int dtype, void* stream) {
   if (!X || !Y || !C || M <= 0 || N1 <= 0 || N2 <= 0 || ldc < N2) return LIDK_ERR_ARG;
-  if (ldx < ((N1 + 7) & ~7) || ldy < ((N2 + 7) & ~7) || (ldx & 7) || (ldy & 7)) return LIDK_ERR_ARG;
+  if ((ldx & 7) || (ldy & 7)) return LIDK_ERR_ARG;        // ldx < N1 / ldy < N2: overlapping rows (strided-view convolution operands)
   hipStream_t s = as_stream(stream);
   if (splitk < 1) splitk = 1;
   if (dtype == LIDK_BF16) {

@@ -345,3 +345,288 @@ extern "C" int lidk_wavlm_attn_fwd(const void* qkv, const float* gate, const flo
                                                                         1.0f / sqrtf(64.0f), NJ);
   return launch_status();
 }
+
+// =====================================================================================================================
+// Backward pass of the transformer part (un-frozen encoder: the reference's regime after freeze_tranformer_epoch).
+// First correct versions: the attention backward is a VALU two-pass form (row pass + column pass through an f32 dS buffer),
+// like attn.hip's v1 kernels, with the bias-table and gate gradients added.
+// =====================================================================================================================
+
+// Attention forward variant that also stores the probabilities (needed by backward): same kernel as above, P written out.
+// probs [B][H][T][Tp32] bf16.  Implemented by a flag of wavlm_attn_fwd_kernel would cost registers in the inference path, so the
+// training path runs this small extra kernel instead: it recomputes S rows (VALU) - only T*T*dh per (b,h), once per layer.
+template <int DH>
+__global__ void __launch_bounds__(256)
+wavlm_attn_probs_kernel(const bf16* __restrict__ qkv, const float* __restrict__ gate, const float* __restrict__ rb,
+                        bf16* __restrict__ probs, int T_, int H, int RB, int ldp, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int LDK = DH + 2;
+  bf16* Ks = reinterpret_cast<bf16*>(smem);                                  // [T][LDK]
+  float* fb = reinterpret_cast<float*>(smem + (((size_t)T_ * LDK * 2) + 15) / 16 * 16);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* qs = fb + wave * (DH + T_);
+  float* ps = qs + DH;
+  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 16, inner = H * DH, ld = 3 * inner;
+  const bf16* base = qkv + (size_t)b * T_ * ld + h * DH;
+  for (int idx = threadIdx.x; idx < T_ * DH; idx += blockDim.x) {
+    const int j = idx / DH, d = idx - j * DH;
+    Ks[j * LDK + d] = base[(size_t)j * ld + inner + d];
+  }
+  __syncthreads();
+  const float* rbh = rb + (size_t)h * (2 * RB - 1) + RB - 1;
+  for (int ii = wave; ii < 16; ii += 4) {
+    const int i = i0 + ii;
+    if (i >= T_) break;
+    for (int d = lane; d < DH; d += 64) qs[d] = to_f(base[(size_t)i * ld + d]);
+    __builtin_amdgcn_wave_barrier();
+    const float g = gate[((size_t)b * H + h) * T_ + i];
+    float mx = -INFINITY;
+    for (int j = lane; j < T_; j += 64) {
+      float s = 0.f;
+      for (int d = 0; d < DH; ++d) s = fmaf(qs[d], to_f(Ks[j * LDK + d]), s);
+      s = s * scale + g * rbh[j - i];
+      ps[j] = s; mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < T_; j += 64) { float e = __expf(ps[j] - mx); ps[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    bf16* prow = probs + (((size_t)b * H + h) * T_ + i) * ldp;
+    for (int j = lane; j < ldp; j += 64) prow[j] = (bf16)(j < T_ ? ps[j] * inv : 0.f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// row pass: dP = dO.V^T ; delta = sum_j P dP ; dS = P (dP - delta) -> dscores (f32 [B][H][T][T]) ; dq = scale dS.K ;
+// dgate[b][h][i] = sum_j dS[i][j] rb[h][j - i]
+template <int DH>
+__global__ void __launch_bounds__(256)
+wavlm_attn_bwd_rows_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ probs, const bf16* __restrict__ dout,
+                           const float* __restrict__ rb, bf16* __restrict__ dqkv, float* __restrict__ dscores,
+                           float* __restrict__ dgate, int T_, int H, int RB, int ldp, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int LDK = DH + 2;
+  bf16* Ks = reinterpret_cast<bf16*>(smem);
+  bf16* Vs = Ks + (size_t)T_ * LDK;
+  float* fb = reinterpret_cast<float*>(smem + (((size_t)2 * T_ * LDK * 2) + 15) / 16 * 16);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* dos = fb + wave * (DH + T_);
+  float* ps = dos + DH;
+  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 16, inner = H * DH, ld = 3 * inner;
+  const bf16* base = qkv + (size_t)b * T_ * ld + h * DH;
+  for (int idx = threadIdx.x; idx < T_ * DH; idx += blockDim.x) {
+    const int j = idx / DH, d = idx - j * DH;
+    Ks[j * LDK + d] = base[(size_t)j * ld + inner + d];
+    Vs[j * LDK + d] = base[(size_t)j * ld + 2 * inner + d];
+  }
+  __syncthreads();
+  const float* rbh = rb + (size_t)h * (2 * RB - 1) + RB - 1;
+  for (int ii = wave; ii < 16; ii += 4) {
+    const int i = i0 + ii;
+    if (i >= T_) break;
+    for (int d = lane; d < DH; d += 64) dos[d] = to_f(dout[((size_t)b * T_ + i) * inner + h * DH + d]);
+    __builtin_amdgcn_wave_barrier();
+    const bf16* prow = probs + (((size_t)b * H + h) * T_ + i) * ldp;
+    float delta = 0.f;
+    for (int j = lane; j < T_; j += 64) {
+      float dp = 0.f;
+      for (int d = 0; d < DH; ++d) dp = fmaf(dos[d], to_f(Vs[j * LDK + d]), dp);
+      ps[j] = dp;
+      delta = fmaf(to_f(prow[j]), dp, delta);
+    }
+    delta = wave_sum(delta);
+    float* dsrow = dscores + (((size_t)b * H + h) * T_ + i) * T_;
+    float dg = 0.f;
+    for (int j = lane; j < T_; j += 64) {
+      const float ds = to_f(prow[j]) * (ps[j] - delta);
+      ps[j] = ds; dsrow[j] = ds;
+      dg = fmaf(ds, rbh[j - i], dg);
+    }
+    dg = wave_sum(dg);
+    if (lane == 0) dgate[((size_t)b * H + h) * T_ + i] = dg;
+    __builtin_amdgcn_wave_barrier();
+    float a = 0.f;                                              // DH == 64: lane <-> d
+    for (int j = 0; j < T_; ++j) a = fmaf(ps[j], to_f(Ks[j * LDK + lane]), a);
+    dqkv[((size_t)b * T_ + i) * ld + h * DH + lane] = (bf16)(a * scale);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// column pass, one item per wave: item < nkc: lane <-> key j: dk[j] = scale sum_i dS[i][j] q[i], dv[j] = sum_i P[i][j] dO[i];
+// item >= nkc: lane <-> offset r = j - i: drb[h][r] += sum_i gate[i] dS[i][i + r]   (atomics over the batch)
+template <int DH>
+__global__ void __launch_bounds__(256)
+wavlm_attn_bwd_cols_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ probs, const bf16* __restrict__ dout,
+                           const float* __restrict__ dscores, const float* __restrict__ gate, bf16* __restrict__ dqkv,
+                           float* __restrict__ drb, int T_, int H, int RB, int ldp, float scale) {
+  __shared__ float Qs[64 * DH];
+  __shared__ float Ds[64 * DH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, inner = H * DH, ld = 3 * inner;
+  const int nkc = (T_ + 63) / 64, nrc = (2 * T_ - 1 + 63) / 64;
+  const int item = blockIdx.y * 4 + wave;
+  const bool is_key = item < nkc, is_rel = !is_key && item < nkc + nrc;
+  const int j = item * 64 + lane, r = (item - nkc) * 64 + lane - (T_ - 1);
+  const size_t sbase = ((size_t)b * H + h) * T_ * T_, pbase = ((size_t)b * H + h) * T_ * ldp;
+  const float* grow = gate + ((size_t)b * H + h) * T_;
+  float ak[DH], av[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) { ak[d] = 0.f; av[d] = 0.f; }
+  float arel = 0.f;
+  for (int ic0 = 0; ic0 < T_; ic0 += 64) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * DH; idx += blockDim.x) {
+      const int ii = idx / DH, d = idx - ii * DH, i = min(ic0 + ii, T_ - 1);
+      Qs[idx] = to_f(qkv[((size_t)b * T_ + i) * ld + h * DH + d]);
+      Ds[idx] = to_f(dout[((size_t)b * T_ + i) * inner + h * DH + d]);
+    }
+    __syncthreads();
+    const int ihi_c = min(ic0 + 64, T_);
+    if (is_key && j < T_) {
+      for (int i = ic0; i < ihi_c; ++i) {
+        const float s = dscores[sbase + (size_t)i * T_ + j];
+        const float pr = to_f(probs[pbase + (size_t)i * ldp + j]);
+        const float* q = Qs + (i - ic0) * DH;
+        const float* dd = Ds + (i - ic0) * DH;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) { ak[d] = fmaf(s, q[d], ak[d]); av[d] = fmaf(pr, dd[d], av[d]); }
+      }
+    } else if (is_rel && r <= T_ - 1) {
+      const int ilo = max(max(0, -r), ic0), ihi = min(min(T_ - 1, T_ - 1 - r), ihi_c - 1);      // 0 <= i + r <= T-1
+      for (int i = ilo; i <= ihi; ++i) arel = fmaf(grow[i], dscores[sbase + (size_t)i * T_ + (i + r)], arel);
+    }
+  }
+  if (is_key && j < T_) {
+    bf16* krow = dqkv + ((size_t)b * T_ + j) * ld + inner + h * DH;
+    bf16* vrow = krow + inner;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { krow[d] = (bf16)(ak[d] * scale); vrow[d] = (bf16)av[d]; }
+  } else if (is_rel && r <= T_ - 1 && r >= -(T_ - 1)) {
+    atomicAdd(&drb[(size_t)h * (2 * RB - 1) + r + RB - 1], arel);
+  }
+}
+
+extern "C" int lidk_wavlm_attn_ldp(int T_) { return (T_ + 31) / 32 * 32; }
+extern "C" int lidk_wavlm_attn_probs(const void* qkv, const float* gate, const float* rb, void* probs, int B, int T_, int H, int dh,
+                                     int RB, void* stream) {
+  if (!qkv || !gate || !rb || !probs || B <= 0 || T_ <= 0 || H <= 0 || RB < T_) return LIDK_ERR_ARG;
+  if (dh != 64 || T_ > 256) return LIDK_ERR_UNSUPPORTED;
+  const size_t lds = (((size_t)T_ * 66 * 2) + 15) / 16 * 16 + 4 * (size_t)(64 + T_) * 4;
+  (void)hipFuncSetAttribute((const void*)wavlm_attn_probs_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  wavlm_attn_probs_kernel<64><<<dim3(cdiv(T_, 16), H, B), 256, lds, as_stream(stream)>>>(
+      (const bf16*)qkv, gate, rb, (bf16*)probs, T_, H, RB, lidk_wavlm_attn_ldp(T_), 0.125f);
+  return launch_status();
+}
+extern "C" int lidk_wavlm_attn_bwd(const void* qkv, const void* probs, const void* dout, const float* gate, const float* rb,
+                                   void* dqkv, float* dgate, float* drb, float* dscores, int B, int T_, int H, int dh, int RB,
+                                   void* stream) {
+  if (!qkv || !probs || !dout || !gate || !rb || !dqkv || !dgate || !drb || !dscores || B <= 0 || T_ <= 0 || H <= 0 || RB < T_)
+    return LIDK_ERR_ARG;
+  if (dh != 64 || T_ > 256) return LIDK_ERR_UNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  const int ldp = lidk_wavlm_attn_ldp(T_);
+  const size_t lds = (((size_t)2 * T_ * 66 * 2) + 15) / 16 * 16 + 4 * (size_t)(64 + T_) * 4;
+  (void)hipFuncSetAttribute((const void*)wavlm_attn_bwd_rows_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  wavlm_attn_bwd_rows_kernel<64><<<dim3(cdiv(T_, 16), H, B), 256, lds, s>>>(
+      (const bf16*)qkv, (const bf16*)probs, (const bf16*)dout, rb, (bf16*)dqkv, dscores, dgate, T_, H, RB, ldp, 0.125f);
+  const int items = (T_ + 63) / 64 + (2 * T_ - 1 + 63) / 64;
+  wavlm_attn_bwd_cols_kernel<64><<<dim3(B * H, cdiv(items, 4)), 256, 0, s>>>(
+      (const bf16*)qkv, (const bf16*)probs, (const bf16*)dout, dscores, gate, (bf16*)dqkv, drb, T_, H, RB, ldp, 0.125f);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ gate backward
+// dgate [B][H][T] -> dx[m][h*dh + d] += sum_q du[q] wg[q][d] ; dwg [8][dh], dbg [8], dgrep_a [H] accumulated (workgroup-level
+// reduction in LDS, then one atomic per element per workgroup).
+__global__ void __launch_bounds__(256)
+wavlm_gate_bwd_kernel(const float* __restrict__ x, const float* __restrict__ wg, const float* __restrict__ bg,
+                      const float* __restrict__ grep_a, const float* __restrict__ dgate, float* __restrict__ dx,
+                      float* __restrict__ dwg, float* __restrict__ dbg, float* __restrict__ dgrep_a, int B, int T_, int H, int dh) {
+  extern __shared__ float red[];                       // [8*dh] dwg | [8] dbg | [H] dgrep_a
+  const int nred = 8 * dh + 8 + H;
+  for (int i = threadIdx.x; i < nred; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  const long n = (long)B * T_ * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int h = (int)(i % H); const long m = i / H;
+    const long b = m / T_, t = m % T_;
+    const float* xr = x + m * (long)H * dh + (long)h * dh;
+    float u[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = bg[q];
+    for (int d = 0; d < dh; ++d) {
+      const float v = xr[d];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) u[q] = fmaf(wg[q * dh + d], v, u[q]);
+    }
+    const float ga = 1.f / (1.f + __expf(-(u[0] + u[1] + u[2] + u[3])));
+    const float gb = 1.f / (1.f + __expf(-(u[4] + u[5] + u[6] + u[7])));
+    const float a = grep_a[h], dgt = dgate[(b * H + h) * T_ + t];
+    const float dsa = dgt * (gb * a - 1.f) * ga * (1.f - ga), dsb = dgt * ga * a * gb * (1.f - gb);
+    atomicAdd(&red[8 * dh + 8 + h], dgt * ga * gb);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) atomicAdd(&red[8 * dh + q], q < 4 ? dsa : dsb);
+    float* dxr = dx + m * (long)H * dh + (long)h * dh;
+    for (int d = 0; d < dh; ++d) {
+      const float v = xr[d];
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float du = q < 4 ? dsa : dsb;
+        acc = fmaf(du, wg[q * dh + d], acc);
+        atomicAdd(&red[q * dh + d], du * v);
+      }
+      dxr[d] += acc;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nred; i += blockDim.x) {
+    const float v = red[i];
+    if (v == 0.f) continue;
+    if (i < 8 * dh) atomicAdd(&dwg[i], v);
+    else if (i < 8 * dh + 8) atomicAdd(&dbg[i - 8 * dh], v);
+    else atomicAdd(&dgrep_a[i - 8 * dh - 8], v);
+  }
+}
+extern "C" int lidk_wavlm_gate_bwd(const float* x, const float* wg, const float* bg, const float* grep_a, const float* dgate, float* dx,
+                                   float* dwg, float* dbg, float* dgrep_a, int B, int T_, int H, int dh, void* stream) {
+  if (!x || !wg || !bg || !grep_a || !dgate || !dx || !dwg || !dbg || !dgrep_a || B <= 0 || T_ <= 0 || H <= 0 || dh <= 0) return LIDK_ERR_ARG;
+  const long n = (long)B * T_ * H;
+  int blocks = (int)((n + 255) / 256); if (blocks > 1024) blocks = 1024;
+  wavlm_gate_bwd_kernel<<<blocks, 256, (size_t)(8 * dh + 8 + H) * 4, as_stream(stream)>>>(x, wg, bg, grep_a, dgate, dx, dwg, dbg,
+                                                                                          dgrep_a, B, T_, H, dh);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ positional conv backward operand
+// dpc [B*Pp + slack][C] bf16: row (b, t) = dy[b][t] * gelu'(pre[b*Pp + t]) for t < T, zero elsewhere (pitch padding, slack).
+// dpg (optional) [G][rows_total][C/G] bf16: the same values group-major at row b*Pp + goff + t - the operand of the DATA gradient
+// (a strided-view GEMM against the flipped kernel); its other rows are never written and must be zero from allocation.
+__global__ void wavlm_posconv_dprep_kernel(const float* __restrict__ dy, const bf16* __restrict__ pre, bf16* __restrict__ dpc,
+                                           bf16* __restrict__ dpg, int B, int T_, int Pp, int C, int G, int goff, long rows_total) {
+  const long n = rows_total * C;
+  const int cg = C / G;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); const long row = i / C;
+    float v = 0.f;
+    if (row < (long)B * Pp) {
+      const long b = row / Pp, t = row % Pp;
+      if (t < T_) {
+        v = dy[(b * T_ + t) * C + c] * gelu_grad_(to_f(pre[row * C + c]));
+        if (dpg) { const int g = c / cg; dpg[((size_t)g * rows_total + row + goff) * cg + (c - g * cg)] = (bf16)v; }
+      }
+    }
+    dpc[i] = (bf16)v;
+  }
+}
+extern "C" int lidk_wavlm_posconv_dprep(const float* dy, const void* pre, void* dpc, void* dpg, int B, int T_, int Pp, int C, int G,
+                                        int goff, long rows_total, void* stream) {
+  if (!dy || !pre || !dpc || B <= 0 || T_ <= 0 || Pp < T_ || C <= 0 || rows_total < (long)B * Pp) return LIDK_ERR_ARG;
+  if (dpg && (G <= 0 || C % G || goff < 0 || goff + T_ > Pp)) return LIDK_ERR_ARG;
+  const long n = rows_total * C;
+  int blocks = (int)((n + 255) / 256); if (blocks > 16384) blocks = 16384;
+  wavlm_posconv_dprep_kernel<<<blocks, 256, 0, as_stream(stream)>>>(dy, (const bf16*)pre, (bf16*)dpc, (bf16*)dpg, B, T_, Pp, C,
+                                                                    G > 0 ? G : 1, goff, rows_total);
+  return launch_status();
+}

@@ -55,8 +55,10 @@ class _EngineFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         model = ctx.model
-        model.lidk_engine.backward(dlogits)
+        dfeat = model.lidk_engine.backward(dlogits)
         model._publish_grads(ctx.lang, ctx.keep)
+        if dfeat is not None and hasattr(model, "_backbone_backward"):      # features front: the backbone's own backward
+            model._backbone_backward(dfeat)
         return None, None, None, None, None, None
 
 

@@ -31,7 +31,7 @@ class LidModule(CCMLModule):
                  conformer_linear: bool = False, double_swish: bool = False, use_pre_train: bool = True,
                  mask_channel_prob: float = 0.0, mask_prob: float = 0.0, sr: int = 22050, conformer_pure: bool = False,
                  extrme_mode: bool = False, keep_train_lang: str = None, use_mask: bool = False, dim_head: int = 32,
-                 num_head: int = 8, wavlm_cfg: Dict = None, *args, **kwargs):
+                 num_head: int = 8, wavlm_cfg: Dict = None, train_input_norm: bool = True, *args, **kwargs):
         super().__init__(pt_path=pt_path, feature_selection=feature_selection, linear_dim=linear_dim, mask=mask,
                          num_layers=num_layers, hidden_dim=hidden_dim, lang2vocab=lang2vocab, lang2index_dict=lang2index_dict,
                          tokenizer_dict=tokenizer_dict, use_wav2vec=use_wav2vec, conformer_linear=conformer_linear,
@@ -56,7 +56,7 @@ class LidModule(CCMLModule):
             num_layers=num_layers, lang2vocab=lang2vocab, lang2index=lang2index_dict, hidden_dim=hidden_dim,
             conformer_linear=conformer_linear, double_swish=double_swish, use_pre_train=use_pre_train,
             mask_channel_prob=mask_channel_prob, mask_prob=mask_prob, conformer_pure=conformer_pure, use_mask=use_mask,
-            dim_head=dim_head, num_head=num_head, wavlm_cfg=wavlm_cfg)
+            dim_head=dim_head, num_head=num_head, wavlm_cfg=wavlm_cfg, train_input_norm=train_input_norm)
         self.count, self.avg_loss, self.avg_wer = 1, 0.0, 0.0
         self.predict_texts, self.label_texts, self.wer = None, None, 0.0
         self.countdown_20 = 0
@@ -65,7 +65,11 @@ class LidModule(CCMLModule):
 
     # ------------------------------------------------------------------ optimizer / schedule (reference :140-176)
     def config_optim(self, *args, **kwargs):
-        params = [p for p in self.model.parameters() if p.requires_grad]          # the frozen backbone takes no optimizer state
+        # all parameters, like the reference (:140-150): frozen ones carry no gradient, so the optimizer skips them (and
+        # allocates no state) until freeze_tranformer_epoch has passed; the never-trained conv extractor is left out
+        never = {id(p) for n, p in self.model.named_parameters()
+                 if n.startswith(("model.featurizer.model.feature_extractor.", "model.featurizer.model.post_extract_proj."))}
+        params = [p for p in self.model.parameters() if id(p) not in never]
         name = self.optimizer_name
         if name == "sgd":
             optimizer = torch.optim.SGD(params, **self.optimizer_param)

@@ -9,10 +9,14 @@ Kept: constructor keywords, ``forward(x: list of 1-D waveforms, sample_rate, lan
 key>``, ``model.last_projects.<lang>.block.*`` / ``.linear.*``, ``lang_discriminator.linear.{0,2}.*`` (the reference's
 torchaudio ``data_processor.resampler*.kernel`` buffers are ignored on load and not written).
 
-What runs: the backbone FORWARD on hand-written HIP (lidk/wavlm.py) without autograd, the heads forward + backward on the lidk
-Engine (``front="features"``).  This is the reference's training regime while the backbone is frozen
-(``freeze_encoder_epoch`` / ``freeze_tranformer_epoch``, lid/LidModule_ASR.py:243-258) and its inference path; un-freezing the
-backbone raises: its backward pass is not built.
+What runs: the backbone on hand-written HIP (lidk/wavlm.py) without autograd, the heads forward + backward on the lidk Engine
+(``front="features"``).  While the backbone is frozen (``freeze_encoder_epoch`` / ``freeze_tranformer_epoch``,
+lid/LidModule_ASR.py:243-258) and in inference the backbone forward is two captured graphs.  After
+``unfreeze_tranformer_encoder()`` the transformer encoder (pos-conv, encoder LayerNorm, every layer, the relative-position
+bucket embedding) trains too: the forward keeps each layer's activations, the Engine hands back d(loss)/d(features) and
+``WavLMBackbone.backward`` produces the encoder gradients, published as the ``.grad`` of the reference-named Parameters.  The
+convolutional feature extractor + post_extract_proj stay frozen (``unfreeze_feature_extractor`` raises): the reference's
+default schedule never reaches it (freeze_encoder_epoch = 100 >= total_epoch, lid/LidModule_ASR.py:26).
 """
 import logging
 from typing import Dict, List, Optional
@@ -32,7 +36,8 @@ class WavLMMutiLangModel(_EngineBoundModel):
                  mask: bool = True, num_layers: int = 1, lang2vocab: Dict = None, lang2index: Dict = None, hidden_dim: int = 128,
                  conformer_linear: bool = False, double_swish: bool = False, use_pre_train: bool = True,
                  mask_channel_prob: float = 0, mask_prob: float = 0.0, conformer_pure: bool = False, use_mask: bool = False,
-                 dim_head: int = 32, num_head: int = 8, compute_dtype=torch.bfloat16, wavlm_cfg: Optional[Dict] = None, **_ignored):
+                 dim_head: int = 32, num_head: int = 8, compute_dtype=torch.bfloat16, wavlm_cfg: Optional[Dict] = None,
+                 train_input_norm: bool = True, **_ignored):
         super().__init__()
         if not conformer_linear:
             raise NotImplementedError("LSTM heads (conformer_linear=False) are outside the lidk path (SURVEY 2 #3)")
@@ -70,6 +75,15 @@ class WavLMMutiLangModel(_EngineBoundModel):
         self.lang_discriminator.classes = len(lang2vocab)
         self.forced_masks = None
         self._backbone_frozen = {"extractor": True, "encoder": True}
+        self._bb_stale = False                    # encoder parameters changed since the bf16 operands were derived
+        # The reference's freeze_feature_extractor / freeze_tranformer_encoder (lid/WavLMMutiLangModel.py:78-104) leave WavLM's
+        # own ``layer_norm`` (in front of post_extract_proj) and ``mask_emb`` trainable, so even the "frozen" regime back-
+        # propagates through the whole transformer to reach them.  train_input_norm=True (default) keeps that; False stops
+        # the gradient at the features (backbone forward = two captured graphs, nothing saved: the fast frozen regime).
+        self.train_input_norm = bool(train_input_norm)
+        for n in WavLMBackbone.INPUT_SIDE:
+            dict(self.named_parameters())["model.featurizer.model." + n].requires_grad = self.train_input_norm
+        self.on_backbone_grads_ready = None       # data parallelism: called with the backbone's flat gradient arena
 
     @staticmethod
     def _random_backbone(cfg):
@@ -95,7 +109,8 @@ class WavLMMutiLangModel(_EngineBoundModel):
         return {n: params["model.featurizer.model." + n].data for n in self._bb_names}
 
     def _sync_backbone(self):
-        self.backbone.load_state_dict(self._backbone_params())
+        self.backbone.load_state_dict(self._backbone_params(), share=True)      # optimizer updates reach backbone.refresh()
+        self._bb_stale = False
 
     def _moved(self, device):
         for n in self._bb_names:                                   # the frozen backbone's parameters follow the model
@@ -120,10 +135,16 @@ class WavLMMutiLangModel(_EngineBoundModel):
         wav = torch.nn.utils.rnn.pad_sequence([w.reshape(-1) for w in wavs], batch_first=True).float()
         if not wav.is_cuda:
             raise LidkError("WavLMMutiLangModel.forward: waveforms must be on the GPU (no CPU fallback)")
+        grad_path = self.training and torch.is_grad_enabled() and lang is not None
+        if self._bb_stale:
+            self.backbone.refresh()
+            self._bb_stale = False
+        self._bb_shape = tuple(wav.shape)
         with torch.no_grad():
-            feats = self.backbone.forward(wav.contiguous(), mask=self.training, n_samples=n_samples)
+            feats = self.backbone.forward(wav.contiguous(), mask=self.training, n_samples=n_samples,
+                                          train=grad_path and (self.train_input_norm or not self._backbone_frozen["encoder"]))
         eng = self.lidk_engine
-        if self.training and torch.is_grad_enabled() and lang is not None:
+        if grad_path:
             if self._anchor is None or self._anchor.device != feats.device:
                 self._anchor = torch.zeros(1, device=feats.device, requires_grad=True)
             logits = _EngineFn.apply(self._anchor, feats, self, lang, [], self.forced_masks)
@@ -138,19 +159,52 @@ class WavLMMutiLangModel(_EngineBoundModel):
     def freeze_feature_extractor(self):
         self._backbone_frozen["extractor"] = True
 
-    def freeze_tranformer_encoder(self):
-        self._backbone_frozen["encoder"] = True
+    def _encoder_parameters(self):
+        params = dict(self.named_parameters())
+        return {n: params["model.featurizer.model." + n] for n in self._bb_names if n.startswith(WavLMBackbone.TRAINABLE_PREFIX)}
 
-    def _unfreeze(self, what):
-        raise NotImplementedError(
-            f"un-freezing the WavLM {what} needs the backbone's backward pass, which this build does not have yet (forward-only "
-            "HIP path, SURVEY 8f N1): keep freeze_encoder_epoch / freeze_tranformer_epoch at or above trainer.total_epoch")
+    def freeze_tranformer_encoder(self):                                      # noqa: F811 (reference spelling)
+        self._backbone_frozen["encoder"] = True
+        for p in self._encoder_parameters().values():
+            p.requires_grad = False
 
     def unfreeze_feature_extractor(self):
-        self._unfreeze("feature extractor")
+        raise NotImplementedError(
+            "un-freezing the WavLM convolutional feature extractor needs its backward pass, which is not built (SURVEY 8f N1): "
+            "keep freeze_encoder_epoch at or above trainer.total_epoch (the reference's default, 100)")
 
     def unfreeze_tranformer_encoder(self):
-        self._unfreeze("transformer encoder")
+        """lid/WavLMMutiLangModel.py:106-112: the transformer encoder's parameters take gradients from now on."""
+        if any(float(self.backbone.cfg.get(k, 0.0)) > 0 for k in ("dropout", "attention_dropout", "activation_dropout")) \
+                and not getattr(self, "_warned_dropout", False):
+            logging.warning("WavLM encoder dropout / attention_dropout / activation_dropout are not applied by the lidk backbone "
+                            "(LayerDrop and span masking are); set them to 0 in the checkpoint cfg to silence this")
+            self._warned_dropout = True
+        self._backbone_frozen["encoder"] = False
+        for p in self._encoder_parameters().values():
+            p.requires_grad = True
+
+    def _backbone_backward(self, dfeat: torch.Tensor):
+        """Called by the autograd node after the heads' backward: encoder gradients from d(loss)/d(features)."""
+        frozen = self._backbone_frozen["encoder"]
+        if frozen and not self.train_input_norm:
+            return
+        bb = self.backbone
+        params = dict(self.named_parameters())
+        live = {n: params["model.featurizer.model." + n] for n in self._bb_names
+                if params["model.featurizer.model." + n].requires_grad}
+        bb._alloc_grads()
+        if any(p.grad is None for p in live.values()):            # zero_grad(set_to_none) since the last backward: new step
+            bb.zero_grads()
+        bb.backward(dfeat, *self._bb_shape, wgrads=not frozen)
+        masked = bb.cfg.get("mask_prob", 0.0) > 0
+        for n, p in live.items():
+            if n == "mask_emb" and not masked:                     # no span was replaced: the reference leaves .grad None
+                continue
+            p.grad = bb.grads[n]
+        if self.on_backbone_grads_ready is not None:
+            self.on_backbone_grads_ready(bb.grad_flat)
+        self._bb_stale = True                                      # an optimizer step follows
 
     def keep_last_lang_model_train(self, lang):
         raise NotImplementedError("keep_train_lang (freezing all heads but one) is not built")

@@ -5,7 +5,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_SWISH, ACT_RELU, ACT_SWISH_GRAD, ACT_GELU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_SWISH, ACT_RELU, ACT_SWISH_GRAD, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2, 3, 4, 5
 LN_PARTIAL_BLOCKS = 256
 LN_BWD_BLOCKS = 1024
 BN_PARTIAL_BLOCKS = 1024
@@ -87,6 +87,11 @@ SIGNATURES = {
     "lidk_wavlm_apply_mask": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_wavlm_gate": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "lidk_wavlm_attn_max_frames": (_I, [_I]),
+    "lidk_wavlm_attn_ldp": (_I, [_I]),
+    "lidk_wavlm_attn_probs": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lidk_wavlm_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lidk_wavlm_gate_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "lidk_wavlm_posconv_dprep": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _P]),
     "lidk_wavlm_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lidk_ctc_greedy": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "lidk_lid_mlp": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

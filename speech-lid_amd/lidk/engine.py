@@ -847,8 +847,8 @@ class Engine:
             if self.on_stage_grads_ready:
                 self.on_stage_grads_ready(prev[4])
         dy = dfeat                                   # f32 gradient at the first block's input (after pos-enc dropout)
-        if cfg.front != "subsample":                 # frozen backbone: nothing upstream takes a gradient
-            return
+        if cfg.front != "subsample":                 # backbone features: hand d(loss)/d(features) to the caller
+            return dfeat[:M].view(ctx["front_in"].shape)
         # front end: x0 = sqrt(d) * (r @ Wl^T + b) [dropout]; r = relu(col @ Wc^T + bc)
         fz = "model.featurizer.sub_sampling"
         if cfg.pos_dropout > 0:

@@ -504,6 +504,36 @@ def wavlm_attn_fwd(qkv, gate, rb, out, B, T, H, dh):
     return out
 
 
+def wavlm_attn_ldp(T):
+    return lib().lidk_wavlm_attn_ldp(T)
+
+
+def wavlm_attn_probs(qkv, gate, rb, probs, B, T, H, dh):
+    RB = (rb.shape[1] + 1) // 2
+    check(lib().lidk_wavlm_attn_probs(_p(qkv), _p(gate), _p(rb), _p(probs), B, T, H, dh, RB, _stream()), "wavlm_attn_probs")
+    return probs
+
+
+def wavlm_attn_bwd(qkv, probs, dout, gate, rb, dqkv, dgate, drb, dscores, B, T, H, dh):
+    RB = (rb.shape[1] + 1) // 2
+    check(lib().lidk_wavlm_attn_bwd(_p(qkv), _p(probs), _p(dout), _p(gate), _p(rb), _p(dqkv), _p(dgate), _p(drb), _p(dscores),
+                                    B, T, H, dh, RB, _stream()), "wavlm_attn_bwd")
+
+
+def wavlm_gate_bwd(x, wg, bg, grep_a, dgate, dx, dwg, dbg, dgrep_a, B, T, H, dh):
+    check(lib().lidk_wavlm_gate_bwd(_p(x), _p(wg), _p(bg), _p(grep_a), _p(dgate), _p(dx), _p(dwg), _p(dbg), _p(dgrep_a), B, T, H,
+                                    dh, _stream()), "wavlm_gate_bwd")
+
+
+def wavlm_posconv_dprep(dy, pre, dpc, B, T, Pp, dpg=None, goff=0):
+    G = dpg.shape[0] if dpg is not None else 0
+    if dpg is not None and dpg.shape[1] != dpc.shape[0]:
+        raise LidkError("wavlm_posconv_dprep: dpg must hold as many rows per group as dpc")
+    check(lib().lidk_wavlm_posconv_dprep(_p(dy), _p(pre), _p(dpc), _p(dpg), B, T, Pp, dy.shape[1], G, goff, dpc.shape[0],
+                                         _stream()), "wavlm_posconv_dprep")
+    return dpc
+
+
 # ----------------------------------------------------------------------------------------------- optimizer
 def novograd_step(params, grads, exp_avg, exp_avg_sq, work, n_tensors, lr, betas, eps, weight_decay, grad_averaging,
                   max_norm, scratch, total_norm):

@@ -22,6 +22,7 @@ MI355X-first design of the pieces:
 import math
 from typing import Dict, List
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -78,6 +79,25 @@ def span_mask(shape, padding_mask, mask_prob: float, mask_length: int, min_masks
             r = rng.choice(r, keep, replace=False)
         mask[i, r] = True
     return mask
+
+
+def _same_tree(a, b):
+    if isinstance(a, dict):
+        return isinstance(b, dict) and a.keys() == b.keys() and all(_same_tree(a[k], b[k]) for k in a)
+    if isinstance(a, list):
+        return isinstance(b, list) and len(a) == len(b) and all(_same_tree(x, y) for x, y in zip(a, b))
+    return torch.is_tensor(a) and torch.is_tensor(b) and a.shape == b.shape and a.dtype == b.dtype and a.device == b.device
+
+
+def _copy_tree(dst, src):
+    if isinstance(dst, dict):
+        for k in dst:
+            _copy_tree(dst[k], src[k])
+    elif isinstance(dst, list):
+        for x, y in zip(dst, src):
+            _copy_tree(x, y)
+    else:
+        dst.copy_(src)
 
 
 class WavLMBackbone:
@@ -139,8 +159,10 @@ class WavLMBackbone:
                   "layer_norm.bias": (C,)})
         return s
 
-    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
-        self.params = {k: v.detach().clone().float() for k, v in sd.items()}
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], share: bool = False):
+        """``share``: keep references to the caller's f32 tensors (the model's nn.Parameters) instead of copies, so that an
+        optimizer's in-place updates reach the next ``refresh()``."""
+        self.params = {k: (v.detach() if share and v.dtype == torch.float32 else v.detach().clone().float()) for k, v in sd.items()}
         self._prepared = False
 
     def state_dict(self):
@@ -175,6 +197,11 @@ class WavLMBackbone:
         r = torch.arange(-(self.RB - 1), self.RB, device=dev)
         bucket = relative_buckets(r, self.cfg.get("num_buckets", 320), self.cfg.get("max_distance", 800))
         W["rb"] = emb[bucket].t().contiguous()                                   # [H][2*RB-1], entry r + RB - 1
+        W["rb_bucket"] = bucket
+        W["mask_emb"] = g("mask_emb")
+        W["proj_wT"] = W["proj_w"].t().contiguous()                              # data gradient of post_extract_proj
+        # pos-conv data gradient = the same strided-view GEMM with the kernel flipped: [c][j'*cg + o] = w[o][c][k-1-j']
+        W["pos_wd"] = [w[i * cg:(i + 1) * cg].flip(2).permute(1, 2, 0).reshape(cg, -1).to(bf).contiguous() for i in range(self.gpos)]
         W["layers"] = []
         for i in range(self.n_layers):
             q = f"encoder.layers.{i}."
@@ -187,7 +214,15 @@ class WavLMBackbone:
                 ln1_w=g(q + "self_attn_layer_norm.weight"), ln1_b=g(q + "self_attn_layer_norm.bias"),
                 w1=g(q + "fc1.weight").to(bf), b1=g(q + "fc1.bias"), w2=g(q + "fc2.weight").to(bf), b2=g(q + "fc2.bias"),
                 ln2_w=g(q + "final_layer_norm.weight"), ln2_b=g(q + "final_layer_norm.bias")))
-        self.W = W
+        for Lw_ in W["layers"]:                       # W^T copies: the data gradients are NT GEMMs on them (un-frozen encoder)
+            for n in ("wqkv", "wo", "w1", "w2"):
+                Lw_[n + "T"] = Lw_[n].t().contiguous()
+        old = getattr(self, "W", None)
+        if old is not None and _same_tree(old, W):    # refresh: same addresses, so captured graphs and views stay valid
+            _copy_tree(old, W)
+        else:
+            self.W = W
+            self.graphs.clear()
         self._prepared = True
 
     # ------------------------------------------------------------------ geometry
@@ -223,7 +258,7 @@ class WavLMBackbone:
         ws = dict(T=T, P=P, bufs=bufs, M=M, Tn=Tn, Pp=Pp, wav=torch.empty(B, Lw, device=dev),
                   c0ws=torch.empty(ops.wavlm_conv0_workspace(B, T[0], self.C), device=dev),
                   tmask=torch.zeros(B, Tn, device=dev, dtype=torch.uint8), cmask=torch.zeros(B, d, device=dev, dtype=torch.uint8),
-                  xc=torch.empty(M, self.C, device=dev), h0=torch.empty(M, self.C, device=dev, dtype=bf),
+                  xc=torch.empty(M, self.C, device=dev), mean_in=torch.empty(M, device=dev), rstd_in=torch.empty(M, device=dev), h0=torch.empty(M, self.C, device=dev, dtype=bf),
                   x=torch.empty(M, d, device=dev), xb=torch.empty(M, d, device=dev, dtype=bf),
                   x1=torch.empty(M, d, device=dev), x1b=torch.empty(M, d, device=dev, dtype=bf), y=torch.empty(M, d, device=dev),
                   xg=torch.empty(self.gpos, B * Pp + self.kpos, d // self.gpos, device=dev, dtype=bf),
@@ -236,13 +271,36 @@ class WavLMBackbone:
         self._ws[key] = ws
         return ws
 
+    def _train_buffers(self, ws, B):
+        """Per-layer saved activations + backward scratch of one input shape (allocated on the first training forward)."""
+        if "save" in ws:
+            return ws["save"]
+        dev, bf, d, M, Tn, H = self.device, torch.bfloat16, self.d, ws["M"], ws["Tn"], self.H
+        e = lambda *sh: torch.empty(*sh, device=dev, dtype=bf)
+        f = lambda *sh: torch.empty(*sh, device=dev)
+        ldp = ops.wavlm_attn_ldp(Tn)
+        layers = []
+        for _ in range(self.n_layers):
+            layers.append(dict(xin=f(M, d), xinb=e(M, d), qkv=e(M, 3 * d), gate=f(B, H, Tn), probs=e(B, H, Tn, ldp), o=e(M, d),
+                               y1=f(M, d), mean1=f(M), rstd1=f(M), x1=f(M, d), x1b=e(M, d), pre=e(M, self.ffn), hm=e(M, self.ffn),
+                               y2=f(M, d), mean2=f(M), rstd2=f(M)))
+        Pp = ws["Pp"]
+        sv = dict(layers=layers, y0=f(M, d), mean0=f(M), rstd0=f(M), pcp=e(B * Pp, d),
+                  dxa=f(M, d), dxb=f(M, d), da=f(M, d), dab=e(M, d), dpre=e(M, self.ffn), dx1=f(M, d), db=f(M, d), dbb=e(M, d),
+                  do=e(M, d), dqkv=e(M, 3 * d), dgate=f(B, H, Tn), dsc=f(B, H, Tn, Tn), partial=f(L.LN_BWD_BLOCKS * 2 * d),
+                  dpc=torch.zeros(B * Pp + self.kpos, d, device=dev, dtype=bf), dy0=f(M, d),
+                  dpg=torch.zeros(self.gpos, B * Pp + self.kpos, d // self.gpos, device=dev, dtype=bf), dxp=f(B * Pp, d),
+                  dxc=f(M, self.C))
+        ws["save"] = sv
+        return sv
+
     def _apply_mask(self, ws, B, Tn, Lw, n_samples):
         cfg, dev = self.cfg, self.device
         pad = None
-        if n_samples is not None and min(n_samples) < Lw:          # WavLM.forward_padding_mask: a frame is padding if all of
-            per = Lw // Tn                                          # its Lw // T samples are (the remainder samples are dropped)
-            pm = torch.ones(B, Lw, dtype=torch.bool)
-            for i, n in enumerate(n_samples):
+        if n_samples is not None:       # the model surface ALWAYS hands WavLM a padding mask (lid/WavLMMutiLangModel.py:271-274),
+            per = Lw // Tn              # even when nothing is padded - which changes compute_mask_indices' draw order (one
+            pm = torch.ones(B, Lw, dtype=torch.bool)      # rounding draw per row).  WavLM.forward_padding_mask: a frame is padding
+            for i, n in enumerate(n_samples):             # if all of its Lw // T samples are (remainder samples dropped)
                 pm[i, :n] = False
             pad = pm[:, :per * Tn].view(B, Tn, per).all(-1)
         tmask = cmask = None
@@ -254,9 +312,8 @@ class WavLMBackbone:
             m = span_mask((B, self.d), None, cfg["mask_channel_prob"], cfg.get("mask_channel_length", 10))
             cmask = ws["cmask"]
             cmask.copy_(torch.from_numpy(m.view("uint8")), non_blocking=True)
-        if "mask_emb" not in self.W:
-            self.W["mask_emb"] = self.params["mask_emb"].to(dev).contiguous()
         ops.wavlm_apply_mask(ws["x"], tmask, cmask, self.W["mask_emb"], B, Tn)
+        ws["masked"] = (tmask, cmask)
 
 
     def _fwd_pre(self, ws, B, taps):
@@ -273,13 +330,16 @@ class WavLMBackbone:
         k.scale_cast_2d(last.view(B, P[-1] * C), ws["xc"].view(B, Tn * C), B, Tn * C)       # drop the pitch padding rows
         if taps is not None:
             taps["conv"] = ws["xc"].view(B, Tn, C).clone()
-        k.layernorm_fwd(ws["xc"], W["ln0_w"], W["ln0_b"], yT=ws["h0"])
+        k.layernorm_fwd(ws["xc"], W["ln0_w"], W["ln0_b"], yT=ws["h0"], mean=ws["mean_in"], rstd=ws["rstd_in"])
         k.gemm_nt(ws["h0"], W["proj_w"], ws["x"], bias=W["proj_b"])
         if taps is not None:
             taps["proj"] = ws["x"].view(B, Tn, d).clone()
 
-    def _fwd_post(self, ws, B, taps):
-        """Positional convolution + LayerNorm, transformer layers -> ws["x"]."""
+    def _fwd_post(self, ws, B, taps, save=None):
+        """Positional convolution + LayerNorm, transformer layers -> ws["x"].  ``save``: the training buffers (activations kept
+        for ``backward``); None on the inference / frozen path."""
+        if save is not None:
+            return self._fwd_post_train(ws, B, save)
         W, k = self.W, ops
         Tn, M, Pp, d = ws["Tn"], ws["M"], ws["Pp"], self.d
         # positional convolution + residual + LayerNorm
@@ -307,9 +367,201 @@ class WavLMBackbone:
             if taps is not None:
                 taps[f"layer{i}"] = ws["x"].view(B, Tn, d).clone()
 
+
+    # ------------------------------------------------------------------ training: forward with saved activations, backward
+    def _fwd_post_train(self, ws, B, sv):
+        W, k = self.W, ops
+        Tn, M, Pp, d = ws["Tn"], ws["M"], ws["Pp"], self.d
+        cg = d // self.gpos
+        k.wavlm_posconv_prep(ws["x"], ws["xg"], B, Tn, self.gpos, Pp, self.kpos // 2)
+        for g in range(self.gpos):
+            A = ws["xg"][g].as_strided((B * Pp, self.kpos * cg), (cg, 1))
+            k.gemm_nt(A, W["pos_w"][g], ws["pc"][:, g * cg:(g + 1) * cg], bias=W["pos_b"][g * cg:(g + 1) * cg].contiguous(),
+                      act=L.ACT_GELU, out2=sv["pcp"][:, g * cg:(g + 1) * cg])
+        k.wavlm_add_rows(ws["x"], ws["pc"], sv["y0"], B, Tn, Pp)
+        # LayerDrop (WavLM.py:620-628: one np.random.random() per layer and step; a layer runs when the draw exceeds
+        # encoder_layerdrop): the kept layers are chained through each other's saved-input buffers
+        drop = float(self.cfg.get("encoder_layerdrop", 0.0))
+        active = [i for i in range(self.n_layers) if np.random.random() > drop or drop <= 0.0]
+        sv["active"] = active
+        first = sv["layers"][active[0]] if active else None
+        o32, ob = (first["xin"], first["xinb"]) if first is not None else (ws["x"], ws["xb"])
+        k.layernorm_fwd(sv["y0"], W["enc_ln_w"], W["enc_ln_b"], yT=ob, y32=o32, mean=sv["mean0"], rstd=sv["rstd0"])
+        for n, i in enumerate(active):
+            Lw_, S = W["layers"][i], sv["layers"][i]
+            nxt = sv["layers"][active[n + 1]] if n + 1 < len(active) else None
+            xo32, xob = (nxt["xin"], nxt["xinb"]) if nxt is not None else (ws["x"], ws["xb"])
+            k.gemm_nt(S["xinb"], Lw_["wqkv"], S["qkv"], bias=Lw_["bqkv"])
+            k.wavlm_gate(S["xin"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], S["gate"], B, Tn, self.H, self.dh)
+            k.wavlm_attn_probs(S["qkv"], S["gate"], W["rb"], S["probs"], B, Tn, self.H, self.dh)
+            k.wavlm_attn_fwd(S["qkv"], S["gate"], W["rb"], S["o"], B, Tn, self.H, self.dh)
+            k.gemm_nt(S["o"], Lw_["wo"], S["y1"], bias=Lw_["bo"], res=S["xin"])
+            k.layernorm_fwd(S["y1"], Lw_["ln1_w"], Lw_["ln1_b"], yT=S["x1b"], y32=S["x1"], mean=S["mean1"], rstd=S["rstd1"])
+            k.gemm_nt(S["x1b"], Lw_["w1"], S["hm"], bias=Lw_["b1"], act=L.ACT_GELU, out2=S["pre"])
+            k.gemm_nt(S["hm"], Lw_["w2"], S["y2"], bias=Lw_["b2"], res=S["x1"])
+            k.layernorm_fwd(S["y2"], Lw_["ln2_w"], Lw_["ln2_b"], yT=xob, y32=xo32, mean=S["mean2"], rstd=S["rstd2"])
+
+    TRAINABLE_PREFIX = "encoder."
+    INPUT_SIDE = ("layer_norm.weight", "layer_norm.bias", "mask_emb")      # never frozen by the reference's freeze_* helpers
+
+    def zero_grads(self):
+        if getattr(self, "grads", None):
+            self.grad_flat.zero_()
+
+    def _alloc_grads(self):
+        """f32 gradients of the trainable (encoder) parameters as views into ONE flat arena (``grad_flat``: a single buffer
+        to zero and, under data parallelism, to all-reduce); q/k/v projections share a fused [3d, d] block whose row blocks
+        are the three parameters' gradients."""
+        if getattr(self, "grads", None):
+            return
+        dev, d = self.device, self.d
+        plan, off = [], 0
+
+        def take(name, shape):
+            nonlocal off
+            n = 1
+            for v in shape:
+                n *= v
+            plan.append((name, off, tuple(shape)))
+            off += -(-n // 64) * 64
+
+        fused = (".q_proj.", ".k_proj.", ".v_proj.")
+        for name, t in self.params.items():
+            if (name.startswith(self.TRAINABLE_PREFIX) or name in self.INPUT_SIDE) and not any(f in name for f in fused):
+                take(name, t.shape)
+        for i in range(self.n_layers):
+            take(f"qkv_w.{i}", (3 * d, d))
+            take(f"qkv_b.{i}", (3 * d,))
+        self.grad_flat = torch.zeros(off, device=dev)
+        view = {name: self.grad_flat[o:o + math.prod(shape)].view(shape) for name, o, shape in plan}
+        g = {n: v for n, v in view.items() if not n.startswith("qkv_")}
+        self._gqkv = []
+        for i in range(self.n_layers):
+            a = f"encoder.layers.{i}.self_attn."
+            gw, gb = view[f"qkv_w.{i}"], view[f"qkv_b.{i}"]
+            self._gqkv.append((gw, gb))
+            for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                g[a + n + ".weight"], g[a + n + ".bias"] = gw[j * d:(j + 1) * d], gb[j * d:(j + 1) * d]
+        self._gposw = torch.zeros(self.gpos, d // self.gpos, self.kpos * (d // self.gpos), device=dev)
+        self._drb = torch.zeros(self.H, 2 * self.RB - 1, device=dev)
+        self.grads = g
+
+    @staticmethod
+    def _splitk(n, kk):
+        tiles = -(-n // 64) * -(-kk // 64)
+        return max(1, min(16, round(512 / tiles)))
+
+    def _wgrad(self, dy, x, gw, gb=None):
+        ops.gemm_tn(dy, x, gw, colsum=gb, splitk=self._splitk(gw.shape[0], gw.shape[1]))
+
+    def backward(self, dfeat: torch.Tensor, B: int, Lw: int, wgrads: bool = True):
+        """Backward of the last ``forward(..., train=True)`` of this (B, L) shape from dfeat = d(loss)/d(features) (B, T, d) f32.
+        Accumulates into ``self.grads`` (reference names): always the parameters upstream of the transformer that the reference
+        never freezes (``layer_norm.*`` in front of post_extract_proj and, under span masking, ``mask_emb``); with ``wgrads``
+        (un-frozen encoder) also every ``encoder.*`` parameter.  With wgrads False the chain carries data gradients only."""
+        ws = self._ws[(B, Lw)]
+        sv, W, k = ws["save"], self.W, ops
+        Tn, M, Pp, d, H = ws["Tn"], ws["M"], ws["Pp"], self.d, self.H
+        self._alloc_grads()
+        g, bf = self.grads, torch.bfloat16
+        G = (lambda n: g[n]) if wgrads else (lambda n: None)
+        self._drb.zero_()
+        dx = sv["dxa"]
+        k.scale_cast(dfeat.reshape(M, d).contiguous(), dx, 1.0)
+        for i in reversed(sv["active"]):
+            S, Lw_ = sv["layers"][i], W["layers"][i]
+            q = f"encoder.layers.{i}."
+            a = q + "self_attn."
+            other = sv["dxb"] if dx is sv["dxa"] else sv["dxa"]
+            k.layernorm_bwd(dx, S["y2"], S["mean2"], S["rstd2"], Lw_["ln2_w"], sv["partial"], dx=sv["da"], dxT=sv["dab"],
+                            dgamma=G(q + "final_layer_norm.weight"), dbeta=G(q + "final_layer_norm.bias"), dtype=bf)
+            if wgrads:
+                self._wgrad(sv["dab"], S["hm"], g[q + "fc2.weight"], g[q + "fc2.bias"])
+            k.gemm_nt(sv["dab"], Lw_["w2T"], sv["dpre"], act=L.ACT_GELU_GRAD, aux=S["pre"])
+            if wgrads:
+                self._wgrad(sv["dpre"], S["x1b"], g[q + "fc1.weight"], g[q + "fc1.bias"])
+            k.gemm_nt(sv["dpre"], Lw_["w1T"], sv["dx1"], res=sv["da"])
+            k.layernorm_bwd(sv["dx1"], S["y1"], S["mean1"], S["rstd1"], Lw_["ln1_w"], sv["partial"], dx=sv["db"], dxT=sv["dbb"],
+                            dgamma=G(q + "self_attn_layer_norm.weight"), dbeta=G(q + "self_attn_layer_norm.bias"), dtype=bf)
+            if wgrads:
+                self._wgrad(sv["dbb"], S["o"], g[a + "out_proj.weight"], g[a + "out_proj.bias"])
+            k.gemm_nt(sv["dbb"], Lw_["woT"], sv["do"])
+            k.wavlm_attn_bwd(S["qkv"], S["probs"], sv["do"], S["gate"], W["rb"], sv["dqkv"], sv["dgate"], self._drb, sv["dsc"],
+                             B, Tn, H, self.dh)
+            if wgrads:
+                gw, gb = self._gqkv[i]
+                self._wgrad(sv["dqkv"], S["xinb"], gw, gb)
+            k.gemm_nt(sv["dqkv"], Lw_["wqkvT"], other, res=sv["db"])
+            gp = g if wgrads else self._gate_scratch()
+            k.wavlm_gate_bwd(S["xin"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], sv["dgate"], other, gp[a + "grep_linear.weight"],
+                             gp[a + "grep_linear.bias"], gp[a + "grep_a"].view(-1), B, Tn, H, self.dh)
+            dx = other
+        # encoder.layer_norm, then y0 = x + gelu(pos_conv(x))
+        k.layernorm_bwd(dx, sv["y0"], sv["mean0"], sv["rstd0"], W["enc_ln_w"], sv["partial"], dx=sv["dy0"],
+                        dgamma=G("encoder.layer_norm.weight"), dbeta=G("encoder.layer_norm.bias"), dtype=bf)
+        k.wavlm_posconv_dprep(sv["dy0"], sv["pcp"], sv["dpc"], B, Tn, Pp, dpg=sv["dpg"], goff=self.kpos - 1 - self.kpos // 2)
+        cg = d // self.gpos
+        if wgrads:
+            self._gposw.zero_()
+            for gi in range(self.gpos):
+                A = ws["xg"][gi].as_strided((B * Pp, self.kpos * cg), (cg, 1))
+                X = sv["dpc"][:B * Pp, gi * cg:(gi + 1) * cg]
+                ops.gemm_tn(X, A, self._gposw[gi], colsum=g["encoder.pos_conv.0.bias"][gi * cg:(gi + 1) * cg], splitk=16)
+            self._posconv_weight_grads()
+            # the bias table's gradient back into the bucket embedding (owned by layer 0): emb[bucket(r)][h] += drb[h][r]
+            g["encoder.layers.0.self_attn.relative_attention_bias.weight"].index_add_(0, W["rb_bucket"], self._drb.t().contiguous())
+        # data gradient of the positional convolution (the same strided-view GEMM on the flipped kernel) + the residual path
+        for gi in range(self.gpos):
+            A = sv["dpg"][gi].as_strided((B * Pp, self.kpos * cg), (cg, 1))
+            k.gemm_nt(A, W["pos_wd"][gi], sv["dxp"][:, gi * cg:(gi + 1) * cg])
+        k.wavlm_add_rows(sv["dy0"], sv["dxp"], sv["da"], B, Tn, Pp)            # da = d(loss)/d(x after masking)
+        dxm = sv["da"]
+        if ws.get("masked"):                                                   # WavLM.apply_mask backward (WavLM.py:300-337)
+            tm, cm = ws["masked"]
+            v3 = dxm.view(B, Tn, d)
+            if cm is not None:
+                v3.mul_((cm == 0).to(v3.dtype)[:, None, :])
+            if tm is not None:
+                sel = tm.bool()
+                g["mask_emb"] += (v3 * sel[:, :, None].to(v3.dtype)).sum((0, 1))
+                v3.mul_((~sel)[:, :, None].to(v3.dtype))
+        # post_extract_proj (frozen: data gradient only), then the LayerNorm on the conv features
+        k.scale_cast(dxm, sv["dab"], 1.0)
+        k.gemm_nt(sv["dab"], W["proj_wT"], sv["dxc"])
+        k.layernorm_bwd(sv["dxc"], ws["xc"], ws["mean_in"], ws["rstd_in"], W["ln0_w"], sv["partial"],
+                        dx=sv["db"].view(-1)[:M * self.C].view(M, self.C),      # (unused: the conv extractor below is frozen)
+                        dgamma=g["layer_norm.weight"], dbeta=g["layer_norm.bias"], dtype=bf)
+
+    def _gate_scratch(self):
+        """Throw-away targets for the gate's parameter gradients while the encoder is frozen (data gradients only)."""
+        if getattr(self, "_gscratch", None) is None:
+            dev = self.device
+            t = dict(w=torch.zeros(8, self.dh, device=dev), b=torch.zeros(8, device=dev), a=torch.zeros(self.H, device=dev))
+
+            class _D(dict):
+                def __missing__(self_, key):
+                    return t["w"] if key.endswith("grep_linear.weight") else t["b"] if key.endswith("grep_linear.bias") else t["a"]
+            self._gscratch = _D()
+        return self._gscratch
+
+    def _posconv_weight_grads(self):
+        """Gradient of the effective weight w = g * v / ||v|| (weight_norm, dim = 2) back to weight_g / weight_v: a few
+        element-wise passes over 4.7 M values (torch ops on the device: parameter bookkeeping, not the hot path)."""
+        cg = self.d // self.gpos
+        dw = self._gposw.view(self.gpos, cg, self.kpos, cg).permute(0, 1, 3, 2).reshape(self.d, cg, self.kpos)   # [o][c][j]
+        v, gg = self.params["encoder.pos_conv.0.weight_v"].to(self.device), self.params["encoder.pos_conv.0.weight_g"].to(self.device)
+        norm = v.pow(2).sum((0, 1), keepdim=True).sqrt()
+        dot = (dw * v).sum((0, 1), keepdim=True)
+        self.grads["encoder.pos_conv.0.weight_g"] += dot / norm
+        self.grads["encoder.pos_conv.0.weight_v"] += gg / norm * (dw - v * dot / norm.pow(2))
+
+    def refresh(self):
+        """Re-derive the bf16 operands after the optimizer changed the (encoder) parameters (in place)."""
+        self._prepared = False
+
     # ------------------------------------------------------------------ forward
     def forward(self, wav: torch.Tensor, taps: Dict[str, torch.Tensor] = None, mask: bool = False,
-                n_samples: List[int] = None) -> torch.Tensor:
+                n_samples: List[int] = None, train: bool = False) -> torch.Tensor:
         """wav (B, L) f32 on the GPU -> (B, T, d) f32.  ``taps`` (tests): receives copies of the stage outputs.
         mask=True (training, WavLM.apply_mask): spans of the projected features are replaced by ``mask_emb`` / zeroed channels
         with cfg mask_prob / mask_channel_prob; n_samples (true lengths of a zero-padded batch) only shapes the padding mask
@@ -324,7 +576,13 @@ class WavLMBackbone:
         Tn, d = ws["Tn"], self.d
         ws["wav"].copy_(wav)                                  # static input buffer: captured launches see one address
         masking = mask and (self.cfg.get("mask_prob", 0.0) > 0 or self.cfg.get("mask_channel_prob", 0.0) > 0)
-        if taps is not None:                                  # tests: eager, with copies of the stage outputs
+        ws["masked"] = None
+        if train:                                             # un-frozen encoder: keep what backward needs (eager launches)
+            self.graphs.run(("pre", B, Lw), lambda: self._fwd_pre(ws, B, None))
+            if masking:
+                self._apply_mask(ws, B, Tn, Lw, n_samples)
+            self._fwd_post_train(ws, B, self._train_buffers(ws, B))
+        elif taps is not None:                                # tests: eager, with copies of the stage outputs
             self._fwd_pre(ws, B, taps)
             if masking:
                 self._apply_mask(ws, B, Tn, Lw, n_samples)

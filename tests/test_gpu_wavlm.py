@@ -121,11 +121,11 @@ def test_backbone_forward_stages_against_the_reference():
     assert out2.shape == (1, 37, 768) and bool(torch.isfinite(out2).all())
 
 
-def _model(dt=torch.bfloat16, dropout=0.0):
+def _model(dt=torch.bfloat16, dropout=0.0, cfg=wc.CFG, mask=False, **kw):
     from lid.WavLMMutiLangModel import WavLMMutiLangModel
-    m = WavLMMutiLangModel(dropout=dropout, linear_dim=768, mask=False, lang2vocab=wc.L2V, lang2index=wc.L2I,
+    m = WavLMMutiLangModel(dropout=dropout, linear_dim=768, mask=mask, **kw, lang2vocab=wc.L2V, lang2index=wc.L2I,
                            hidden_dim=wc.HEAD["hidden_dim"], conformer_linear=True, dim_head=wc.HEAD["dim_head"],
-                           num_head=wc.HEAD["num_head"], wavlm_cfg=wc.CFG, compute_dtype=dt)
+                           num_head=wc.HEAD["num_head"], wavlm_cfg=cfg, compute_dtype=dt)
     sd = {"model.featurizer.model." + k: v for k, v in wc.backbone_weights().items()}
     sd.update(wc.head_weights())
     sd["data_processor.resampler22k.kernel"] = torch.zeros(1, 1, 3)          # a reference checkpoint carries these: ignored
@@ -199,6 +199,108 @@ def test_head_training_step_on_frozen_backbone_against_the_reference(dt):
             bad.append((name, round(cos, 5), round(nrel, 4)))
     print(f"[wavlm head step {dt}] {len(g['grad_names'])} gradient tensors: worst sampled cosine {worst_cos:.5f}, worst norm rel err {worst_n:.3e}")
     assert not bad, bad[:8]
+
+
+def _cmp_grads(g, grad_of, tag, cos_min=0.99, nrel_max=0.08, skip=()):
+    big = float(g["grad_norms"].max())
+    worst_cos, worst_n, bad, n = 1.0, 0.0, [], 0
+    for name, ref_norm in zip(g["grad_names"], g["grad_norms"]):
+        name = str(name)
+        if ref_norm < 1e-6 * big or name in skip:
+            continue
+        got = grad_of(name)
+        assert got is not None, f"{name}: no gradient"
+        got = got.reshape(-1)
+        idx = (torch.randperm(got.numel(), generator=torch.Generator().manual_seed(wc._seed(name)))[:2048].sort().values
+               if got.numel() > 2048 else torch.arange(got.numel()))
+        gs, rs = got[idx.to(got.device)].cpu().double(), torch.from_numpy(g["gs::" + name]).double()
+        cos = float((gs @ rs) / (gs.norm() * rs.norm() + 1e-300))
+        nrel = abs(float(got.double().norm()) - ref_norm) / ref_norm
+        worst_cos, worst_n, n = min(worst_cos, cos), max(worst_n, nrel), n + 1
+        if cos < cos_min or nrel > nrel_max:
+            bad.append((name, round(cos, 5), round(nrel, 4)))
+    print(f"[{tag}] {n} gradient tensors: worst sampled cosine {worst_cos:.5f}, worst norm rel err {worst_n:.3e}")
+    assert not bad, bad[:10]
+    return n
+
+
+def test_finetune_step_with_unfrozen_encoder_against_the_reference():
+    """One training-mode step with the transformer encoder UN-frozen through the model surface (forward, CtcLossFn, .backward()):
+    logits, loss and the gradient of every encoder parameter (pos-conv weight_g / weight_v / bias, encoder LayerNorm, q/k/v/out
+    projections, GRU gate, bucket embedding, FFN, LayerNorms) and every head parameter against the reference's autograd
+    (tests/golden/wavlm_finetune.npz).  bf16 operands with f32 accumulation on this side, f32 on the reference's."""
+    from lid.ConformerLangModel import CtcLossFn
+    g = load_npz("wavlm_finetune.npz")
+    m = _model(cfg=wc.CFG_TRAIN)
+    m.train()
+    m.freeze_feature_extractor()
+    m.unfreeze_tranformer_encoder()
+    wav = wc.waveforms().to(DEV)
+    texts = wc.texts().to(DEV)
+    m.zero_grad()
+    logits, _ = m([wav[i] for i in range(wav.shape[0])], 16000, "b")
+    z = logits["b"]
+    B, T, _ = z.shape
+    per = CtcLossFn.apply(z, texts, torch.full((B,), T, device=DEV, dtype=torch.long),
+                          torch.full((B,), texts.shape[1], device=DEV, dtype=torch.long), 40, m.lidk_engine.k)
+    per.mean().backward()
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(g["train_logits_b"])
+    lerr, loss, ref_loss = float((z.detach().cpu() - ref).abs().max()), float(per.mean().detach()), float(g["train_loss"])
+    print(f"[wavlm finetune step] logits err {lerr:.3e} (max |ref| {float(ref.abs().max()):.2f}); loss {loss:.4f} vs {ref_loss:.4f}")
+    assert lerr <= 4e-2 * max(1.0, float(ref.abs().max())) and abs(loss - ref_loss) <= 2e-2 * ref_loss
+    params = dict(m.named_parameters())
+    n = _cmp_grads(g, lambda name: params[name].grad, "wavlm finetune step")
+    assert n >= 70
+    # a second step accumulates from zero again (zero_grad(set_to_none) -> the backbone arena is re-zeroed)
+    first = params["model.featurizer.model.encoder.layers.1.fc1.weight"].grad.clone()
+    m.zero_grad()
+    logits, _ = m([wav[i] for i in range(wav.shape[0])], 16000, "b")
+    per = CtcLossFn.apply(logits["b"], texts, torch.full((B,), T, device=DEV, dtype=torch.long),
+                          torch.full((B,), texts.shape[1], device=DEV, dtype=torch.long), 40, m.lidk_engine.k)
+    per.mean().backward()
+    again = params["model.featurizer.model.encoder.layers.1.fc1.weight"].grad
+    assert float((again - first).abs().max()) <= 1e-3 * float(first.abs().max())
+
+
+def test_frozen_masked_step_trains_layer_norm_and_mask_emb_like_the_reference():
+    """The reference's default first-epoch regime: extractor + encoder frozen, span masking on.  Its freeze_* helpers leave
+    WavLM's layer_norm and mask_emb trainable, so the gradient runs back through the whole frozen transformer, the positional
+    convolution, the mask and post_extract_proj.  Same numpy seed -> same spans; logits, loss and the gradients of the heads,
+    layer_norm.{weight,bias} and mask_emb against the reference's autograd (tests/golden/wavlm_frozen_masked.npz)."""
+    from lid.ConformerLangModel import CtcLossFn
+    g = load_npz("wavlm_frozen_masked.npz")
+    m = _model(cfg=wc.CFG_TRAIN, mask=True, mask_prob=wc.MASK_PROB, mask_channel_prob=wc.MASK_CHANNEL_PROB)
+    m.train()
+    m.freeze_feature_extractor()
+    m.freeze_tranformer_encoder()
+    wav, texts = wc.waveforms().to(DEV), wc.texts().to(DEV)
+    m.zero_grad()
+    np.random.seed(wc.MASK_SEED)
+    logits, _ = m([wav[i] for i in range(wav.shape[0])], 16000, "b")
+    z = logits["b"]
+    B, T, _ = z.shape
+    per = CtcLossFn.apply(z, texts, torch.full((B,), T, device=DEV, dtype=torch.long),
+                          torch.full((B,), texts.shape[1], device=DEV, dtype=torch.long), 40, m.lidk_engine.k)
+    per.mean().backward()
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(g["train_logits_b"])
+    lerr, loss, ref_loss = float((z.detach().cpu() - ref).abs().max()), float(per.mean().detach()), float(g["train_loss"])
+    print(f"[wavlm frozen masked step] logits err {lerr:.3e} (max |ref| {float(ref.abs().max()):.2f}); loss {loss:.4f} vs {ref_loss:.4f}")
+    assert lerr <= 4e-2 * max(1.0, float(ref.abs().max())) and abs(loss - ref_loss) <= 2e-2 * ref_loss
+    params = dict(m.named_parameters())
+    assert _cmp_grads(g, lambda name: params[name].grad, "wavlm frozen masked step") >= 30
+    assert all(p.grad is None for n, p in params.items() if ".encoder." in n)           # frozen: no gradient published
+    # train_input_norm=False: the gradient stops at the features (graph-replayed backbone, nothing saved)
+    m2 = _model(cfg=wc.CFG_TRAIN, train_input_norm=False)
+    m2.train()
+    logits, _ = m2([wav[i] for i in range(wav.shape[0])], 16000, "b")
+    per = CtcLossFn.apply(logits["b"], texts, torch.full((B,), T, device=DEV, dtype=torch.long),
+                          torch.full((B,), texts.shape[1], device=DEV, dtype=torch.long), 40, m2.lidk_engine.k)
+    per.mean().backward()
+    p2 = dict(m2.named_parameters())
+    assert all(p.grad is None for n, p in p2.items() if n.startswith("model.featurizer."))
+    assert p2["model.last_projects.b.linear.weight"].grad is not None
 
 
 def test_trainer_fit_wavlm_frozen_backbone(tmp_path, monkeypatch):

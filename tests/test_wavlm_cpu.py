@@ -50,8 +50,15 @@ def test_wavlm_model_state_dict_names_and_module_surface():
     assert mod.model.backbone.cfg["mask_prob"] == 0.15 and mod.model.backbone.cfg["mask_channel_prob"] == 0.15
     assert set(WavLMBackbone.param_shapes(wc.CFG)) == set(wc.backbone_shapes(2))
     trainable = [n for n, p in mod.model.named_parameters() if p.requires_grad]
-    assert trainable and not any(n.startswith("model.featurizer.") for n in trainable)          # frozen backbone
+    # "frozen" backbone = what the reference's freeze_* helpers leave trainable: WavLM's layer_norm + mask_emb (never frozen)
+    assert {n for n in trainable if n.startswith("model.featurizer.")} == {
+        "model.featurizer.model." + k for k in ("layer_norm.weight", "layer_norm.bias", "mask_emb")}
+    mod.model.unfreeze_tranformer_encoder()                      # lid/WavLMMutiLangModel.py:106-112: exactly the encoder.* parameters
+    now = {n for n, p in mod.model.named_parameters() if p.requires_grad} - set(trainable)
+    assert now == {"model.featurizer.model." + k for k in WavLMBackbone.param_shapes(wc.CFG) if k.startswith("encoder.")}
+    mod.model.freeze_tranformer_encoder()
+    assert [n for n, p in mod.model.named_parameters() if p.requires_grad] == trainable
     with pytest.raises(NotImplementedError):
-        mod.model.unfreeze_tranformer_encoder()
+        mod.model.unfreeze_feature_extractor()
     with pytest.raises(NotImplementedError):
         LidModule(lang2vocab=wc.L2V, lang2index_dict=wc.L2I, tokenizer_dict=toks, use_wav2vec=True, conformer_linear=True)

@@ -11,6 +11,10 @@ CFG = dict(encoder_layers=2, encoder_embed_dim=768, encoder_ffn_embed_dim=3072, 
            conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2", conv_pos=128, conv_pos_groups=16,
            relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True, layer_norm_first=False,
            extractor_mode="default", conv_bias=False, mask_prob=0.0, mask_channel_prob=0.0)
+# fine-tuning fixtures: the same model with every dropout and LayerDrop switched off, so a training-mode step is deterministic
+CFG_TRAIN = dict(CFG, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0, dropout_features=0.0,
+                 encoder_layerdrop=0.0)
+MASK_PROB, MASK_CHANNEL_PROB, MASK_SEED = 0.3, 0.2, 5           # the span-masked frozen-regime fixture (numpy seed before the step)
 L2V = {"a": 30, "b": 40, "c": 50}
 L2I = {"a": 0, "b": 1, "c": 2}
 HEAD = dict(dim_head=32, num_head=8, linear_dim=768, hidden_dim=32)
