@@ -68,12 +68,15 @@ def build(args, rank, world, device):
     global N_LANGS
     if args.model == "wavlm":
         ov = [o for o in ov if not o.startswith(("model.n_blocks", "trainer.total_epoch", "module.optimizer_param.lr"))] + ["trainer.total_epoch=1000",
-              f"model.wavlm_cfg.encoder_layers={args.blocks}", "data.synthetic.seconds=3.0"]
+              f"model.wavlm_cfg.encoder_layers={args.blocks}", "data.synthetic.seconds=3.0",
+              f"+module.train_input_norm={'false' if args.wavlm_regime == 'heads' else 'true'}"]
     cfg = hydra_lite.load_config(os.path.join(ROOT, "speech-lid_amd", "lid", "conf"),
                                  "synthetic_cfg2" if args.model == "conformer" else "synthetic_wavlm", ov)
     N_LANGS = len(cfg["data"]["langs"])
     module, sets, params = launcher.build(cfg, rank, world)
     module.model.use_stochastic_depth = bool(args.stochastic_depth)
+    if args.model == "wavlm" and args.wavlm_regime == "finetune":
+        module.model.unfreeze_tranformer_encoder()
     trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
     trainer.ccml_module = module
     trainer.train_dataset, trainer.val_dataset, trainer.test_dataset = sets["train"], sets["val"], sets["test"]
@@ -501,6 +504,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", choices=["conformer", "wavlm"], default="conformer",
                     help="conformer = BASELINE configs[1] (the headline); wavlm = configs[3]: WavLM-base backbone (frozen) + heads")
+    ap.add_argument("--wavlm-regime", choices=["heads", "frozen", "finetune"], default="frozen",
+                    help="heads = gradient stops at the features (train_input_norm=false: backbone = 2 graphs); frozen = the "
+                         "reference's first-epoch regime (encoder frozen, layer_norm + mask_emb train: data gradients through the "
+                         "transformer); finetune = transformer encoder un-frozen (after freeze_tranformer_epoch)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -615,9 +622,13 @@ def main():
         audio_s = world * args.batch * SECONDS * args.steps
         med = sorted(chunk_ms)[len(chunk_ms) // 2]
         if args.model == "wavlm":
-            metric = "audio-seconds/sec LID training, WavLM-base backbone (frozen) + Conformer heads"
+            regime = {"heads": "backbone forward only (gradient stops at the features)",
+                      "frozen": "encoder frozen as in the reference's first epochs: data gradients through the transformer to "
+                                "layer_norm + mask_emb",
+                      "finetune": "transformer encoder un-frozen: full encoder backward + Adam on it"}[args.wavlm_regime]
+            metric = f"audio-seconds/sec LID training, WavLM-base backbone ({args.wavlm_regime}) + Conformer heads"
             workload = (f"WavLMMutiLangModel: WavLM-base width backbone ({args.blocks} transformer layers, conv extractor on raw "
-                        f"3 s@16 kHz waveforms, forward only = frozen, span masking on) + {N_LANGS} Conformer CTC heads d768 "
+                        f"3 s@16 kHz waveforms, span masking on; {regime}) + {N_LANGS} Conformer CTC heads d768 "
                         f"(forward + backward), Adam, batch={args.batch}/GPU")
         else:
             metric = "audio-seconds/sec LID training, Conformer d256"

@@ -44,6 +44,21 @@ def _lookahead(iterable):
         cur = nxt
 
 
+def _cpu_quota() -> int:
+    """Cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (0 = unknown)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 0
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 class Trainer:
     def __init__(self, total_epoch: int = 0, world_size: int = 1, local_rank: int = -1, accumulate_grad: int = 1,
                  eval_interval: int = 1, train_data_factor: float = 1.0, ddp: bool = False, backend: str = "gloo",
@@ -67,6 +82,11 @@ class Trainer:
         self.device = torch.device(f"cuda:{gpu_id}") if gpu_id is not None else torch.device("cpu")
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
+            # Host-side torch ops (collate, masks) must not fan out over more threads than the container's CPU quota: a
+            # throttled OpenMP team stalls the launch thread for tens of milliseconds per step.
+            quota = _cpu_quota()
+            if quota and torch.get_num_threads() > quota:
+                torch.set_num_threads(quota)
         if ddp:
             self._init_process_group(backend, init_method, master_addr, str(master_port))
             self.local_rank, self.world_size = dist.get_rank(), dist.get_world_size()

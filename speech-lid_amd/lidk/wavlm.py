@@ -60,7 +60,7 @@ def span_mask(shape, padding_mask, mask_prob: float, mask_length: int, min_masks
     rows = []
     for i in range(bsz):
         if padding_mask is not None:
-            sz = all_sz - int(padding_mask[i].long().sum().item())
+            sz = all_sz - int(np.asarray(padding_mask[i]).sum())
             num = max(min_masks, int(mask_prob * sz / float(mask_length) + rng.rand()))
         else:
             sz, num = all_sz, all_num
@@ -298,23 +298,39 @@ class WavLMBackbone:
         cfg, dev = self.cfg, self.device
         pad = None
         if n_samples is not None:       # the model surface ALWAYS hands WavLM a padding mask (lid/WavLMMutiLangModel.py:271-274),
-            per = Lw // Tn              # even when nothing is padded - which changes compute_mask_indices' draw order (one
-            pm = torch.ones(B, Lw, dtype=torch.bool)      # rounding draw per row).  WavLM.forward_padding_mask: a frame is padding
-            for i, n in enumerate(n_samples):             # if all of its Lw // T samples are (remainder samples dropped)
-                pm[i, :n] = False
-            pad = pm[:, :per * Tn].view(B, Tn, per).all(-1)
+            # even when nothing is padded - which changes compute_mask_indices' draw order (one rounding draw per row).
+            # WavLM.forward_padding_mask: a frame is padding if all of its Lw // T samples are (remainder samples dropped), i.e.
+            # frame t of an utterance of n samples is padding iff t * per >= n.  (Closed form: no (B, Lw) host tensor per step.)
+            per = Lw // Tn
+            first_pad = -(-np.asarray(n_samples, dtype=np.int64) // per)
+            pad = np.arange(Tn)[None, :] >= first_pad[:, None]
         tmask = cmask = None
         if cfg.get("mask_prob", 0.0) > 0:
             m = span_mask((B, Tn), pad, cfg["mask_prob"], cfg.get("mask_length", 10), min_masks=2)
-            tmask = ws["tmask"]
-            tmask.copy_(torch.from_numpy(m.view("uint8")), non_blocking=True)
+            tmask = self._upload_mask(ws, "tmask", m)
         if cfg.get("mask_channel_prob", 0.0) > 0:
             m = span_mask((B, self.d), None, cfg["mask_channel_prob"], cfg.get("mask_channel_length", 10))
-            cmask = ws["cmask"]
-            cmask.copy_(torch.from_numpy(m.view("uint8")), non_blocking=True)
+            cmask = self._upload_mask(ws, "cmask", m)
         ops.wavlm_apply_mask(ws["x"], tmask, cmask, self.W["mask_emb"], B, Tn)
         ws["masked"] = (tmask, cmask)
 
+    @staticmethod
+    def _upload_mask(ws, name, m):
+        """Host-drawn spans -> the device mask through one of two PINNED staging buffers (a copy from pageable memory would
+        block the host until the stream drains); a buffer is reused two steps later, after its copy's event has passed."""
+        dst = ws[name]
+        st = ws.setdefault(name + "_stage", dict(bufs=[torch.empty(dst.shape, dtype=torch.uint8).pin_memory() for _ in range(2)],
+                                                 events=[None, None], turn=0))
+        i = st["turn"]
+        st["turn"] = 1 - i
+        if st["events"][i] is not None:
+            st["events"][i].synchronize()
+        st["bufs"][i].numpy()[...] = m.view("uint8")
+        dst.copy_(st["bufs"][i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["events"][i] = ev
+        return dst
 
     def _fwd_pre(self, ws, B, taps):
         """Feature extractor, LayerNorm, post_extract_proj -> ws["x"] (B*T, d) f32."""

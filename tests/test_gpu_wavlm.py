@@ -337,3 +337,40 @@ def test_trainer_fit_wavlm_frozen_backbone(tmp_path, monkeypatch):
     sd = torch.load("ckpt/last.pt", weights_only=False)["model"]
     assert torch.equal(sd["model.featurizer.model.encoder.layers.0.fc1.weight"].cpu(), bb0.cpu())      # frozen
     assert all(torch.isfinite(v.float()).all() for v in sd.values())
+
+
+def test_trainer_fit_unfreezes_the_encoder_after_freeze_tranformer_epoch(tmp_path, monkeypatch):
+    """The reference's schedule (lid/LidModule_ASR.py:282-295): epoch <= freeze_tranformer_epoch trains heads (+ layer_norm /
+    mask_emb), later epochs also the transformer encoder.  After fit: encoder weights moved, the conv extractor did not, and the
+    backbone's bf16 operands follow the optimizer (eval logits change with the parameters, and stay finite)."""
+    import os
+    from conftest import PKG
+    from ccml import seed_everything
+    from ccml.trainer import Trainer
+    from lid import hydra_lite
+    import lid.main as launcher
+    monkeypatch.chdir(tmp_path)
+    seed_everything(0)
+    cfg = hydra_lite.load_config(os.path.join(PKG, "lid", "conf"), "synthetic_wavlm",
+                                 ["model.wavlm_cfg.encoder_layers=2", "data.synthetic.items_per_lang=16", "data.synthetic.seconds=1.0",
+                                  "data.synthetic.text_len=8", "+data.synthetic.min_seconds=0.6", "data.sampler_common.train_batch_size=8",
+                                  "module.optimizer_param.lr=0.0005", "trainer.total_epoch=2", "module.freeze_tranformer_epoch=0"])
+    module, sets, params = launcher.build(cfg)
+    trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
+    sd0 = {k: v.clone() for k, v in module.model.state_dict().items() if k.startswith("model.featurizer.")}
+    trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=params)
+    sd1 = module.model.state_dict()
+    moved = lambda k: float((sd1["model.featurizer.model." + k].cpu() - sd0["model.featurizer.model." + k].cpu()).abs().max())
+    assert moved("encoder.layers.0.fc1.weight") > 0 and moved("encoder.layers.1.self_attn.q_proj.weight") > 0
+    assert moved("encoder.pos_conv.0.weight_v") > 0 and moved("encoder.layers.0.self_attn.relative_attention_bias.weight") > 0
+    assert moved("layer_norm.weight") > 0 and moved("mask_emb") > 0
+    assert moved("feature_extractor.conv_layers.3.0.weight") == 0 and moved("post_extract_proj.weight") == 0
+    assert all(torch.isfinite(v.float()).all() for v in sd1.values()) and np.isfinite(module.last_val["val_loss"])
+    # the GEMM operands were re-derived from the updated parameters
+    bb = module.model.backbone
+    i = 0
+    want = torch.cat([sd1[f"model.featurizer.model.encoder.layers.{i}.self_attn.{n}_proj.weight"] for n in "qkv"]).to(torch.bfloat16)
+    module.model.eval()
+    with torch.no_grad():
+        module.model([torch.as_tensor(sets["val"][0][0]).float().reshape(-1).to(DEV)], 16000, None)
+    assert torch.equal(bb.W["layers"][0]["wqkv"], want.to(DEV))

@@ -62,3 +62,18 @@ def test_wavlm_model_state_dict_names_and_module_surface():
         mod.model.unfreeze_feature_extractor()
     with pytest.raises(NotImplementedError):
         LidModule(lang2vocab=wc.L2V, lang2index_dict=wc.L2I, tokenizer_dict=toks, use_wav2vec=True, conformer_linear=True)
+
+
+def test_padding_frames_closed_form_equals_forward_padding_mask():
+    """WavLM.forward_padding_mask (lid/wavlm/WavLM.py:290-296) over the model's (B, L) sample mask against the closed form the
+    backbone uses per step (frame t of an n-sample utterance is padding iff t * (L // T) >= n)."""
+    rng = np.random.default_rng(0)
+    for Lw, Tn in ((48000, 149), (16000, 49), (12345, 38)):
+        n = np.concatenate([rng.integers(400, Lw + 1, size=9), [Lw]])
+        per = Lw // Tn
+        pm = torch.ones(len(n), Lw, dtype=torch.bool)
+        for i, v in enumerate(n):
+            pm[i, :v] = False
+        brute = pm[:, :per * Tn].view(len(n), Tn, per).all(-1).numpy()
+        closed = np.arange(Tn)[None, :] >= (-(-n.astype(np.int64) // per))[:, None]
+        assert (brute == closed).all()

@@ -20,9 +20,10 @@ def main():
     ap.add_argument("--model", default="conformer")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--wavlm-regime", default="frozen")
     a = ap.parse_args()
     args = argparse.Namespace(model=a.model, batch=a.batch, resident=1, val_items=2, blocks=12, lr=0.01, stochastic_depth=False,
-                              warmup=0, steps=a.steps, cavg_steps=0)
+                              warmup=0, steps=a.steps, cavg_steps=0, wavlm_regime=a.wavlm_regime)
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     cfg, module, trainer, sets = bench.build(args, 0, 1, dev)
