@@ -537,65 +537,66 @@ extern "C" int lidk_wavlm_attn_bwd(const void* qkv, const void* probs, const voi
 }
 
 // ------------------------------------------------------------------------------------ gate backward
-// dgate [B][H][T] -> dx[m][h*dh + d] += sum_q du[q] wg[q][d] ; dwg [8][dh], dbg [8], dgrep_a [H] accumulated (workgroup-level
-// reduction in LDS, then one atomic per element per workgroup).
+// dgate [B][H][T] -> dx[m][h*dh + d] += sum_q du[q] wg[q][d] ; dwg [8][dh], dbg [8], dgrep_a [H] accumulated.
+// One wave per (m, h) row, lane = channel d (dh <= 64): the 8 projections collapse to two (rows 0-3 feed gate a, rows 4-7 gate b,
+// and du is the same within each group), so a lane carries two weight sums and two dW accumulators; per workgroup the four
+// waves' accumulators meet in LDS and leave through one atomic per element.
 __global__ void __launch_bounds__(256)
 wavlm_gate_bwd_kernel(const float* __restrict__ x, const float* __restrict__ wg, const float* __restrict__ bg,
                       const float* __restrict__ grep_a, const float* __restrict__ dgate, float* __restrict__ dx,
                       float* __restrict__ dwg, float* __restrict__ dbg, float* __restrict__ dgrep_a, int B, int T_, int H, int dh) {
-  extern __shared__ float red[];                       // [8*dh] dwg | [8] dbg | [H] dgrep_a
-  const int nred = 8 * dh + 8 + H;
-  for (int i = threadIdx.x; i < nred; i += blockDim.x) red[i] = 0.f;
+  extern __shared__ float red[];                       // [4][2][64] dW partials | [2] db | [H] dgrep_a
+  float* red_a = red + 4 * 2 * 64 + 2;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < H + 2; i += blockDim.x) red[4 * 2 * 64 + i] = 0.f;
   __syncthreads();
+  float wsa = 0.f, wsb = 0.f;
+  if (lane < dh) {
+    wsa = wg[lane] + wg[dh + lane] + wg[2 * dh + lane] + wg[3 * dh + lane];
+    wsb = wg[4 * dh + lane] + wg[5 * dh + lane] + wg[6 * dh + lane] + wg[7 * dh + lane];
+  }
+  const float ba = bg[0] + bg[1] + bg[2] + bg[3], bb = bg[4] + bg[5] + bg[6] + bg[7];
+  float acc_wa = 0.f, acc_wb = 0.f, acc_ba = 0.f, acc_bb = 0.f;
   const long n = (long)B * T_ * H;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)blockIdx.x * 4 + wv; i < n; i += (long)gridDim.x * 4) {
     const int h = (int)(i % H); const long m = i / H;
     const long b = m / T_, t = m % T_;
-    const float* xr = x + m * (long)H * dh + (long)h * dh;
-    float u[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) u[q] = bg[q];
-    for (int d = 0; d < dh; ++d) {
-      const float v = xr[d];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) u[q] = fmaf(wg[q * dh + d], v, u[q]);
-    }
-    const float ga = 1.f / (1.f + __expf(-(u[0] + u[1] + u[2] + u[3])));
-    const float gb = 1.f / (1.f + __expf(-(u[4] + u[5] + u[6] + u[7])));
+    const long off = m * (long)H * dh + (long)h * dh + lane;
+    const float v = lane < dh ? x[off] : 0.f;
+    const float ua = wave_sum(v * wsa) + ba, ub = wave_sum(v * wsb) + bb;
+    const float ga = 1.f / (1.f + __expf(-ua)), gb = 1.f / (1.f + __expf(-ub));
     const float a = grep_a[h], dgt = dgate[(b * H + h) * T_ + t];
     const float dsa = dgt * (gb * a - 1.f) * ga * (1.f - ga), dsb = dgt * ga * a * gb * (1.f - gb);
-    atomicAdd(&red[8 * dh + 8 + h], dgt * ga * gb);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) atomicAdd(&red[8 * dh + q], q < 4 ? dsa : dsb);
-    float* dxr = dx + m * (long)H * dh + (long)h * dh;
-    for (int d = 0; d < dh; ++d) {
-      const float v = xr[d];
-      float acc = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float du = q < 4 ? dsa : dsb;
-        acc = fmaf(du, wg[q * dh + d], acc);
-        atomicAdd(&red[q * dh + d], du * v);
-      }
-      dxr[d] += acc;
-    }
+    if (lane < dh) dx[off] += dsa * wsa + dsb * wsb;
+    acc_wa = fmaf(dsa, v, acc_wa); acc_wb = fmaf(dsb, v, acc_wb);
+    acc_ba += dsa; acc_bb += dsb;
+    if (lane == 0) atomicAdd(&red_a[h], dgt * ga * gb);
   }
+  red[(wv * 2 + 0) * 64 + lane] = acc_wa;
+  red[(wv * 2 + 1) * 64 + lane] = acc_wb;
+  if (lane == 0) { atomicAdd(&red[4 * 2 * 64 + 0], acc_ba); atomicAdd(&red[4 * 2 * 64 + 1], acc_bb); }
   __syncthreads();
-  for (int i = threadIdx.x; i < nred; i += blockDim.x) {
-    const float v = red[i];
-    if (v == 0.f) continue;
-    if (i < 8 * dh) atomicAdd(&dwg[i], v);
-    else if (i < 8 * dh + 8) atomicAdd(&dbg[i - 8 * dh], v);
-    else atomicAdd(&dgrep_a[i - 8 * dh - 8], v);
+  if (threadIdx.x < 128) {                             // thread = (group g, channel d): rows 4g .. 4g+3 of dwg share the value
+    const int g = threadIdx.x >> 6, d = threadIdx.x & 63;
+    const float v = red[(0 * 2 + g) * 64 + d] + red[(1 * 2 + g) * 64 + d] + red[(2 * 2 + g) * 64 + d] + red[(3 * 2 + g) * 64 + d];
+    if (d < dh && v != 0.f)
+      for (int q = 0; q < 4; ++q) atomicAdd(&dwg[(4 * g + q) * dh + d], v);
+  } else if (threadIdx.x < 136) {
+    const int q = threadIdx.x - 128;
+    const float v = red[4 * 2 * 64 + (q >> 2)];
+    if (v != 0.f) atomicAdd(&dbg[q], v);
   }
+  for (int i = threadIdx.x; i < H; i += blockDim.x)
+    if (red_a[i] != 0.f) atomicAdd(&dgrep_a[i], red_a[i]);
 }
 extern "C" int lidk_wavlm_gate_bwd(const float* x, const float* wg, const float* bg, const float* grep_a, const float* dgate, float* dx,
                                    float* dwg, float* dbg, float* dgrep_a, int B, int T_, int H, int dh, void* stream) {
-  if (!x || !wg || !bg || !grep_a || !dgate || !dx || !dwg || !dbg || !dgrep_a || B <= 0 || T_ <= 0 || H <= 0 || dh <= 0) return LIDK_ERR_ARG;
+  if (!x || !wg || !bg || !grep_a || !dgate || !dx || !dwg || !dbg || !dgrep_a || B <= 0 || T_ <= 0 || H <= 0 || dh <= 0 || dh > 64)
+    return LIDK_ERR_ARG;
   const long n = (long)B * T_ * H;
-  int blocks = (int)((n + 255) / 256); if (blocks > 1024) blocks = 1024;
-  wavlm_gate_bwd_kernel<<<blocks, 256, (size_t)(8 * dh + 8 + H) * 4, as_stream(stream)>>>(x, wg, bg, grep_a, dgate, dx, dwg, dbg,
-                                                                                          dgrep_a, B, T_, H, dh);
+  int blocks = (int)((n + 63) / 64); if (blocks > 512) blocks = 512;         // >= 16 rows per wave
+  wavlm_gate_bwd_kernel<<<blocks, 256, (size_t)(4 * 2 * 64 + 2 + H) * 4, as_stream(stream)>>>(x, wg, bg, grep_a, dgate, dx, dwg, dbg,
+                                                                                              dgrep_a, B, T_, H, dh);
   return launch_status();
 }
 
