@@ -8,6 +8,7 @@
 //   C/D lane l, reg r -> row 4*(l>>4)+r, col (l&15).
 // f32 path (parity mode): 64x64 tile, BK = 16, 4x4 outputs per thread, plain FMA.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -333,31 +334,37 @@ gemm_nt_bf16_direct_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
   };
-  // one K tile: registers -> LDS, refill the register set with the tile two ahead (k_next >= 0), MFMAs
-  // e.dbg (LIDK_GEMM_DBG, tuning aid): 1 = no epilogue stores, 2 = no operand reloads inside the loop, 4 = no LDS/MFMA work
-  auto stage = [&](u32x4 (&ra)[CA], u32x4 (&rb)[CB], int k_next) __attribute__((always_inline)) {
-    if (!(e.dbg & 4)) { lstore(ra, rb); __syncthreads(); }
-    else { acc[0][0][0] += __uint_as_float((ra[0][0] ^ rb[0][0]) & 1u); }
-    if (k_next >= 0 && !(e.dbg & 2)) gload(ra, rb, k_next);   // compile-time after inlining: callers pass -1 or a real k
-    if (!(e.dbg & 4)) { mma(); __syncthreads(); }
+  // one K tile: registers -> LDS, refill the register set with the tile two ahead, MFMAs.  The refill is a COMPILE-TIME choice
+  // (pf is std::true_type / std::false_type): a load behind any runtime condition - even one that is always true - makes
+  // hipcc's waitcnt pass assume it may not have been issued, and the counted wait in front of the next LDS write
+  // (vmcnt(7..4): leave the other register set's 4 loads in flight) degrades to vmcnt(3..0), i.e. the prefetch is drained
+  // every K tile and each tile pays a full memory latency (seen in the ISA of the previous version of this loop).
+  auto stage = [&](auto pf, u32x4 (&ra)[CA], u32x4 (&rb)[CB], int k_next) __attribute__((always_inline)) {
+    lstore(ra, rb);
+    __syncthreads();
+    if constexpr (decltype(pf)::value) gload(ra, rb, k_next);
+    mma();
+    __syncthreads();
   };
+  constexpr std::true_type PF{};
+  constexpr std::false_type NOPF{};
   const int nt = K / BK;
   gload(ra0, rb0, 0);
-  if (nt > 1) gload(ra1, rb1, BK);
-  int t = 0;
+  gload(ra1, rb1, nt > 1 ? BK : 0);          // unconditional (a one-tile problem re-reads tile 0): the loop header's counted
+  int t = 0;                                 // wait is the minimum over all paths that reach it
   for (; t + 3 < nt; t += 2) {
-    stage(ra0, rb0, (t + 2) * BK);
-    stage(ra1, rb1, (t + 3) * BK);
+    stage(PF, ra0, rb0, (t + 2) * BK);
+    stage(PF, ra1, rb1, (t + 3) * BK);
   }
   if (nt - t == 3) {
-    stage(ra0, rb0, (t + 2) * BK);
-    stage(ra1, rb1, -1);
-    stage(ra0, rb0, -1);
+    stage(PF, ra0, rb0, (t + 2) * BK);
+    stage(NOPF, ra1, rb1, 0);
+    stage(NOPF, ra0, rb0, 0);
   } else if (nt - t == 2) {
-    stage(ra0, rb0, -1);
-    stage(ra1, rb1, -1);
+    stage(NOPF, ra0, rb0, 0);
+    stage(NOPF, ra1, rb1, 0);
   } else {
-    stage(ra0, rb0, -1);
+    stage(NOPF, ra0, rb0, 0);
   }
 
   // lane (fr, fq) holds, for row tile i and column tile j, row m = ... + fr and 4 consecutive columns
@@ -365,7 +372,7 @@ gemm_nt_bf16_direct_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * (BM / 2) + i * 16 + fr;
-    if (m >= M || ((e.dbg & 1) && acc[i][0][0] != 12345.f)) continue;
+    if (m >= M) continue;
     if (pair) {
 #pragma unroll
       for (int c = 0; c < TN / 2; ++c) {
@@ -712,10 +719,12 @@ gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict_
       *reinterpret_cast<u32x4*>(&Ys[row * LDY + col]) = ry[i];
     }
   };
-  auto stage = [&](u32x4 (&rx)[CX], u32x4 (&ry)[CY], int m_next) __attribute__((always_inline)) {
+  // pf: compile-time "refill this register set" (see gemm_nt_bf16_direct_kernel: a refill behind a runtime condition costs
+  // the counted vmcnt waits and with them the whole prefetch)
+  auto stage = [&](auto pf, u32x4 (&rx)[CX], u32x4 (&ry)[CY], int m_next) __attribute__((always_inline)) {
     lstore(rx, ry);
     __syncthreads();
-    if (m_next >= 0) gload(rx, ry, m_next);
+    if constexpr (decltype(pf)::value) gload(rx, ry, m_next);
 #pragma unroll
     for (int kk = 0; kk < BKM; kk += 32) {
       bf16x8 af[TM], bfr[TN];
@@ -730,23 +739,25 @@ gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict_
     }
     __syncthreads();
   };
+  constexpr std::true_type PF{};
+  constexpr std::false_type NOPF{};
   const int nt = (mend - mbeg + BKM - 1) / BKM;            // block-uniform; >= 1
   gload(rx0, ry0, mbeg);
-  if (nt > 1) gload(rx1, ry1, mbeg + BKM);
+  gload(rx1, ry1, nt > 1 ? mbeg + BKM : mbeg);       // unconditional, like the NT kernel's prologue
   int t = 0;
   for (; t + 3 < nt; t += 2) {
-    stage(rx0, ry0, mbeg + (t + 2) * BKM);
-    stage(rx1, ry1, mbeg + (t + 3) * BKM);
+    stage(PF, rx0, ry0, mbeg + (t + 2) * BKM);
+    stage(PF, rx1, ry1, mbeg + (t + 3) * BKM);
   }
   if (nt - t == 3) {
-    stage(rx0, ry0, mbeg + (t + 2) * BKM);
-    stage(rx1, ry1, -1);
-    stage(rx0, ry0, -1);
+    stage(PF, rx0, ry0, mbeg + (t + 2) * BKM);
+    stage(NOPF, rx1, ry1, 0);
+    stage(NOPF, rx0, ry0, 0);
   } else if (nt - t == 2) {
-    stage(rx0, ry0, -1);
-    stage(rx1, ry1, -1);
+    stage(NOPF, rx0, ry0, 0);
+    stage(NOPF, rx1, ry1, 0);
   } else {
-    stage(rx0, ry0, -1);
+    stage(NOPF, rx0, ry0, 0);
   }
   // bias gradient: threads with equal tid % PX hold partial sums of the same 8 columns
   if (want_cs) {      // block-uniform
