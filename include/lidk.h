@@ -187,7 +187,16 @@ int lidk_dwconv_fwd(const void* g, const float* w, const float* bias, void* c, f
  * a*sigmoid(gate) [B*T][C] for the weight gradient.  C % 4 == 0. */
 int lidk_glu_dwconv_fwd(const void* y, const float* w, const float* bias, void* g, void* c, float* stat_partial, int B, int T,
                         int C, int K, int pad_left, int dtype, void* stream);
-int lidk_dwconv_stat_parts(int B, int T);
+int lidk_dwconv_stat_parts(int B, int T, int C, int dtype);
+/* Depthwise-conv weight gradient with the BatchNorm+Swish backward apply step fused into its operand load (bf16, C % 8 == 0:
+ * lidk_dwconv_bwd_weight_bn_supported): equivalent to lidk_bn_swish_bwd_apply (-> dc, dgamma, dbeta) followed by
+ * lidk_dwconv_bwd_weight(dc, g, ...), without dc in HBM.  Replaces the reference's autograd of
+ * BatchNorm1d -> Swish after the depthwise Conv1d (lid/conformer.py:189-201) on the weight-gradient side. */
+int lidk_dwconv_bwd_weight_bn_supported(int C, int dtype);
+int lidk_dwconv_bwd_weight_bn(const void* ds, const void* c, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, const double* sums, const double* sums_local, double count, const void* g,
+                              float* dw, float* db, float* dgamma, float* dbeta, float* partial, int B, int T, int C, int K,
+                              int pad_left, int dtype, void* stream);
 int lidk_dwconv_bwd_input(const void* dc, const float* w, void* dg, int B, int T, int C, int K, int pad_left, int dtype,
                           void* stream);
 /* dw [C][K] += , db [C] += ;  partial: >= B*C*(K+1) floats */

@@ -52,6 +52,24 @@ __device__ __forceinline__ void store4(bf16* p, float4 v) {
   *reinterpret_cast<uint2*>(p) = t.u;
 }
 
+// 8-wide (16-byte) load/store of bf16 activations; p must be 8-element aligned.
+struct f32x8_t { float4 lo, hi; };
+__device__ __forceinline__ f32x8_t load8(const bf16* p) {
+  uint4 r = *reinterpret_cast<const uint4*>(p);
+  f32x8_t v;
+  v.lo.x = __uint_as_float(r.x << 16); v.lo.y = __uint_as_float(r.x & 0xffff0000u);
+  v.lo.z = __uint_as_float(r.y << 16); v.lo.w = __uint_as_float(r.y & 0xffff0000u);
+  v.hi.x = __uint_as_float(r.z << 16); v.hi.y = __uint_as_float(r.z & 0xffff0000u);
+  v.hi.z = __uint_as_float(r.w << 16); v.hi.w = __uint_as_float(r.w & 0xffff0000u);
+  return v;
+}
+__device__ __forceinline__ void store8(bf16* p, const f32x8_t& v) {
+  union { bf16 h[8]; uint4 u; } t;
+  t.h[0] = (bf16)v.lo.x; t.h[1] = (bf16)v.lo.y; t.h[2] = (bf16)v.lo.z; t.h[3] = (bf16)v.lo.w;
+  t.h[4] = (bf16)v.hi.x; t.h[5] = (bf16)v.hi.y; t.h[6] = (bf16)v.hi.z; t.h[7] = (bf16)v.hi.w;
+  *reinterpret_cast<uint4*>(p) = t.u;
+}
+
 // Fragment of X^T for v_mfma_f32_16x16x32_bf16 from a ROW-MAJOR LDS tile X[k][n] (leading dimension ld elements, ld*2 % 8 == 0):
 // lane (fq = lane>>4, fr = lane&15) receives X[k0 + 8*fq + jj][n0 + fr], jj = 0..7, through two ds_read_b64_tr_b16.  EXEC must be
 // all ones at the call (the transposed read gathers across lanes); lane mapping pinned by lidk_selftest_tr16.

@@ -211,11 +211,171 @@ dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float
   }
 }
 
-extern "C" int lidk_dwconv_stat_parts(int B, int T_) { return B * cdiv(T_, DW_TT); }
+
+// ------------------------------------------------------------------------------------ depthwise conv, long-tile bf16 form
+// The same arithmetic as dwconv_kernel MODE 1 / MODE 3 (bf16-rounded tile, f32 taps and accumulation: bit-identical results),
+// re-tiled for the training shapes: DW2_TT = 80 output steps per workgroup instead of 32 (halo re-reads 1.94x -> 1.375x and 2.5x
+// fewer workgroups re-staging the taps), 16-byte accesses (8 channels per thread) on every global stream, per-channel
+// BatchNorm constants staged once in LDS.  A wave slides a 20-output window through registers.
+template <int MODE, int DW2_TT>
+__global__ void __launch_bounds__(256)
+dwconv2_bf16_kernel(const bf16* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, bf16* __restrict__ out,
+                    float* __restrict__ stat_partial, int B, int T_, int C, int K, int pad_left, int flip,
+                    const bf16* __restrict__ yglu, bf16* __restrict__ gout, BnBwd bn) {
+  constexpr int OPW = DW2_TT / 4, DW2_ROWS = DW2_TT + DW_KMAX;
+  constexpr int TILE_BYTES = DW2_ROWS * 64 * 2, OT_BYTES = DW2_TT * 64 * 4;
+  constexpr int SM_BYTES = (TILE_BYTES + 64 * DW_KMAX * 4) > OT_BYTES ? (TILE_BYTES + 64 * DW_KMAX * 4) : OT_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
+  __shared__ float red[4][2][64];
+  __shared__ __attribute__((aligned(16))) float cst[6][64];          // MODE 3: mean, rstd, gamma, beta, sum0/count, sum1/count
+  bf16 (*tile)[64] = reinterpret_cast<bf16 (*)[64]>(smem);
+  float* wsh = reinterpret_cast<float*>(smem + TILE_BYTES);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = blockIdx.x * DW2_TT, c0 = blockIdx.y * 64, b = blockIdx.z;
+  {
+    const int nw = min(64, C - c0) * K;
+    for (int i = threadIdx.x; i < nw; i += 256) wsh[i] = w[(size_t)c0 * K + i];
+  }
+  const int ch = c0 + lane;
+  const bool chok = ch < C;
+  if (MODE == 3) {
+    if (threadIdx.x < 64) {
+      float mu = 0.f, rs = 0.f, gm = 0.f, bt = 0.f, m0 = 0.f, m1 = 0.f;
+      if (chok) {
+        const double cnt = bn.count > 0 ? bn.count : bn.sums[2 * C];
+        mu = bn.mean[ch]; rs = bn.rstd[ch]; gm = bn.gamma[ch]; bt = bn.beta[ch];
+        m0 = (float)(bn.sums[ch] / cnt); m1 = (float)(bn.sums[C + ch] / cnt);
+      }
+      cst[0][lane] = mu; cst[1][lane] = rs; cst[2][lane] = gm; cst[3][lane] = bt; cst[4][lane] = m0; cst[5][lane] = m1;
+    }
+    __syncthreads();
+  }
+  // stage rows t0 - pad_left .. of 64 channels: 8 channels (16 bytes) per thread, 32 rows per pass; a thread keeps its channels
+  {
+    const int cc = (threadIdx.x & 7) * 8;
+    const bool cok = c0 + cc < C;                                    // C % 8 == 0 (host check): whole vectors in or out
+    const int need = DW2_TT + K - 1;
+    f32x8_t mu, rs, gm, bt, m0, m1;
+    if (MODE == 3) {
+      mu.lo = *reinterpret_cast<const float4*>(&cst[0][cc]); mu.hi = *reinterpret_cast<const float4*>(&cst[0][cc + 4]);
+      rs.lo = *reinterpret_cast<const float4*>(&cst[1][cc]); rs.hi = *reinterpret_cast<const float4*>(&cst[1][cc + 4]);
+      gm.lo = *reinterpret_cast<const float4*>(&cst[2][cc]); gm.hi = *reinterpret_cast<const float4*>(&cst[2][cc + 4]);
+      bt.lo = *reinterpret_cast<const float4*>(&cst[3][cc]); bt.hi = *reinterpret_cast<const float4*>(&cst[3][cc + 4]);
+      m0.lo = *reinterpret_cast<const float4*>(&cst[4][cc]); m0.hi = *reinterpret_cast<const float4*>(&cst[4][cc + 4]);
+      m1.lo = *reinterpret_cast<const float4*>(&cst[5][cc]); m1.hi = *reinterpret_cast<const float4*>(&cst[5][cc + 4]);
+    }
+    for (int r = threadIdx.x >> 3; r < DW2_ROWS; r += 32) {
+      const int t = t0 - pad_left + r;
+      f32x8_t o;
+      o.lo = make_float4(0.f, 0.f, 0.f, 0.f); o.hi = o.lo;
+      if (cok && t >= 0 && t < T_ && r < need) {
+        if (MODE == 1) {
+          const bf16* yr = in + ((size_t)b * T_ + t) * 2 * C + c0 + cc;
+          const f32x8_t a = load8(yr), gt = load8(yr + C);
+          o.lo.x = a.lo.x * sigmoidf_(gt.lo.x); o.lo.y = a.lo.y * sigmoidf_(gt.lo.y);
+          o.lo.z = a.lo.z * sigmoidf_(gt.lo.z); o.lo.w = a.lo.w * sigmoidf_(gt.lo.w);
+          o.hi.x = a.hi.x * sigmoidf_(gt.hi.x); o.hi.y = a.hi.y * sigmoidf_(gt.hi.y);
+          o.hi.z = a.hi.z * sigmoidf_(gt.hi.z); o.hi.w = a.hi.w * sigmoidf_(gt.hi.w);
+          if (gout && r >= pad_left && r < pad_left + DW2_TT) store8(gout + ((size_t)b * T_ + t) * C + c0 + cc, o);
+        } else if (MODE == 0) {
+          o = load8(in + ((size_t)b * T_ + t) * C + c0 + cc);
+        } else {
+          const size_t e = ((size_t)b * T_ + t) * C + c0 + cc;
+          const f32x8_t x = load8(reinterpret_cast<const bf16*>(bn.c) + e), d = load8(in + e);
+          float xh, dz;
+#define DW2_BN(F, H)                                                                                                     \
+          xh = (x.H.F - mu.H.F) * rs.H.F; dz = d.H.F * swish_grad(xh * gm.H.F + bt.H.F);                                 \
+          o.H.F = gm.H.F * rs.H.F * (dz - m0.H.F - xh * m1.H.F);
+          DW2_BN(x, lo) DW2_BN(y, lo) DW2_BN(z, lo) DW2_BN(w, lo) DW2_BN(x, hi) DW2_BN(y, hi) DW2_BN(z, hi) DW2_BN(w, hi)
+#undef DW2_BN
+        }
+      }
+      store8(&tile[r][cc], o);
+    }
+  }
+  const float bv = (bias && chok) ? bias[ch] : 0.f;
+  __syncthreads();
+  float wr[DW_KMAX];
+#pragma unroll
+  for (int k = 0; k < DW_KMAX; ++k) wr[k] = (chok && k < K) ? wsh[lane * K + (flip ? K - 1 - k : k)] : 0.f;
+  float res[OPW];
+  float s1 = 0.f, s2 = 0.f;
+  {
+    float x[OPW + DW_KMAX - 1];
+#pragma unroll
+    for (int r = 0; r < OPW + DW_KMAX - 1; ++r) x[r] = to_f(tile[wave * OPW + r][lane]);
+#pragma unroll
+    for (int o = 0; o < OPW; ++o) {
+      float acc = bv;
+#pragma unroll
+      for (int k = 0; k < DW_KMAX; ++k) acc = fmaf(wr[k], x[o + k], acc);
+      res[o] = acc;
+      if (chok && t0 + wave * OPW + o < T_) { s1 += acc; s2 = fmaf(acc, acc, s2); }
+    }
+  }
+  __syncthreads();                                                   // the input tile is dead: the f32 result tile takes its place
+  float (*ot)[64] = reinterpret_cast<float (*)[64]>(smem);          // DW2_TT x 64 f32 = 20 KB <= tile + taps
+#pragma unroll
+  for (int o = 0; o < OPW; ++o) ot[wave * OPW + o][lane] = res[o];
+  if (stat_partial) { red[wave][0][lane] = s1; red[wave][1][lane] = s2; }
+  __syncthreads();
+  {
+    const int cc = (threadIdx.x & 7) * 8;
+    if (c0 + cc < C)
+      for (int r = threadIdx.x >> 3; r < DW2_TT; r += 32) {
+        const int t = t0 + r;
+        if (t >= T_) break;
+        f32x8_t v;
+        v.lo = *reinterpret_cast<const float4*>(&ot[r][cc]); v.hi = *reinterpret_cast<const float4*>(&ot[r][cc + 4]);
+        if (MODE == 3) {
+          const bf16* yr = yglu + ((size_t)b * T_ + t) * 2 * C + c0 + cc;
+          const f32x8_t a = load8(yr), gt = load8(yr + C);
+          f32x8_t da, dgt;
+          float sg;
+#define DW2_GLU(F, H) sg = sigmoidf_(gt.H.F); da.H.F = v.H.F * sg; dgt.H.F = v.H.F * a.H.F * sg * (1.f - sg);
+          DW2_GLU(x, lo) DW2_GLU(y, lo) DW2_GLU(z, lo) DW2_GLU(w, lo) DW2_GLU(x, hi) DW2_GLU(y, hi) DW2_GLU(z, hi) DW2_GLU(w, hi)
+#undef DW2_GLU
+          bf16* dr = out + ((size_t)b * T_ + t) * 2 * C + c0 + cc;
+          store8(dr, da);
+          store8(dr + C, dgt);
+        } else {
+          store8(out + ((size_t)b * T_ + t) * C + c0 + cc, v);
+        }
+      }
+  }
+  if (stat_partial && wave == 0 && chok) {
+    const size_t p = (size_t)b * gridDim.x + blockIdx.x;
+    stat_partial[(p * 2 + 0) * C + ch] = red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane];
+    stat_partial[(p * 2 + 1) * C + ch] = red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane];
+  }
+}
+static inline bool dw2_ok(int C, int dtype) {
+  static const int off = getenv("LIDK_DWCONV_V1") ? atoi(getenv("LIDK_DWCONV_V1")) : 0;
+  return dtype == LIDK_BF16 && (C & 7) == 0 && !off;
+}
+static inline int dw2_tt() {
+  static const int tt = getenv("LIDK_DW2_TT") ? atoi(getenv("LIDK_DW2_TT")) : 80;
+  return tt == 40 || tt == 64 || tt == 112 ? tt : 80;
+}
+#define DW2_LAUNCH(MODE_, ...)                                                                                   \
+  do {                                                                                                           \
+    const int tt_ = dw2_tt();                                                                                    \
+    dim3 grid2(cdiv(T_, tt_), cdiv(C, 64), B);                                                                   \
+    if (tt_ == 40) dwconv2_bf16_kernel<MODE_, 40><<<grid2, 256, 0, as_stream(stream)>>>(__VA_ARGS__);            \
+    else if (tt_ == 64) dwconv2_bf16_kernel<MODE_, 64><<<grid2, 256, 0, as_stream(stream)>>>(__VA_ARGS__);       \
+    else if (tt_ == 112) dwconv2_bf16_kernel<MODE_, 112><<<grid2, 256, 0, as_stream(stream)>>>(__VA_ARGS__);     \
+    else dwconv2_bf16_kernel<MODE_, 80><<<grid2, 256, 0, as_stream(stream)>>>(__VA_ARGS__);                      \
+  } while (0)
+
+extern "C" int lidk_dwconv_stat_parts(int B, int T_, int C, int dtype) { return B * cdiv(T_, dw2_ok(C, dtype) ? dw2_tt() : DW_TT); }
 
 extern "C" int lidk_dwconv_fwd(const void* g, const float* w, const float* bias, void* c, float* stat_partial, int B,
                                int T_, int C, int K, int pad_left, int dtype, void* stream) {
   if (!g || !w || !c || B <= 0 || T_ <= 0 || C <= 0 || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K) return LIDK_ERR_ARG;
+  if (dw2_ok(C, dtype)) {
+    DW2_LAUNCH(0, (const bf16*)g, w, bias, (bf16*)c, stat_partial, B, T_, C, K, pad_left, 0, nullptr, nullptr, BnBwd{});
+    return launch_status();
+  }
   dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
   LIDK_DISPATCH(dtype, (dwconv_kernel<T, 0><<<grid, 256, 0, as_stream(stream)>>>((const T*)g, w, bias, (T*)c, stat_partial, B,
                                                                                 T_, C, K, pad_left, 0, nullptr, nullptr, BnBwd{})));
@@ -226,6 +386,10 @@ extern "C" int lidk_glu_dwconv_fwd(const void* y, const float* w, const float* b
                                    int B, int T_, int C, int K, int pad_left, int dtype, void* stream) {
   if (!y || !w || !c || B <= 0 || T_ <= 0 || C <= 0 || (C & 3) || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K)
     return LIDK_ERR_ARG;
+  if (dw2_ok(C, dtype)) {
+    DW2_LAUNCH(1, (const bf16*)y, w, bias, (bf16*)c, stat_partial, B, T_, C, K, pad_left, 0, nullptr, (bf16*)g, BnBwd{});
+    return launch_status();
+  }
   dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
   LIDK_DISPATCH(dtype, (dwconv_kernel<T, 1><<<grid, 256, 0, as_stream(stream)>>>((const T*)y, w, bias, (T*)c, stat_partial, B,
                                                                                 T_, C, K, pad_left, 0, nullptr, (T*)g, BnBwd{})));
@@ -257,8 +421,12 @@ extern "C" int lidk_dwconv_bwd_input_bn_glu(const void* ds, const void* c, const
   if (!ds || !c || !mean || !rstd || !gamma || !beta || !sums || !w || !y || !dy || B <= 0 || T_ <= 0 || C <= 0 ||
       (C & 3) || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K)
     return LIDK_ERR_ARG;
-  dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
   BnBwd bn{c, mean, rstd, gamma, beta, sums, count};
+  if (dw2_ok(C, dtype)) {
+    DW2_LAUNCH(3, (const bf16*)ds, w, nullptr, (bf16*)dy, nullptr, B, T_, C, K, K - 1 - pad_left, 1, (const bf16*)y, nullptr, bn);
+    return launch_status();
+  }
+  dim3 grid(cdiv(T_, DW_TT), cdiv(C, 64), B);
   LIDK_DISPATCH(dtype, (dwconv_kernel<T, 3><<<grid, 256, 0, as_stream(stream)>>>((const T*)ds, w, nullptr, (T*)dy, nullptr, B,
                                                                                 T_, C, K, K - 1 - pad_left, 1, (const T*)y, nullptr, bn)));
   return launch_status();
@@ -355,6 +523,119 @@ extern "C" int lidk_dwconv_bwd_weight(const void* dc, const void* g, float* dw, 
   hipStream_t s = as_stream(stream);
   dim3 grid(cdiv(C, 64), B);
   LIDK_DISPATCH(dtype, dwconv_wgrad_kernel<T><<<grid, 256, 0, s>>>((const T*)dc, (const T*)g, partial, B, T_, C, K, pad_left));
+  dwconv_wgrad_finalize_kernel<<<cdiv(C * (K + 1), 64), 1024, 0, s>>>(partial, B, C, K, dw, db);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ depthwise conv wgrad, fused bf16 form
+// The depthwise-conv weight gradient with the BatchNorm+Swish backward "apply" step in its operand load: dc (the gradient at
+// the conv output) is formed from ds and c while the tile is staged - exactly the values lidk_bn_swish_bwd_apply would have
+// written (bf16-rounded) - so dc never exists in HBM (-2 x 9.9 MB per block at cfg2) and one launch disappears.  Workgroup
+// (0, 0) also adds this rank's BatchNorm parameter gradients (dbeta += sum dz, dgamma += sum dz*xhat) from sums_local.
+// 80-row time tiles, 16-byte accesses; partial[b][ch][k] as in dwconv_wgrad_kernel, finished by dwconv_wgrad_finalize_kernel.
+#define DWG_TT 80
+__global__ void __launch_bounds__(256)
+dwconv_wgrad_bn_bf16_kernel(const bf16* __restrict__ ds, const bf16* __restrict__ g, float* __restrict__ partial, int B, int T_, int C,
+                            int K, int pad_left, BnBwd bn, const double* __restrict__ sums_local, float* __restrict__ dgamma,
+                            float* __restrict__ dbeta) {
+  constexpr int OPW = DWG_TT / 4, GROWS = DWG_TT + DW_KMAX;
+  constexpr int G_BYTES = GROWS * 64 * 2, D_BYTES = DWG_TT * 64 * 2, R_BYTES = 4 * (DW_KMAX + 1) * 64 * 4;
+  constexpr int SM = (G_BYTES + D_BYTES) > R_BYTES ? (G_BYTES + D_BYTES) : R_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
+  __shared__ __attribute__((aligned(16))) float cst[6][64];
+  bf16 (*gt)[64] = reinterpret_cast<bf16 (*)[64]>(smem);
+  bf16 (*dt)[64] = reinterpret_cast<bf16 (*)[64]>(smem + G_BYTES);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 64, b = blockIdx.y, ch = c0 + lane;
+  const bool chok = ch < C;
+  if (blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i < C; i += 256) {
+      if (dbeta) dbeta[i] += (float)sums_local[i];
+      if (dgamma) dgamma[i] += (float)sums_local[C + i];
+    }
+  if (threadIdx.x < 64) {
+    float mu = 0.f, rs = 0.f, gm = 0.f, bt = 0.f, m0 = 0.f, m1 = 0.f;
+    if (chok) {
+      const double cnt = bn.count > 0 ? bn.count : bn.sums[2 * C];
+      mu = bn.mean[ch]; rs = bn.rstd[ch]; gm = bn.gamma[ch]; bt = bn.beta[ch];
+      m0 = (float)(bn.sums[ch] / cnt); m1 = (float)(bn.sums[C + ch] / cnt);
+    }
+    cst[0][lane] = mu; cst[1][lane] = rs; cst[2][lane] = gm; cst[3][lane] = bt; cst[4][lane] = m0; cst[5][lane] = m1;
+  }
+  __syncthreads();
+  const int cc = (threadIdx.x & 7) * 8;
+  const bool cok = c0 + cc < C;
+  f32x8_t mu, rs, gm, bt, m0, m1;
+  mu.lo = *reinterpret_cast<const float4*>(&cst[0][cc]); mu.hi = *reinterpret_cast<const float4*>(&cst[0][cc + 4]);
+  rs.lo = *reinterpret_cast<const float4*>(&cst[1][cc]); rs.hi = *reinterpret_cast<const float4*>(&cst[1][cc + 4]);
+  gm.lo = *reinterpret_cast<const float4*>(&cst[2][cc]); gm.hi = *reinterpret_cast<const float4*>(&cst[2][cc + 4]);
+  bt.lo = *reinterpret_cast<const float4*>(&cst[3][cc]); bt.hi = *reinterpret_cast<const float4*>(&cst[3][cc + 4]);
+  m0.lo = *reinterpret_cast<const float4*>(&cst[4][cc]); m0.hi = *reinterpret_cast<const float4*>(&cst[4][cc + 4]);
+  m1.lo = *reinterpret_cast<const float4*>(&cst[5][cc]); m1.hi = *reinterpret_cast<const float4*>(&cst[5][cc + 4]);
+  const bf16* cbuf = reinterpret_cast<const bf16*>(bn.c);
+  float acc[DW_KMAX + 1];
+#pragma unroll
+  for (int k = 0; k <= DW_KMAX; ++k) acc[k] = 0.f;
+  for (int t0 = 0; t0 < T_; t0 += DWG_TT) {
+    __syncthreads();
+    for (int r = threadIdx.x >> 3; r < GROWS; r += 32) {
+      const int t = t0 - pad_left + r;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (cok && t >= 0 && t < T_) v = *reinterpret_cast<const uint4*>(g + ((size_t)b * T_ + t) * C + c0 + cc);
+      *reinterpret_cast<uint4*>(&gt[r][cc]) = v;
+    }
+    for (int r = threadIdx.x >> 3; r < DWG_TT; r += 32) {
+      const int t = t0 + r;
+      f32x8_t o;
+      o.lo = make_float4(0.f, 0.f, 0.f, 0.f); o.hi = o.lo;
+      if (cok && t < T_) {
+        const size_t e = ((size_t)b * T_ + t) * C + c0 + cc;
+        const f32x8_t x = load8(cbuf + e), d = load8(ds + e);
+        float xh, dz;
+#define DWG_BN(F, H)                                                                                                     \
+        xh = (x.H.F - mu.H.F) * rs.H.F; dz = d.H.F * swish_grad(xh * gm.H.F + bt.H.F);                                   \
+        o.H.F = gm.H.F * rs.H.F * (dz - m0.H.F - xh * m1.H.F);
+        DWG_BN(x, lo) DWG_BN(y, lo) DWG_BN(z, lo) DWG_BN(w, lo) DWG_BN(x, hi) DWG_BN(y, hi) DWG_BN(z, hi) DWG_BN(w, hi)
+#undef DWG_BN
+      }
+      store8(&dt[r][cc], o);
+    }
+    __syncthreads();
+    float x[OPW + DW_KMAX - 1];
+#pragma unroll
+    for (int r = 0; r < OPW + DW_KMAX - 1; ++r) x[r] = to_f(gt[wave * OPW + r][lane]);
+#pragma unroll
+    for (int o = 0; o < OPW; ++o) {
+      const float d = to_f(dt[wave * OPW + o][lane]);
+#pragma unroll
+      for (int k = 0; k < DW_KMAX; ++k) acc[k] = fmaf(d, x[o + k], acc[k]);
+      acc[DW_KMAX] += d;
+    }
+  }
+  __syncthreads();
+  float (*red)[DW_KMAX + 1][64] = reinterpret_cast<float (*)[DW_KMAX + 1][64]>(smem);
+#pragma unroll
+  for (int k = 0; k <= DW_KMAX; ++k) red[wave][k][lane] = acc[k];
+  __syncthreads();
+  if (wave == 0 && chok) {
+    float* p = partial + ((size_t)b * C + ch) * (K + 1);
+    for (int k = 0; k < K; ++k) p[k] = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
+    p[K] = red[0][DW_KMAX][lane] + red[1][DW_KMAX][lane] + red[2][DW_KMAX][lane] + red[3][DW_KMAX][lane];
+  }
+}
+extern "C" int lidk_dwconv_bwd_weight_bn_supported(int C, int dtype) { return dw2_ok(C, dtype) ? 1 : 0; }
+extern "C" int lidk_dwconv_bwd_weight_bn(const void* ds, const void* c, const float* mean, const float* rstd, const float* gamma,
+                                         const float* beta, const double* sums, const double* sums_local, double count,
+                                         const void* g, float* dw, float* db, float* dgamma, float* dbeta, float* partial, int B,
+                                         int T_, int C, int K, int pad_left, int dtype, void* stream) {
+  if (!ds || !c || !mean || !rstd || !gamma || !beta || !sums || !sums_local || !g || !dw || !partial || B <= 0 || T_ <= 0 ||
+      C <= 0 || K <= 0 || K > DW_KMAX || pad_left < 0 || pad_left >= K || !dw2_ok(C, dtype))
+    return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  BnBwd bn{c, mean, rstd, gamma, beta, sums, count};
+  dim3 grid(cdiv(C, 64), B);
+  dwconv_wgrad_bn_bf16_kernel<<<grid, 256, 0, s>>>((const bf16*)ds, (const bf16*)g, partial, B, T_, C, K, pad_left, bn, sums_local,
+                                                  dgamma, dbeta);
   dwconv_wgrad_finalize_kernel<<<cdiv(C * (K + 1), 64), 1024, 0, s>>>(partial, B, C, K, dw, db);
   return launch_status();
 }

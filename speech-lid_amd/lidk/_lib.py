@@ -67,7 +67,9 @@ SIGNATURES = {
     "lidk_dwconv_bwd_input_glu": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_dwconv_bwd_input_bn_glu": (_I, [_P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_dwconv_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "lidk_dwconv_stat_parts": (_I, [_I, _I]),
+    "lidk_dwconv_stat_parts": (_I, [_I, _I, _I, _I]),
+    "lidk_dwconv_bwd_weight_bn_supported": (_I, [_I, _I]),
+    "lidk_dwconv_bwd_weight_bn": (_I, [_P] * 8 + [_D, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_dwconv_bwd_input": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_dwconv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_bn_train_stats_from_partials": (_I, [_P, _I, _D, _P, _P, _P, _P, _P, _F, _F, _I, _P]),

@@ -228,7 +228,7 @@ class _Work:
         self.dxa, self.dxb = f(M, d), f(M, d)
         hmax = max(cfg.heads, cfg.last_heads)
         self.partial = f(max(L.LN_PARTIAL_BLOCKS * 2 * cmax, L.LN_BWD_BLOCKS * 2 * d, L.BN_PARTIAL_BLOCKS * 2 * ci))
-        self.stat_parts = eng.k.dwconv_stat_parts(B, T)
+        self.stat_parts = eng.k.dwconv_stat_parts(B, T, ci, eng.act_dtype)
         self.stat_partial = f(self.stat_parts * 2 * ci)
         self.dw_partial = f(B * ci * (max(cfg.conv_kernel_size, 31) + 1))
         self.sums = f64(2 * ci + 1)                                                 # (sum x, sum x^2) [2*ci] + row count
@@ -739,6 +739,11 @@ class Engine:
         C = bp.conv
         ci, K = C["dw"].shape[0], C["dw"].shape[2]
         ds = S.ds.view(-1)[:M * ci].view(M, ci)
+        if self._hip and self.k.dwconv_bwd_weight_bn_supported(ci, self.act_dtype):     # one pass, dc never written
+            self.k.dwconv_bwd_weight_bn(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], S.sums[:2 * ci + 1],
+                                        S.sums_local[:2 * ci + 1], 0, bb.g, C["ddw"].view(ci, K), C["ddwb"], C["dbn_w"],
+                                        C["dbn_b"], w.dw_partial, B, T, K // 2)
+            return
         dc = S.dc.view(-1)[:M * ci].view(M, ci)
         self.k.bn_swish_bwd_apply(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], S.sums[:2 * ci + 1],
                                   S.sums_local[:2 * ci + 1], 0, dc, C["dbn_w"], C["dbn_b"])

@@ -331,8 +331,9 @@ def glu_bwd(y, dg, dy):
     check(lib().lidk_glu_bwd(_p(y), _p(dg), _p(dy), M, C2 // 2, _code(y), _stream()), "glu_bwd")
 
 
-def dwconv_stat_parts(B, T):
-    return lib().lidk_dwconv_stat_parts(B, T)
+def dwconv_stat_parts(B, T, C, dtype):
+    """Rows of the (parts, 2, C) BatchNorm partial-sum buffer glu_dwconv_fwd / dwconv_fwd fill for this shape and dtype."""
+    return lib().lidk_dwconv_stat_parts(B, T, C, dtype_code(dtype))
 
 
 def dwconv_fwd(g, w, bias, c, stat_partial, B, T, pad_left):
@@ -372,6 +373,18 @@ def dwconv_bwd_weight(dc, g, dw, db, partial, B, T, pad_left):
     Cc, K = dw.shape
     check(lib().lidk_dwconv_bwd_weight(_p(dc), _p(g), _p(dw), _p(db), _p(partial), B, T, Cc, K, pad_left, _code(dc),
                                        _stream()), "dwconv_bwd_weight")
+
+
+def dwconv_bwd_weight_bn_supported(C, dtype):
+    return bool(lib().lidk_dwconv_bwd_weight_bn_supported(C, dtype_code(dtype)))
+
+
+def dwconv_bwd_weight_bn(ds, c, mean, rstd, gamma, beta, sums, sums_local, count, g, dw, db, dgamma, dbeta, partial, B, T, pad_left):
+    """bn_swish_bwd_apply + dwconv_bwd_weight in one pass over ds / c / g (dc is never written)."""
+    Cc, K = dw.shape
+    check(lib().lidk_dwconv_bwd_weight_bn(_p(ds), _p(c), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), _p(sums_local),
+                                          float(count), _p(g), _p(dw), _p(db), _p(dgamma), _p(dbeta), _p(partial), B, T, Cc, K,
+                                          pad_left, _code(ds), _stream()), "dwconv_bwd_weight_bn")
 
 
 def bn_train_stats(sums, count, mean, rstd, running_mean, running_var, nbt, momentum=0.1, eps=1e-5):

@@ -189,7 +189,7 @@ def glu_bwd(y, dg, dy):
     dy[:, C:] = (d * a * s * (1 - s)).to(dy.dtype)
 
 
-def dwconv_stat_parts(B, T):
+def dwconv_stat_parts(B, T, C=0, dtype=None):
     return B * ((T + 31) // 32)
 
 

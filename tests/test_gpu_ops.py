@@ -378,7 +378,7 @@ def test_dwconv_fwd_bwd_and_stats(dt, B, T, C, K):
     y.backward(rt(dy, dt))
     xd, wd, bd = dev(x, dt), dev(w.detach()), dev(b.detach())
     c = torch.empty(B, T, C, device=DEV, dtype=dt)
-    nparts = ops.dwconv_stat_parts(B, T)
+    nparts = ops.dwconv_stat_parts(B, T, C, dt)
     stat = torch.empty(nparts, 2, C, device=DEV)
     ops.dwconv_fwd(xd, wd, bd, c, stat, B, T, pad[0])
     check("dwconv_fwd", c, y, tol(dt, 2e-5, 3e-2))
@@ -410,7 +410,7 @@ def test_glu_dwconv_fused_matches_separate_kernels(dt, B, T, C, K):
     b = 0.1 * torch.randn(C, generator=g(132))
     dc = torch.randn(M, C, generator=g(133))
     yd, wd, bd, dcd = dev(y, dt), dev(w), dev(b), dev(dc, dt)
-    nparts = ops.dwconv_stat_parts(B, T)
+    nparts = ops.dwconv_stat_parts(B, T, C, dt)
     g_sep, c_sep = torch.empty(M, C, device=DEV, dtype=dt), torch.empty(M, C, device=DEV, dtype=dt)
     st_sep = torch.empty(nparts, 2, C, device=DEV)
     ops.glu_fwd(yd, g_sep)
@@ -492,6 +492,54 @@ def test_batchnorm_swish_train_and_eval(dt):
     ops.bn_swish_fwd(cd, mean, rstd, gd, bd, so)
     ze = F.batch_norm(rt(c, dt), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 1e-5)
     check("bn_swish_eval", so, ze * torch.sigmoid(ze), tol(dt, 2e-5, 3e-2))
+
+
+@pytest.mark.parametrize("B,T,C,K", [(3, 151, 128, 31), (2, 37, 72, 15), (5, 200, 64, 31)])
+def test_dwconv_wgrad_with_fused_bn_apply_equals_the_two_launch_sequence(B, T, C, K):
+    """lidk_dwconv_bwd_weight_bn (dc formed in the operand load, never written) against lidk_bn_swish_bwd_apply followed by
+    lidk_dwconv_bwd_weight: the same bf16-rounded dc values enter the same f32 sums, only grouped differently (80-row tiles of
+    20 rows per wave instead of 32 / 8), so dw / db agree to f32 summation noise and dgamma / dbeta to the last bit; and
+    against torch autograd within bf16 tolerance."""
+    dt = torch.bfloat16
+    M = B * T
+    assert ops.dwconv_bwd_weight_bn_supported(C, dt)
+    gin = torch.randn(M, C, generator=g(140))
+    c = 1.2 * torch.randn(M, C, generator=g(141)) + 0.2
+    ds = torch.randn(M, C, generator=g(142))
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g(143)), 0.1 * torch.randn(C, generator=g(144))
+    gd, cd, dsd = dev(gin, dt), dev(c, dt), dev(ds, dt)
+    cr = rt(c, dt)
+    sums = torch.stack([cr.double().sum(0), (cr.double() ** 2).sum(0)]).reshape(-1).to(DEV)
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_train_stats(sums, M, mean, rstd, None, None, None)
+    gmd, btd = dev(gamma), dev(beta)
+    partial = torch.empty(L.BN_PARTIAL_BLOCKS * 2 * C, device=DEV)
+    ops.bn_swish_bwd_reduce(dsd, cd, mean, rstd, gmd, btd, partial)
+    bs = torch.zeros(2 * C + 1, device=DEV, dtype=torch.float64)
+    ops.reduce_partials_f64(partial, L.BN_PARTIAL_BLOCKS, 2 * C, bs, tail=M)
+    # two launches
+    dc = torch.empty(M, C, device=DEV, dtype=dt)
+    dgam0, dbet0 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.bn_swish_bwd_apply(dsd, cd, mean, rstd, gmd, btd, bs, bs, 0, dc, dgam0, dbet0)
+    dw0, db0 = torch.zeros(C, K, device=DEV), torch.zeros(C, device=DEV)
+    wp = torch.empty(B * C * (K + 1), device=DEV)
+    ops.dwconv_bwd_weight(dc, gd, dw0, db0, wp, B, T, K // 2)
+    # fused
+    dgam1, dbet1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dw1, db1 = torch.zeros(C, K, device=DEV), torch.zeros(C, device=DEV)
+    ops.dwconv_bwd_weight_bn(dsd, cd, mean, rstd, gmd, btd, bs, bs, 0, gd, dw1, db1, dgam1, dbet1, wp, B, T, K // 2)
+    assert torch.equal(dgam0, dgam1) and torch.equal(dbet0, dbet1)
+    scale = float(dw0.abs().max())
+    assert float((dw0 - dw1).abs().max()) <= 2e-6 * scale and float((db0 - db1).abs().max()) <= 2e-6 * float(db0.abs().max() + 1)
+    # torch autograd of conv -> BatchNorm(train) -> Swish with respect to the conv weight, on the bf16-rounded operands
+    w = (0.2 * torch.randn(C, K, generator=g(145))).requires_grad_()
+    xg = rt(gin, dt).view(B, T, C)
+    conv = F.conv1d(F.pad(xg.transpose(1, 2), (K // 2, K - 1 - K // 2)), w[:, None, :], None, groups=C).transpose(1, 2).reshape(M, C)
+    # the kernel differentiates at the GIVEN c (the forward's bf16 conv output), so substitute it without cutting the graph
+    cc = conv + (cr - conv).detach()
+    z = F.batch_norm(cc, None, None, gamma, beta, True, 0.1, 1e-5)
+    (z * torch.sigmoid(z)).backward(rt(ds, dt))
+    check("dwconv_wgrad_bn_dw", dw1, w.grad, 0.15, 2e-2)        # dc is rounded to bf16 (rel 4e-3) before ~T*B products are summed
 
 
 # ------------------------------------------------------------------------------------------------ front-end
