@@ -328,6 +328,68 @@ ln_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x, const flo
     partial[(size_t)blockIdx.x * 2 * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
+// C <= 256 (one float4 per lane): the same arithmetic with TWO rows of loads in flight per wave - with ~2.4 rows per wave at the
+// training shapes the one-row loop is a chain of exposed memory latencies - and 8 KB of LDS instead of 32.
+template <typename T, typename TDY>
+__global__ void __launch_bounds__(256)
+ln_bwd_c256_kernel(const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                   const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ dres,
+                   float* __restrict__ dx, T* __restrict__ dxT, float dxT_scale, float* __restrict__ partial, int M, int C) {
+  __shared__ float red[4][2 * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane * 4;
+  const bool ok = c < C;
+  float4 dg = make_float4(0, 0, 0, 0), db = dg;
+  const float4 gm = ok ? load4(gamma + c) : make_float4(0, 0, 0, 0);
+  const int stride = gridDim.x * 4;
+  for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += 2 * stride) {
+    const int row1 = row0 + stride;
+    const bool has1 = row1 < M;                                  // wave-uniform
+    const int r1 = has1 ? row1 : row0;                           // clamped: the second set of loads is unconditional
+    const float mu0 = mean[row0], rs0 = rstd[row0], mu1 = mean[r1], rs1 = rstd[r1];
+    float4 xv0 = make_float4(0, 0, 0, 0), d0 = xv0, xv1 = xv0, d1 = xv0, q0 = xv0, q1 = xv0;
+    if (ok) {
+      xv0 = load4(x + (size_t)row0 * C + c); d0 = load4(dy + (size_t)row0 * C + c);
+      xv1 = load4(x + (size_t)r1 * C + c);   d1 = load4(dy + (size_t)r1 * C + c);
+      if (dres) { q0 = load4(dres + (size_t)row0 * C + c); q1 = load4(dres + (size_t)r1 * C + c); }
+    }
+    float4 xh0, g0, xh1, g1;
+    xh0.x = (xv0.x - mu0) * rs0; xh0.y = (xv0.y - mu0) * rs0; xh0.z = (xv0.z - mu0) * rs0; xh0.w = (xv0.w - mu0) * rs0;
+    xh1.x = (xv1.x - mu1) * rs1; xh1.y = (xv1.y - mu1) * rs1; xh1.z = (xv1.z - mu1) * rs1; xh1.w = (xv1.w - mu1) * rs1;
+    g0.x = d0.x * gm.x; g0.y = d0.y * gm.y; g0.z = d0.z * gm.z; g0.w = d0.w * gm.w;
+    g1.x = d1.x * gm.x; g1.y = d1.y * gm.y; g1.z = d1.z * gm.z; g1.w = d1.w * gm.w;
+    float a0 = g0.x + g0.y + g0.z + g0.w, b0 = g0.x * xh0.x + g0.y * xh0.y + g0.z * xh0.z + g0.w * xh0.w;
+    float a1 = g1.x + g1.y + g1.z + g1.w, b1 = g1.x * xh1.x + g1.y * xh1.y + g1.z * xh1.z + g1.w * xh1.w;
+    if (!ok) { a0 = b0 = a1 = b1 = 0.f; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a0 += __shfl_xor(a0, o, 64); b0 += __shfl_xor(b0, o, 64); a1 += __shfl_xor(a1, o, 64); b1 += __shfl_xor(b1, o, 64);
+    }
+    const float inv = 1.f / (float)C;
+    a0 *= inv; b0 *= inv; a1 *= inv; b1 *= inv;
+    if (ok) {
+      dg.x += d0.x * xh0.x; dg.y += d0.y * xh0.y; dg.z += d0.z * xh0.z; dg.w += d0.w * xh0.w;
+      db.x += d0.x; db.y += d0.y; db.z += d0.z; db.w += d0.w;
+      float4 o;
+      o.x = rs0 * (g0.x - a0 - xh0.x * b0) + q0.x; o.y = rs0 * (g0.y - a0 - xh0.y * b0) + q0.y;
+      o.z = rs0 * (g0.z - a0 - xh0.z * b0) + q0.z; o.w = rs0 * (g0.w - a0 - xh0.w * b0) + q0.w;
+      if (dx) store4(dx + (size_t)row0 * C + c, o);
+      if (dxT) { o.x *= dxT_scale; o.y *= dxT_scale; o.z *= dxT_scale; o.w *= dxT_scale; store4(dxT + (size_t)row0 * C + c, o); }
+      if (has1) {
+        dg.x += d1.x * xh1.x; dg.y += d1.y * xh1.y; dg.z += d1.z * xh1.z; dg.w += d1.w * xh1.w;
+        db.x += d1.x; db.y += d1.y; db.z += d1.z; db.w += d1.w;
+        o.x = rs1 * (g1.x - a1 - xh1.x * b1) + q1.x; o.y = rs1 * (g1.y - a1 - xh1.y * b1) + q1.y;
+        o.z = rs1 * (g1.z - a1 - xh1.z * b1) + q1.z; o.w = rs1 * (g1.w - a1 - xh1.w * b1) + q1.w;
+        if (dx) store4(dx + (size_t)row1 * C + c, o);
+        if (dxT) { o.x *= dxT_scale; o.y *= dxT_scale; o.z *= dxT_scale; o.w *= dxT_scale; store4(dxT + (size_t)row1 * C + c, o); }
+      }
+    }
+  }
+  if (ok) { store4(&red[wave][c], dg); store4(&red[wave][C + c], db); }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256)
+    partial[(size_t)blockIdx.x * 2 * C + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
 extern "C" int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
                                   const float* gamma, const float* dres, float* dx, void* dxT, float dxT_scale,
                                   float* dgamma, float* dbeta, float* partial, int M, int C, int dtype, void* stream) {
@@ -337,7 +399,16 @@ extern "C" int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, 
   if (dy_dtype != LIDK_F32 && dy_dtype != dtype) return LIDK_ERR_ARG;
   hipStream_t s = as_stream(stream);
   int G = cdiv(M, 4) < LIDK_LN_BWD_BLOCKS ? cdiv(M, 4) : LIDK_LN_BWD_BLOCKS;   // one wave per row in flight: latency-bound otherwise
-  if (dy_dtype == LIDK_F32) {
+  static const int small = getenv("LIDK_LN_BWD_SMALL") ? atoi(getenv("LIDK_LN_BWD_SMALL")) : 1;
+  if (small && C <= 256) {
+    if (dy_dtype == LIDK_F32) {
+      LIDK_DISPATCH(dtype, ln_bwd_c256_kernel<T, float><<<G, 256, 0, s>>>((const float*)dy, x, mean, rstd, gamma, dres, dx,
+                                                                         (T*)dxT, dxT_scale, partial, M, C));
+    } else {
+      LIDK_DISPATCH(dtype, ln_bwd_c256_kernel<T, T><<<G, 256, 0, s>>>((const T*)dy, x, mean, rstd, gamma, dres, dx, (T*)dxT,
+                                                                     dxT_scale, partial, M, C));
+    }
+  } else if (dy_dtype == LIDK_F32) {
     LIDK_DISPATCH(dtype, ln_bwd_kernel<T, float><<<G, 256, 0, s>>>((const float*)dy, x, mean, rstd, gamma, dres, dx,
                                                                   (T*)dxT, dxT_scale, partial, M, C));
   } else {
