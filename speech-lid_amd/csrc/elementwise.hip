@@ -257,9 +257,60 @@ ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, cons
   }
 }
 
+// C <= 256: two rows per wave, both rows' loads in flight together (half the waves, one scheduling round at the training shapes)
+template <typename T>
+__global__ void __launch_bounds__(256)
+ln_fwd_c256_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                   T* __restrict__ yT, float* __restrict__ y32, float* __restrict__ mean, float* __restrict__ rstd, int M,
+                   int C, float eps) {
+  const int lane = threadIdx.x & 63, c = lane * 4;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+  if (row0 >= M) return;
+  const bool has1 = row0 + 1 < M, ok = c < C;                 // has1 is wave-uniform
+  const int row1 = has1 ? row0 + 1 : row0;
+  float4 v0 = make_float4(0, 0, 0, 0), v1 = v0, g = v0, b = v0;
+  if (ok) { v0 = load4(x + (size_t)row0 * C + c); v1 = load4(x + (size_t)row1 * C + c); g = load4(gamma + c); b = load4(beta + c); }
+  float s0 = v0.x + v0.y + v0.z + v0.w, s1 = v1.x + v1.y + v1.z + v1.w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+  const float mu0 = s0 / (float)C, mu1 = s1 / (float)C;        // the same expressions as ln_fwd_kernel: bit-identical outputs
+  float q0 = 0.f, q1 = 0.f;
+  if (ok) {
+    float a = v0.x - mu0, b2 = v0.y - mu0, d = v0.z - mu0, e = v0.w - mu0;
+    q0 += a * a + b2 * b2 + d * d + e * e;
+    a = v1.x - mu1; b2 = v1.y - mu1; d = v1.z - mu1; e = v1.w - mu1;
+    q1 += a * a + b2 * b2 + d * d + e * e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { q0 += __shfl_xor(q0, o, 64); q1 += __shfl_xor(q1, o, 64); }
+  const float rs0 = rsqrtf(q0 / (float)C + eps), rs1 = rsqrtf(q1 / (float)C + eps);
+  if (lane == 0) {
+    if (mean) { mean[row0] = mu0; if (has1) mean[row1] = mu1; }
+    if (rstd) { rstd[row0] = rs0; if (has1) rstd[row1] = rs1; }
+  }
+  if (!ok) return;
+  float4 o;
+  o.x = (v0.x - mu0) * rs0 * g.x + b.x; o.y = (v0.y - mu0) * rs0 * g.y + b.y;
+  o.z = (v0.z - mu0) * rs0 * g.z + b.z; o.w = (v0.w - mu0) * rs0 * g.w + b.w;
+  if (yT) store4(yT + (size_t)row0 * C + c, o);
+  if (y32) store4(y32 + (size_t)row0 * C + c, o);
+  if (has1) {
+    o.x = (v1.x - mu1) * rs1 * g.x + b.x; o.y = (v1.y - mu1) * rs1 * g.y + b.y;
+    o.z = (v1.z - mu1) * rs1 * g.z + b.z; o.w = (v1.w - mu1) * rs1 * g.w + b.w;
+    if (yT) store4(yT + (size_t)row1 * C + c, o);
+    if (y32) store4(y32 + (size_t)row1 * C + c, o);
+  }
+}
+
 extern "C" int lidk_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* yT, float* y32,
                                   float* mean, float* rstd, int M, int C, float eps, int dtype, void* stream) {
   if (!x || !gamma || !beta || (!yT && !y32) || M <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAX_VEC) return LIDK_ERR_ARG;
+  static const int small = getenv("LIDK_LN_FWD_SMALL") ? atoi(getenv("LIDK_LN_FWD_SMALL")) : 1;
+  if (small && C <= 256) {
+    LIDK_DISPATCH(dtype, ln_fwd_c256_kernel<T><<<cdiv(M, 8), 256, 0, as_stream(stream)>>>(x, gamma, beta, (T*)yT, y32, mean,
+                                                                                         rstd, M, C, eps));
+    return launch_status();
+  }
   LIDK_DISPATCH(dtype, ln_fwd_kernel<T><<<cdiv(M, 4), 256, 0, as_stream(stream)>>>(x, gamma, beta, (T*)yT, y32, mean,
                                                                                   rstd, M, C, eps));
   return launch_status();
@@ -364,8 +415,7 @@ ln_bwd_c256_kernel(const TDY* __restrict__ dy, const float* __restrict__ x, cons
     for (int o = 32; o > 0; o >>= 1) {
       a0 += __shfl_xor(a0, o, 64); b0 += __shfl_xor(b0, o, 64); a1 += __shfl_xor(a1, o, 64); b1 += __shfl_xor(b1, o, 64);
     }
-    const float inv = 1.f / (float)C;
-    a0 *= inv; b0 *= inv; a1 *= inv; b1 *= inv;
+    a0 /= (float)C; b0 /= (float)C; a1 /= (float)C; b1 /= (float)C;      // as ln_bwd_kernel: bit-identical outputs
     if (ok) {
       dg.x += d0.x * xh0.x; dg.y += d0.y * xh0.y; dg.z += d0.z * xh0.z; dg.w += d0.w * xh0.w;
       db.x += d0.x; db.y += d0.y; db.z += d0.z; db.w += d0.w;

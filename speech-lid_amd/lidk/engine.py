@@ -237,6 +237,9 @@ class _Work:
         self.logits: Dict[str, torch.Tensor] = {}
 
 
+_WGRAD_WGS = int(__import__("os").environ.get("LIDK_WGRAD_WGS", "512"))      # workgroups a weight-gradient launch aims for (tuning knob)
+
+
 class Engine:
     def __init__(self, cfg: ConformerCfg, act_dtype=torch.bfloat16, backend=None):
         self.cfg = cfg
@@ -635,7 +638,7 @@ class Engine:
         """Split of the M = B*T contraction for a [n, k] weight gradient: enough workgroups to fill 256 CUs, but few enough
         that the float-atomic traffic (splitk * |dW|) stays small next to the operand reads."""
         tiles = -(-n // 64) * -(-k // 64)
-        return max(1, min(16, round(512 / tiles)))
+        return max(1, min(16, round(_WGRAD_WGS / tiles)))
 
     def _fork(self):
         """Context for work that may overlap the main stream from here on: the side stream first waits for everything

@@ -753,7 +753,11 @@ def test_ln_gemm_matches_layernorm_then_gemm(mode, M, N):
     pre1 = torch.zeros_like(out0) if mode == "bias_swish_pre" else None
     ops.ln_gemm_nt(x, gamma, beta, W, out1, h=h1, mean=mean1, rstd=rstd1, bias=bias, act=act, out2=pre1, aux=aux)
     torch.cuda.synchronize()
-    assert torch.equal(h0, h1) and torch.equal(mean0, mean1) and torch.equal(rstd0, rstd1)
+    # the same formulas in two kernels (the standalone LayerNorm now walks two rows per wave): statistics agree to f32 rounding,
+    # the bf16 h to one ulp on a vanishing fraction of elements
+    assert float((mean0 - mean1).abs().max()) <= 1e-6 and float(((rstd0 - rstd1) / rstd0).abs().max()) <= 1e-6
+    dh = (h0.float() - h1.float()).abs()
+    assert float(dh.max()) <= 2.0 ** -7 * float(h0.float().abs().max()) and float((dh > 0).float().mean()) < 1e-3
     scale = float(out0.float().abs().max())
     err = float((out0.float() - out1.float()).abs().max())
     print(f"[ln_gemm {mode} M={M} N={N}] max |fused - unfused| = {err:.3e} (max |out| {scale:.2f})")
@@ -771,7 +775,7 @@ def test_ln_gemm_matches_layernorm_then_gemm(mode, M, N):
     assert float((out1.float() - ref).abs().max()) <= 3e-2 * max(1.0, float(ref.abs().max()))
     # the same kernel without LayerNorm, on the bf16 operand
     out2 = torch.zeros_like(out0)
-    ops.ln_gemm_nt(None, None, None, W, out2, A=h0, bias=bias, act=act, out2=pre1, aux=aux)
+    ops.ln_gemm_nt(None, None, None, W, out2, A=h1, bias=bias, act=act, out2=pre1, aux=aux)       # h1: the panel kernel's own h
     assert torch.equal(out1, out2)
 
 

@@ -30,7 +30,7 @@ def show(name, us, mbytes):
 
 g_, c_, dc_, dg_ = bf(M, ci), bf(M, ci), bf(M, ci), bf(M, ci)
 w, bias = f32(ci, K), f32(ci)
-parts = ops.dwconv_stat_parts(B, T, C, torch.bfloat16)
+parts = ops.dwconv_stat_parts(B, T, ci, torch.bfloat16)
 stat = torch.empty(parts * 2 * ci, device=dev)
 show("dwconv fwd (+BN partial sums)", t(lambda: ops.dwconv_fwd(g_, w, bias, c_, stat, B, T, K // 2)), 2 * M * ci * 2 / 1e6)
 show("dwconv fwd (no stats)", t(lambda: ops.dwconv_fwd(g_, w, bias, c_, None, B, T, K // 2)), 2 * M * ci * 2 / 1e6)
