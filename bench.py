@@ -23,9 +23,9 @@ two barrier + synchronize brackets, max over ranks) plus:
                   path (normalize, dither/pre-emphasis, STFT/mel/dB/SpecAugment: 4 L + 4*80 F bytes per utterance) likewise.
                   ``traffic`` comes from a committed rocprofv3 --pmc pass of this command (``traffic_source`` names the file);
                   it is not measured by this process
-  val_cavg      : (N = 1) the model keeps training on the learnable synthetic corpus for --cavg-steps more steps, then the
-                  held-out set is scored through the module's own val_loop (all 14 heads, CTC-confidence LID score,
-                  lid/eer.py::CAvg)
+  val_cavg      : (N = 1) the model keeps training on the learnable synthetic corpus (peak LR held until the CTC loss leaves its
+                  plateau, then --cavg-decay steps of decay; at most --cavg-steps), then the held-out set is scored through
+                  the module's own val_loop (all 14 heads, CTC-confidence LID score, lid/eer.py::CAvg)
   fit           : (N = 1) the same training through Trainer.fit INCLUDING DataLoader workers, collate, pinned H2D copies
                   (what a user of the launcher gets from in-memory data); never used for ``value``
   cpu_baseline  : the CPU oracle (oracle/, torch fp32) running the same step on all of this host's cores, bounded sample
@@ -423,18 +423,44 @@ def phase_times(trainer, batches, step_fn):
 
 def cavg_phase(args, module, trainer, batches, step_fn, first_step):
     """Keep training on the learnable corpus (the timed steps were ordinary training steps of the same run), then score the
-    held-out utterances through the module's own validation loop."""
+    held-out utterances through the module's own validation loop.
+
+    The learning-rate recipe of this phase is the harness's own (the reference's TriStage is a function of a step count fixed
+    in advance, and the step at which CTC leaves its "right number of tokens, random identities" plateau - loss ~ text_len *
+    ln(vocab) - varies from run to run): ramp to the peak LR, HOLD it until the smoothed training loss has fallen below a
+    third of that plateau, then decay exponentially to 2 % of the peak over --cavg-decay steps; --cavg-steps caps the phase."""
+    import math
     t0 = time.perf_counter()
-    last = None
+    peak, ramp = float(args.lr), 300
+    groups = trainer.optimizer.param_groups
+    lr0 = float(groups[0]["lr"])
+    trainer.lr_scheduler = None                              # this phase sets the learning rate itself
+    text_len = int(batches[0][1].shape[1]) if hasattr(batches[0][1], "shape") else 20
+    vocab = max(int(v) for v in module.model.cfg.lang2vocab.values())
+    plateau = text_len * math.log(max(vocab, 2))                 # loss of "right token count, uniform identities"
+    recent, broke_at, last, steps_run = [], None, None, 0
     for i in range(args.cavg_steps):
+        if broke_at is None:
+            lr = lr0 + (peak - lr0) * min(1.0, (i + 1) / ramp)
+        else:
+            lr = peak * 0.02 ** min(1.0, (i - broke_at) / max(args.cavg_decay, 1))
+        for g in groups:
+            g["lr"] = lr
         out, loss, _ = step_fn(first_step + i, batches[i % len(batches)], batches[(i + 1) % len(batches)])
-        last = loss
+        last, steps_run = loss, i + 1
+        if (i + 1) % 25 == 0:                                # one host read of the loss every 25 steps
+            recent = (recent + [float(loss)])[-8:]
+            if broke_at is None and len(recent) == 8 and sum(recent) / 8 < plateau / 3:
+                broke_at = i
+                log(f"cavg phase: plateau left at extra step {i + 1} (smoothed loss {sum(recent) / 8:.2f} < {plateau / 3:.1f}); decaying")
         if (i + 1) % 500 == 0:
-            log(f"cavg phase: {i + 1}/{args.cavg_steps} extra steps, loss {float(loss):.3f}, lr {trainer.optimizer.param_groups[0]['lr']:.5f}")
+            log(f"cavg phase: {i + 1} extra steps, loss {float(loss):.3f}, lr {lr:.5f}")
         if args.cavg_eval_every > 0 and (i + 1) % args.cavg_eval_every == 0 and i + 1 < args.cavg_steps:
             trainer._evaluate(0)                       # exploration aid: intermediate validation (not part of the default run)
             log(f"cavg phase: step {i + 1} validation {module.last_val}")
             trainer.model.train()
+        if broke_at is not None and i - broke_at >= args.cavg_decay:
+            break
     torch.cuda.synchronize()
     train_s = time.perf_counter() - t0
     t1 = time.perf_counter()
@@ -444,11 +470,13 @@ def cavg_phase(args, module, trainer, batches, step_fn, first_step):
     log(f"cavg phase: validation {val}")
     return {"val_cavg": val["cavg"], "val_eer": round(float(val["eer"]), 4), "val_cer": round(float(val["val_wer"]), 4),
             "val_loss": round(float(val["val_loss"]), 4), "train_loss_last": round(float(last), 4) if last is not None else None,
-            "optimizer_steps_total": int(trainer.current_step), "extra_train_steps": args.cavg_steps,
+            "optimizer_steps_total": int(trainer.current_step), "extra_train_steps": steps_run,
+            "plateau_left_at_extra_step": None if broke_at is None else broke_at + 1,
             "extra_train_seconds": round(train_s, 1), "validation_seconds": round(time.perf_counter() - t1, 1),
             "held_out_utterances": len(trainer.val_dataset), "chance": 0.5,
-            "note": "learnable synthetic corpus (tone-pair transcripts, language-specific symbol tables); CTC-confidence LID "
-                    "score of all 14 heads per utterance -> score_to_prob -> lid/eer.py::CAvg"}
+            "note": "learnable synthetic corpus (tone-pair transcripts, language-specific symbol tables); peak LR held until the "
+                    "CTC loss leaves its plateau, then decayed; CTC-confidence LID score of all 14 heads per utterance -> "
+                    "score_to_prob -> lid/eer.py::CAvg"}
 
 
 class _EpochTimer:
@@ -514,14 +542,17 @@ def main():
     ap.add_argument("--chunks", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--blocks", type=int, default=12)
-    ap.add_argument("--lr", type=float, default=0.01)
-    ap.add_argument("--resident", type=int, default=2, help="resident batches per language")
+    ap.add_argument("--lr", type=float, default=0.003,
+                    help="peak Novograd LR.  0.003: on the synthetic corpus CTC leaves its plateau reliably after ~1.2-1.4 k steps; at the "
+                         "config file's 0.01 that is a coin flip and at >= 0.03 it never does (profiles/r02/cavg_runs.txt)")
+    ap.add_argument("--resident", type=int, default=4, help="resident batches per language (256 utterances per language at batch 64)")
     ap.add_argument("--val-items", type=int, default=16, help="held-out utterances per language")
     ap.add_argument("--stochastic-depth", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cavg-steps", type=int, default=5000, help="extra training steps before the validation Cavg (0 = skip)")
+    ap.add_argument("--cavg-steps", type=int, default=10000, help="cap on the extra training steps before the validation Cavg (0 = skip)")
+    ap.add_argument("--cavg-decay", type=int, default=1500, help="LR decay steps once the CTC loss has left its plateau")
     ap.add_argument("--cavg-eval-every", type=int, default=0, help="also validate every K extra steps (exploration aid)")
     ap.add_argument("--fit-epochs", type=int, default=4, help="epochs of the Trainer.fit measurement (0 = skip)")
     ap.add_argument("--fit-workers", type=int, default=4)
