@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""lidk_gemm_nt on the WavLM conv feature extractor's shapes (strided-view convolutions, B = 64 x 3 s): per-layer time and TF/s.
+Env LIDK_GEMM_DIRECT=0 LIDK_GEMM_TILE=128 selects the 128x128-tile kernel for comparison."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "speech-lid_amd")]
+import torch
+from lidk import ops, _lib as L
+
+dev = "cuda:0"
+B, C = 64, 512
+
+
+def t(fn, n=5):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+P = [9600, 4800, 2400, 1200, 600, 300, 150]
+tot = 0.0
+for l in range(1, 7):
+    kw = 3 if l < 5 else 2
+    rows_in = B * P[l - 1] + 8
+    x = torch.randn(rows_in, C, device=dev).bfloat16()
+    W = (torch.randn(C, kw * C, device=dev) / (kw * C) ** 0.5).bfloat16()
+    M = B * P[l]
+    A = x.as_strided((M, kw * C), (2 * C, 1))
+    out = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+    us = t(lambda: ops.gemm_nt(A, W, out, act=L.ACT_GELU))
+    fl = 2.0 * M * C * kw * C
+    tot += us
+    print(f"conv layer {l}: M={M:7d} N={C} K={kw * C}: {us:9.1f} us  {fl / us / 1e6:7.1f} TF/s")
+print(f"conv layers 1-6 total {tot / 1e3:.2f} ms")
