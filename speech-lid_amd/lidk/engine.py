@@ -540,6 +540,13 @@ class Engine:
             self._ff_fwd(bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.x4, bb.mean[3], bb.rstd[3])
         return bb.x4
 
+    def _whole_graphs(self, keep) -> bool:
+        """One captured sequence for all encoder blocks (forward) / the whole block chain (backward): only without data
+        parallelism (no collective cuts the sequence), with every block kept (stochastic depth changes the sequence from step
+        to step) and with graphs on.  LIDK_WHOLE_GRAPHS=0 restores one graph per block."""
+        return (self.graphs.enabled and self.stat_allreduce is None and self.on_stage_grads_ready is None
+                and self.cfg.n_blocks > 0 and all(keep) and _os_env("LIDK_WHOLE_GRAPHS", "1") == "1")
+
     def _fused_bn_stats(self) -> bool:
         return self.stat_allreduce is None and hasattr(self.k, "bn_train_stats_from_partials")
 
@@ -613,12 +620,27 @@ class Engine:
         seed = (self.seed * 1000003 + self.step_count) & 0x7FFFFFFFFFFF
         x = self._front_fwd(w, mel, training, seed)
         keep = keep_layers if (training and keep_layers is not None) else [True] * self.cfg.n_blocks
-        for i in range(self.cfg.n_blocks):
-            if not keep[i]:
-                continue
-            self._run_split(("ef", id(w), i, x.data_ptr(), training), lambda part: self._enc_block_fwd(x, i, w, training, part),
-                            self._bn_collective(w, self.enc_params[i].conv["dw"].shape[0], training))
-            x = w.enc[i].out
+        if self._whole_graphs(keep):
+            # single process, every block kept: the whole encoder forward is ONE captured sequence (12 x 19 launches, one host
+            # call) instead of one per block - the host then issues ~20 calls per step instead of ~60
+            x_first = x
+
+            def enc_all():
+                xx = x_first
+                for i in range(self.cfg.n_blocks):
+                    self._enc_block_fwd(xx, i, w, training, "all")
+                    xx = w.enc[i].out
+
+            self.graphs.run(("efA", id(w), x.data_ptr(), training), enc_all)
+            x = w.enc[self.cfg.n_blocks - 1].out
+        else:
+            for i in range(self.cfg.n_blocks):
+                if not keep[i]:
+                    continue
+                self._run_split(("ef", id(w), i, x.data_ptr(), training),
+                                lambda part: self._enc_block_fwd(x, i, w, training, part),
+                                self._bn_collective(w, self.enc_params[i].conv["dw"].shape[0], training))
+                x = w.enc[i].out
         out = {}
         langs = [lang] if lang is not None else list(self.cfg.lang2vocab)
         for l in langs:
@@ -787,6 +809,36 @@ class Engine:
                                        and self.k.attn_bwd_relpos_supported(T, dh, self.act_dtype))
         return self._split_ok[key]
 
+    def _backward_blocks(self, w: _Work, blocks, dfeat, defer: bool):
+        """One captured sequence per block (cut at the SyncBatchNorm all-reduce under data parallelism)."""
+        prev = None                                  # (tag, bp, bb, S, stage)
+        for n, (kind, tag, bpk, bbk, x_in, stage) in enumerate(blocks):
+            S = w.sets[n & 1]
+
+            def fn(part, kind=kind, tag=tag, bpk=bpk, bbk=bbk, x_in=x_in, S=S, prev=prev):
+                if prev is not None and part in ("all", "a"):
+                    with self._fork():
+                        self._block_wgrads(w, prev[1], prev[2], prev[3], prev[0][0] == "enc")
+                if kind == "head":
+                    self._block_bwd(w, x_in, bpk, bbk, w.dxa, S, dfeat, part, not defer)
+                else:
+                    self._enc_block_bwd(dfeat, x_in, tag, w, dfeat, part, S, not defer)
+                if prev is not None and part in ("all", "a"):
+                    self._join()
+
+            key = ("bb", id(w), kind, tag, x_in.data_ptr(), n & 1, prev[0] if prev else None)
+            self._run_split(key, fn, self._bn_collective(w, bpk.conv["dw"].shape[0], sums=S.sums))
+            if defer:
+                if prev is not None and self.on_stage_grads_ready:
+                    self.on_stage_grads_ready(prev[4])
+                prev = ((kind, tag), bpk, bbk, S, stage)
+            elif self.on_stage_grads_ready:
+                self.on_stage_grads_ready(stage)
+        if prev is not None:
+            self._block_wgrads(w, prev[1], prev[2], prev[3], prev[0][0] == "enc")
+            if self.on_stage_grads_ready:
+                self.on_stage_grads_ready(prev[4])
+
     def backward(self, dlogits: torch.Tensor):
         """dlogits (B, T, V+1) f32 for the language of the last training forward.  Accumulates into ``grad``."""
         ctx = self._ctx
@@ -827,33 +879,30 @@ class Engine:
             i = kept[idx]
             x_in = w.enc[kept[idx - 1]].out if idx > 0 else (w.x0d if (cfg.pos_dropout > 0) else w.x0)
             blocks.append(("enc", i, self.enc_params[i], w.enc[i], x_in, f"enc.{i}"))
-        prev = None                                  # (tag, bp, bb, S, stage)
-        for n, (kind, tag, bpk, bbk, x_in, stage) in enumerate(blocks):
-            S = w.sets[n & 1]
+        if self._whole_graphs(ctx["keep"]):
+            # the whole chain - every block's dgrad sequence with the previous block's weight gradients forked beside it, and
+            # the last block's weight gradients - as one captured sequence per (workspace, language)
+            def bwd_all():
+                prv = None
+                for n, (kind, tag, bpk, bbk, x_in, stage) in enumerate(blocks):
+                    S = w.sets[n & 1]
+                    if prv is not None:
+                        with self._fork():
+                            self._block_wgrads(w, prv[1], prv[2], prv[3], prv[0][0] == "enc")
+                    if kind == "head":
+                        self._block_bwd(w, x_in, bpk, bbk, w.dxa, S, dfeat, "all", not defer)
+                    else:
+                        self._enc_block_bwd(dfeat, x_in, tag, w, dfeat, "all", S, not defer)
+                    if prv is not None:
+                        self._join()
+                    if defer:
+                        prv = ((kind, tag), bpk, bbk, S, stage)
+                if prv is not None:
+                    self._block_wgrads(w, prv[1], prv[2], prv[3], prv[0][0] == "enc")
 
-            def fn(part, kind=kind, tag=tag, bpk=bpk, bbk=bbk, x_in=x_in, S=S, prev=prev):
-                if prev is not None and part in ("all", "a"):
-                    with self._fork():
-                        self._block_wgrads(w, prev[1], prev[2], prev[3], prev[0][0] == "enc")
-                if kind == "head":
-                    self._block_bwd(w, x_in, bpk, bbk, w.dxa, S, dfeat, part, not defer)
-                else:
-                    self._enc_block_bwd(dfeat, x_in, tag, w, dfeat, part, S, not defer)
-                if prev is not None and part in ("all", "a"):
-                    self._join()
-
-            key = ("bb", id(w), kind, tag, x_in.data_ptr(), n & 1, prev[0] if prev else None)
-            self._run_split(key, fn, self._bn_collective(w, bpk.conv["dw"].shape[0], sums=S.sums))
-            if defer:
-                if prev is not None and self.on_stage_grads_ready:
-                    self.on_stage_grads_ready(prev[4])
-                prev = ((kind, tag), bpk, bbk, S, stage)
-            elif self.on_stage_grads_ready:
-                self.on_stage_grads_ready(stage)
-        if prev is not None:
-            self._block_wgrads(w, prev[1], prev[2], prev[3], prev[0][0] == "enc")
-            if self.on_stage_grads_ready:
-                self.on_stage_grads_ready(prev[4])
+            self.graphs.run(("bbA", id(w), lang, feat.data_ptr()), bwd_all)
+        else:
+            self._backward_blocks(w, blocks, dfeat, defer)
         dy = dfeat                                   # f32 gradient at the first block's input (after pos-enc dropout)
         if cfg.front != "subsample":                 # backbone features: hand d(loss)/d(features) to the caller
             return dfeat[:M].view(ctx["front_in"].shape)

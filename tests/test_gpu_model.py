@@ -180,8 +180,11 @@ def test_own_dropout_masks_are_consistent_between_fwd_and_bwd():
     assert float((got - want).norm() / want.norm()) < 2e-3
 
 
-def test_graph_replay_matches_eager(cfg1_weights):
-    """Block sequences replayed from captured hipGraphs must give what the eager launch path gives (third call = replay)."""
+@pytest.mark.parametrize("whole", ["1", "0"])
+def test_graph_replay_matches_eager(cfg1_weights, whole, monkeypatch):
+    """Sequences replayed from captured hipGraphs must give what the eager launch path gives (third call = replay): with the
+    whole encoder forward / whole backward chain as one graph each (single-process default) and with one graph per block."""
+    monkeypatch.setenv("LIDK_WHOLE_GRAPHS", whole)
     g = load_npz("cfg1_trainA.npz")
     mel = torch.from_numpy(load_npz("cfg1_eval.npz")["mel"]).to(DEV)
     results = []
@@ -197,7 +200,8 @@ def test_graph_replay_matches_eager(cfg1_weights):
             eng.backward(dl)
         torch.cuda.synchronize()
         if graphs:
-            assert sum(1 for st in eng.graphs.state.values() if st[0] is not None) >= 6
+            captured = sum(1 for st in eng.graphs.state.values() if st[0] is not None)
+            assert captured == 3 if whole == "1" else captured >= 6          # encoder forward, head forward, backward chain
         results.append((logits.cpu(), eng.grad.cpu().clone(), {k: v.cpu().clone() for k, v in eng.buffers.items()}))
     (l0, g0, b0), (l1, g1, b1) = results
     assert torch.equal(l0, l1)

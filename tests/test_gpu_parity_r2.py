@@ -54,7 +54,7 @@ def test_cfg2_own_shape_training_step_against_the_reference(cfg2_inputs, dt):
         ops.ctc_loss(out.contiguous(), texts_d, in_len, tg_len, per, dl, ws, 40, grad_scale=1.0 / B)
         eng.backward(dl)
     torch.cuda.synchronize()
-    assert sum(1 for st in eng.graphs.state.values() if st[0] is not None) >= 26          # 13 blocks fwd + 13 bwd
+    assert sum(1 for st in eng.graphs.state.values() if st[0] is not None) == 3       # encoder forward, head forward, whole backward chain
     f32 = dt == torch.float32
     assert out.shape == (B, T, 41) and bool(torch.isfinite(out).all()) and bool(torch.isfinite(per).all())
     # ---- logits and loss

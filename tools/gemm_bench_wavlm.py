@@ -36,3 +36,20 @@ for l in range(1, 7):
     tot += us
     print(f"conv layer {l}: M={M:7d} N={C} K={kw * C}: {us:9.1f} us  {fl / us / 1e6:7.1f} TF/s")
 print(f"conv layers 1-6 total {tot / 1e3:.2f} ms")
+
+print("transformer layer GEMMs (M = 64 x 149 = 9536, d = 768, ffn 3072)")
+M = 64 * 149
+def run(name, m, n, k, **kw):
+    A = torch.randn(m, k, device=dev).bfloat16(); Bm = (torch.randn(n, k, device=dev) / k ** 0.5).bfloat16()
+    bias = torch.randn(n, device=dev)
+    f32 = kw.pop("out_f32", False)
+    out = torch.empty(m, n, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+    extra = {}
+    if kw.pop("res", False): extra["res"] = torch.randn(m, n, device=dev)
+    if kw.get("act") == L.ACT_GELU: extra["out2"] = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+    us = t(lambda: ops.gemm_nt(A, Bm, out, bias=bias, **kw, **extra), n=10)
+    print(f"{name:22s} M={m} N={n:5d} K={k:5d}: {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF/s")
+run("qkv", M, 2304, 768)
+run("out (+res f32)", M, 768, 768, res=True, out_f32=True)
+run("fc1 (gelu, +pre)", M, 3072, 768, act=L.ACT_GELU)
+run("fc2 (+res f32)", M, 768, 3072, res=True, out_f32=True)
