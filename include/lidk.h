@@ -312,6 +312,14 @@ int lidk_wavlm_posconv_dprep(const float* dy, const void* pre, void* dpc, void* 
                              long rows_total, void* stream);
 int lidk_wavlm_attn_fwd(const void* qkv, const float* gate, const float* rb, void* out, int B, int T, int H, int dh, int RB,
                         void* stream);
+/* Training form of lidk_wavlm_attn_fwd: also writes probs [B][H][T][ldp] bf16 (ldp = lidk_wavlm_attn_ldp(T)) for the backward pass. */
+int lidk_wavlm_attn_fwd_probs(const void* qkv, const float* gate, const float* rb, void* out, void* probs, int B, int T, int H, int dh,
+                              int RB, void* stream);
+/* Gradients of the gated relative bias from dS [B][H][T][ldp] bf16 as lidk_attn_bwd (drel_emb = NULL, zero relative-position
+ * table) leaves it: dgate [B][H][T] written, drb [H][2*RB-1] accumulated.  With lidk_attn_bwd for dQ/dK/dV this is the autograd of
+ * lid/wavlm/modules.py:505-560 on the MFMA path. */
+int lidk_wavlm_attn_bias_grads(const void* ds, const float* gate, const float* rb, float* dgate, float* drb, int B, int T, int H,
+                               int RB, int ldp, void* stream);
 
 /* ------------------------------------------------------------------ fused clip + Novograd over the flat arenas
  * ccml/trainer.py:541-543 clip_grad_norm_(max_norm) + ccml/optim/novograd.py:75-145 (amsgrad=False, luc=False).

@@ -209,10 +209,10 @@ extern "C" int lidk_wavlm_gate(const float* x, const float* wg, const float* bg,
 // scores[i][j] = scale * q_i.k_j + gate[b][h][i] * rb[h][j - i] ; probs = softmax_j ; out = probs.v
 // qkv [B*T][3*H*DH] bf16 (q | k | v column blocks, head h at columns h*DH); rb [H][2*RB-1] f32, entry r + RB - 1 for offset r = j - i.
 #define WA_KPAD 8
-template <int DH>
+template <int DH, bool WP>         // WP: also write the probabilities (training: the backward pass reads them)
 __global__ void __launch_bounds__(1024)
 wavlm_attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ gate, const float* __restrict__ rb,
-                      bf16* __restrict__ out, int T_, int H, int RB, float scale, int NJ) {
+                      bf16* __restrict__ out, bf16* __restrict__ probs, int T_, int H, int RB, float scale, int NJ) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Tp = NJ * 16, Tp32 = (Tp + 31) / 32 * 32, LDK = DH + WA_KPAD, LDV = Tp32 + WA_KPAD;
   bf16* Ks = reinterpret_cast<bf16*>(smem);                      // [Tp][LDK]
@@ -303,6 +303,14 @@ wavlm_attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ ga
       for (int r = 0; r < 4; ++r) P[(4 * fq + r) * LDV + Tp + fr] = (bf16)0.f;
     }
     __builtin_amdgcn_wave_barrier();
+    if (WP) {                                             // probs [B][H][T][Tp32] bf16: this wave's 16 rows, 16 bytes per store
+      const int cpr = Tp32 / 8;
+      for (int c = lane; c < 16 * cpr; c += 64) {
+        const int rr = c / cpr, cc = (c - rr * cpr) * 8, i = i0 + rr;
+        if (i < T_)
+          *reinterpret_cast<uint4*>(probs + (((size_t)b * H + h) * T_ + i) * Tp32 + cc) = *reinterpret_cast<const uint4*>(&P[rr * LDV + cc]);
+      }
+    }
     // ---- O = P.V : A = P rows (queries, k = keys), B = V^T rows (d, k = keys)
     f32x4 O[DH / 16];
 #pragma unroll
@@ -340,9 +348,24 @@ extern "C" int lidk_wavlm_attn_fwd(const void* qkv, const float* gate, const flo
   while (nw > 1 && wavlm_attn_lds(NJ, 64, nw) > 160 * 1024) --nw;
   const size_t lds = wavlm_attn_lds(NJ, 64, nw);
   if (lds > 160 * 1024) return LIDK_ERR_UNSUPPORTED;
-  (void)hipFuncSetAttribute((const void*)wavlm_attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  wavlm_attn_fwd_kernel<64><<<B * H, 64 * nw, lds, as_stream(stream)>>>((const bf16*)qkv, gate, rb, (bf16*)out, T_, H, RB,
-                                                                        1.0f / sqrtf(64.0f), NJ);
+  (void)hipFuncSetAttribute((const void*)wavlm_attn_fwd_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  wavlm_attn_fwd_kernel<64, false><<<B * H, 64 * nw, lds, as_stream(stream)>>>((const bf16*)qkv, gate, rb, (bf16*)out, nullptr, T_, H,
+                                                                               RB, 1.0f / sqrtf(64.0f), NJ);
+  return launch_status();
+}
+// The same forward, also storing probs [B][H][T][ldp] bf16 (ldp = lidk_wavlm_attn_ldp(T)) for the backward pass.
+extern "C" int lidk_wavlm_attn_fwd_probs(const void* qkv, const float* gate, const float* rb, void* out, void* probs, int B, int T_,
+                                         int H, int dh, int RB, void* stream) {
+  if (!qkv || !gate || !rb || !out || !probs || B <= 0 || T_ <= 0 || H <= 0 || RB < T_) return LIDK_ERR_ARG;
+  if (dh != 64 || T_ > 256) return LIDK_ERR_UNSUPPORTED;
+  const int NJ = cdiv(T_, 16);
+  int nw = NJ < 16 ? NJ : 16;
+  while (nw > 1 && wavlm_attn_lds(NJ, 64, nw) > 160 * 1024) --nw;
+  const size_t lds = wavlm_attn_lds(NJ, 64, nw);
+  if (lds > 160 * 1024) return LIDK_ERR_UNSUPPORTED;
+  (void)hipFuncSetAttribute((const void*)wavlm_attn_fwd_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  wavlm_attn_fwd_kernel<64, true><<<B * H, 64 * nw, lds, as_stream(stream)>>>((const bf16*)qkv, gate, rb, (bf16*)out, (bf16*)probs, T_,
+                                                                              H, RB, 1.0f / sqrtf(64.0f), NJ);
   return launch_status();
 }
 
@@ -533,6 +556,46 @@ extern "C" int lidk_wavlm_attn_bwd(const void* qkv, const void* probs, const voi
   const int items = (T_ + 63) / 64 + (2 * T_ - 1 + 63) / 64;
   wavlm_attn_bwd_cols_kernel<64><<<dim3(B * H, cdiv(items, 4)), 256, 0, s>>>(
       (const bf16*)qkv, (const bf16*)probs, (const bf16*)dout, dscores, gate, (bf16*)dqkv, drb, T_, H, RB, ldp, 0.125f);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ gradients of the gated bias
+// From dS [B][H][T][ldp] bf16 (left behind by lidk_attn_bwd's MFMA path, which computes dQ/dK/dV: with a zero relative-position
+// table the Conformer's attention backward IS this layer's - the additive bias only enters through the saved probabilities):
+//   dgate[b][h][i] = sum_j dS[i][j] rb[h][j - i]          drb[h][r] += sum_{b,i} gate[b][h][i] dS[i][i + r]
+// One workgroup per (b, h), one wave per row; the per-offset sums meet in LDS (float atomics on distinct addresses within a
+// wave) and leave through one global atomic per offset.
+__global__ void __launch_bounds__(256)
+wavlm_attn_bias_grads_kernel(const bf16* __restrict__ ds, const float* __restrict__ gate, const float* __restrict__ rb,
+                             float* __restrict__ dgate, float* __restrict__ drb, int T_, int H, int RB, int ldp) {
+  extern __shared__ float acc[];                        // [2*T - 1]: offset r + T - 1
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  for (int i = threadIdx.x; i < 2 * T_ - 1; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  const float* rbh = rb + (size_t)h * (2 * RB - 1) + RB - 1;
+  const float* grow = gate + ((size_t)b * H + h) * T_;
+  const bf16* base = ds + ((size_t)b * H + h) * T_ * ldp;
+  for (int i = wave; i < T_; i += 4) {
+    const float gi = grow[i];
+    float dg = 0.f;
+    for (int j = lane; j < T_; j += 64) {
+      const float v = to_f(base[(size_t)i * ldp + j]);
+      dg = fmaf(v, rbh[j - i], dg);
+      atomicAdd(&acc[j - i + T_ - 1], gi * v);
+    }
+    dg = wave_sum(dg);
+    if (lane == 0) dgate[((size_t)b * H + h) * T_ + i] = dg;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * T_ - 1; i += blockDim.x)
+    if (acc[i] != 0.f) atomicAdd(&drb[(size_t)h * (2 * RB - 1) + (i - (T_ - 1)) + RB - 1], acc[i]);
+}
+extern "C" int lidk_wavlm_attn_bias_grads(const void* ds, const float* gate, const float* rb, float* dgate, float* drb, int B, int T_,
+                                          int H, int RB, int ldp, void* stream) {
+  if (!ds || !gate || !rb || !dgate || !drb || B <= 0 || T_ <= 0 || H <= 0 || RB < T_ || ldp < T_) return LIDK_ERR_ARG;
+  wavlm_attn_bias_grads_kernel<<<B * H, 256, (size_t)(2 * T_ - 1) * 4, as_stream(stream)>>>((const bf16*)ds, gate, rb, dgate, drb, T_,
+                                                                                            H, RB, ldp);
   return launch_status();
 }
 

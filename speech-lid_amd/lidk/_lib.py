@@ -95,6 +95,8 @@ SIGNATURES = {
     "lidk_wavlm_gate_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "lidk_wavlm_posconv_dprep": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _P]),
     "lidk_wavlm_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lidk_wavlm_attn_fwd_probs": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lidk_wavlm_attn_bias_grads": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lidk_ctc_greedy": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "lidk_lid_mlp": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_novograd_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P]),

@@ -510,11 +510,25 @@ def wavlm_attn_max_frames(dh):
     return lib().lidk_wavlm_attn_max_frames(dh)
 
 
-def wavlm_attn_fwd(qkv, gate, rb, out, B, T, H, dh):
-    """rb (H, 2*RB-1) f32: the head's bias as a function of the offset j - i (entry r + RB - 1)."""
+def wavlm_attn_fwd(qkv, gate, rb, out, B, T, H, dh, probs=None):
+    """rb (H, 2*RB-1) f32: the head's bias as a function of the offset j - i (entry r + RB - 1).  probs (B, H, T, ldp) bf16
+    (training): the softmax probabilities are written too, for the backward pass."""
     RB = (rb.shape[1] + 1) // 2
-    check(lib().lidk_wavlm_attn_fwd(_p(qkv), _p(gate), _p(rb), _p(out), B, T, H, dh, RB, _stream()), "wavlm_attn_fwd")
+    if probs is None:
+        check(lib().lidk_wavlm_attn_fwd(_p(qkv), _p(gate), _p(rb), _p(out), B, T, H, dh, RB, _stream()), "wavlm_attn_fwd")
+    else:
+        if probs.shape[-1] != wavlm_attn_ldp(T) or probs.dtype != torch.bfloat16:
+            raise LidkError("wavlm_attn_fwd: probs must be bf16 with last dimension wavlm_attn_ldp(T)")
+        check(lib().lidk_wavlm_attn_fwd_probs(_p(qkv), _p(gate), _p(rb), _p(out), _p(probs), B, T, H, dh, RB, _stream()),
+              "wavlm_attn_fwd_probs")
     return out
+
+
+def wavlm_attn_bias_grads(ds, gate, rb, dgate, drb, B, T, H, ldp):
+    """dgate / drb from the bf16 dS rows an ``attn_bwd(..., drel_emb=None)`` call left in its scratch buffer."""
+    RB = (rb.shape[1] + 1) // 2
+    check(lib().lidk_wavlm_attn_bias_grads(_p(ds), _p(gate), _p(rb), _p(dgate), _p(drb), B, T, H, RB, ldp, _stream()),
+          "wavlm_attn_bias_grads")
 
 
 def wavlm_attn_ldp(T):

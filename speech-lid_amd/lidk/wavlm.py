@@ -198,6 +198,8 @@ class WavLMBackbone:
         bucket = relative_buckets(r, self.cfg.get("num_buckets", 320), self.cfg.get("max_distance", 800))
         W["rb"] = emb[bucket].t().contiguous()                                   # [H][2*RB-1], entry r + RB - 1
         W["rb_bucket"] = bucket
+        W["zero_emb"] = torch.zeros(2 * 256 + 1, self.dh, device=dev)          # operands of the MFMA attention backward
+        W["zero_embT"] = torch.zeros(2 * 256 + 1, self.dh, device=dev, dtype=bf)
         W["mask_emb"] = g("mask_emb")
         W["proj_wT"] = W["proj_w"].t().contiguous()                              # data gradient of post_extract_proj
         # pos-conv data gradient = the same strided-view GEMM with the kernel flipped: [c][j'*cg + o] = w[o][c][k-1-j']
@@ -287,7 +289,7 @@ class WavLMBackbone:
         Pp = ws["Pp"]
         sv = dict(layers=layers, y0=f(M, d), mean0=f(M), rstd0=f(M), pcp=e(B * Pp, d),
                   dxa=f(M, d), dxb=f(M, d), da=f(M, d), dab=e(M, d), dpre=e(M, self.ffn), dx1=f(M, d), db=f(M, d), dbb=e(M, d),
-                  do=e(M, d), dqkv=e(M, 3 * d), dgate=f(B, H, Tn), dsc=f(B, H, Tn, Tn), partial=f(L.LN_BWD_BLOCKS * 2 * d),
+                  do=e(M, d), dqkv=e(M, 3 * d), dgate=f(B, H, Tn), dsc=f(B, H, Tn, ldp), partial=f(L.LN_BWD_BLOCKS * 2 * d),
                   dpc=torch.zeros(B * Pp + self.kpos, d, device=dev, dtype=bf), dy0=f(M, d),
                   dpg=torch.zeros(self.gpos, B * Pp + self.kpos, d // self.gpos, device=dev, dtype=bf), dxp=f(B * Pp, d),
                   dxc=f(M, self.C))
@@ -409,8 +411,7 @@ class WavLMBackbone:
             xo32, xob = (nxt["xin"], nxt["xinb"]) if nxt is not None else (ws["x"], ws["xb"])
             k.gemm_nt(S["xinb"], Lw_["wqkv"], S["qkv"], bias=Lw_["bqkv"])
             k.wavlm_gate(S["xin"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], S["gate"], B, Tn, self.H, self.dh)
-            k.wavlm_attn_probs(S["qkv"], S["gate"], W["rb"], S["probs"], B, Tn, self.H, self.dh)
-            k.wavlm_attn_fwd(S["qkv"], S["gate"], W["rb"], S["o"], B, Tn, self.H, self.dh)
+            k.wavlm_attn_fwd(S["qkv"], S["gate"], W["rb"], S["o"], B, Tn, self.H, self.dh, probs=S["probs"])
             k.gemm_nt(S["o"], Lw_["wo"], S["y1"], bias=Lw_["bo"], res=S["xin"])
             k.layernorm_fwd(S["y1"], Lw_["ln1_w"], Lw_["ln1_b"], yT=S["x1b"], y32=S["x1"], mean=S["mean1"], rstd=S["rstd1"])
             k.gemm_nt(S["x1b"], Lw_["w1"], S["hm"], bias=Lw_["b1"], act=L.ACT_GELU, out2=S["pre"])
@@ -502,8 +503,16 @@ class WavLMBackbone:
             if wgrads:
                 self._wgrad(sv["dbb"], S["o"], g[a + "out_proj.weight"], g[a + "out_proj.bias"])
             k.gemm_nt(sv["dbb"], Lw_["woT"], sv["do"])
-            k.wavlm_attn_bwd(S["qkv"], S["probs"], sv["do"], S["gate"], W["rb"], sv["dqkv"], sv["dgate"], self._drb, sv["dsc"],
-                             B, Tn, H, self.dh)
+            if self._mfma_attn_bwd(Tn):
+                # dQ/dK/dV by the Conformer's MFMA attention backward with a ZERO relative-position table (the additive bias only
+                # enters through the saved probabilities); it leaves dS (bf16) in the scratch buffer, from which the gate and
+                # bias-table gradients are reduced
+                k.attn_bwd(S["qkv"], W["zero_emb"], S["probs"], sv["do"], sv["dqkv"], None, sv["dsc"], B, Tn, H, self.dh,
+                           rel_emb_T=W["zero_embT"])
+                k.wavlm_attn_bias_grads(sv["dsc"], S["gate"], W["rb"], sv["dgate"], self._drb, B, Tn, H, S["probs"].shape[-1])
+            else:
+                k.wavlm_attn_bwd(S["qkv"], S["probs"], sv["do"], S["gate"], W["rb"], sv["dqkv"], sv["dgate"], self._drb, sv["dsc"],
+                                 B, Tn, H, self.dh)
             if wgrads:
                 gw, gb = self._gqkv[i]
                 self._wgrad(sv["dqkv"], S["xinb"], gw, gb)
@@ -547,6 +556,15 @@ class WavLMBackbone:
         k.layernorm_bwd(sv["dxc"], ws["xc"], ws["mean_in"], ws["rstd_in"], W["ln0_w"], sv["partial"],
                         dx=sv["db"].view(-1)[:M * self.C].view(M, self.C),      # (unused: the conv extractor below is frozen)
                         dgamma=g["layer_norm.weight"], dbeta=g["layer_norm.bias"], dtype=bf)
+
+    def _mfma_attn_bwd(self, Tn: int) -> bool:
+        ok = getattr(self, "_mfma_ok", None)
+        if ok is None:
+            ok = self._mfma_ok = {}
+        if Tn not in ok:
+            import os
+            ok[Tn] = os.environ.get("LIDK_WAVLM_ATTN_BWD", "mfma") == "mfma" and ops.attn_bwd_relpos_supported(Tn, self.dh, torch.bfloat16)
+        return ok[Tn]
 
     def _gate_scratch(self):
         """Throw-away targets for the gate's parameter gradients while the encoder is frozen (data gradients only)."""
