@@ -563,39 +563,48 @@ extern "C" int lidk_wavlm_attn_bwd(const void* qkv, const void* probs, const voi
 // From dS [B][H][T][ldp] bf16 (left behind by lidk_attn_bwd's MFMA path, which computes dQ/dK/dV: with a zero relative-position
 // table the Conformer's attention backward IS this layer's - the additive bias only enters through the saved probabilities):
 //   dgate[b][h][i] = sum_j dS[i][j] rb[h][j - i]          drb[h][r] += sum_{b,i} gate[b][h][i] dS[i][i + r]
-// One workgroup per (b, h), one wave per row; the per-offset sums meet in LDS (float atomics on distinct addresses within a
-// wave) and leave through one global atomic per offset.
+// One workgroup per (b, h): the dS tile is staged in LDS once (16-byte loads); a thread then owns one row (dgate) and, in a
+// second pass, one offset r (drb: a walk down the r-th diagonal, conflict-free for consecutive r); one global atomic per
+// offset and workgroup.
 __global__ void __launch_bounds__(256)
 wavlm_attn_bias_grads_kernel(const bf16* __restrict__ ds, const float* __restrict__ gate, const float* __restrict__ rb,
                              float* __restrict__ dgate, float* __restrict__ drb, int T_, int H, int RB, int ldp) {
-  extern __shared__ float acc[];                        // [2*T - 1]: offset r + T - 1
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int LDD = ldp + 8;                                        // bf16 elements per LDS row (16-byte aligned rows)
+  bf16* D = reinterpret_cast<bf16*>(smem);                        // [T][LDD]
+  float* gs = reinterpret_cast<float*>(smem + (((size_t)T_ * LDD * 2) + 15) / 16 * 16);   // [T]
+  float* rs = gs + T_;                                            // [2T - 1]: rb[h][r], entry r + T - 1
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  for (int i = threadIdx.x; i < 2 * T_ - 1; i += blockDim.x) acc[i] = 0.f;
-  __syncthreads();
-  const float* rbh = rb + (size_t)h * (2 * RB - 1) + RB - 1;
-  const float* grow = gate + ((size_t)b * H + h) * T_;
   const bf16* base = ds + ((size_t)b * H + h) * T_ * ldp;
-  for (int i = wave; i < T_; i += 4) {
-    const float gi = grow[i];
-    float dg = 0.f;
-    for (int j = lane; j < T_; j += 64) {
-      const float v = to_f(base[(size_t)i * ldp + j]);
-      dg = fmaf(v, rbh[j - i], dg);
-      atomicAdd(&acc[j - i + T_ - 1], gi * v);
-    }
-    dg = wave_sum(dg);
-    if (lane == 0) dgate[((size_t)b * H + h) * T_ + i] = dg;
+  const int cpr = ldp / 8;
+  for (int c = threadIdx.x; c < T_ * cpr; c += blockDim.x) {
+    const int i = c / cpr, cc = (c - i * cpr) * 8;
+    *reinterpret_cast<uint4*>(&D[i * LDD + cc]) = *reinterpret_cast<const uint4*>(base + (size_t)i * ldp + cc);
   }
+  for (int i = threadIdx.x; i < T_; i += blockDim.x) gs[i] = gate[((size_t)b * H + h) * T_ + i];
+  for (int i = threadIdx.x; i < 2 * T_ - 1; i += blockDim.x) rs[i] = rb[(size_t)h * (2 * RB - 1) + (i - (T_ - 1)) + RB - 1];
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * T_ - 1; i += blockDim.x)
-    if (acc[i] != 0.f) atomicAdd(&drb[(size_t)h * (2 * RB - 1) + (i - (T_ - 1)) + RB - 1], acc[i]);
+  for (int i = threadIdx.x; i < T_; i += blockDim.x) {            // dgate[i] = sum_j dS[i][j] rb[j - i]
+    float dg = 0.f;
+    for (int j = 0; j < T_; ++j) dg = fmaf(to_f(D[i * LDD + j]), rs[j - i + T_ - 1], dg);
+    dgate[((size_t)b * H + h) * T_ + i] = dg;
+  }
+  for (int q = threadIdx.x; q < 2 * T_ - 1; q += blockDim.x) {    // drb[r] += sum_i gate[i] dS[i][i + r]
+    const int r = q - (T_ - 1);
+    const int ilo = r < 0 ? -r : 0, ihi = r > 0 ? T_ - 1 - r : T_ - 1;
+    float a = 0.f;
+    for (int i = ilo; i <= ihi; ++i) a = fmaf(gs[i], to_f(D[i * LDD + i + r]), a);
+    if (a != 0.f) atomicAdd(&drb[(size_t)h * (2 * RB - 1) + r + RB - 1], a);
+  }
 }
 extern "C" int lidk_wavlm_attn_bias_grads(const void* ds, const float* gate, const float* rb, float* dgate, float* drb, int B, int T_,
                                           int H, int RB, int ldp, void* stream) {
   if (!ds || !gate || !rb || !dgate || !drb || B <= 0 || T_ <= 0 || H <= 0 || RB < T_ || ldp < T_) return LIDK_ERR_ARG;
-  wavlm_attn_bias_grads_kernel<<<B * H, 256, (size_t)(2 * T_ - 1) * 4, as_stream(stream)>>>((const bf16*)ds, gate, rb, dgate, drb, T_,
-                                                                                            H, RB, ldp);
+  if (ldp & 7) return LIDK_ERR_ARG;
+  const size_t lds = (((size_t)T_ * (ldp + 8) * 2) + 15) / 16 * 16 + (size_t)(3 * T_ - 1) * 4;
+  if (lds > 160 * 1024) return LIDK_ERR_UNSUPPORTED;
+  (void)hipFuncSetAttribute((const void*)wavlm_attn_bias_grads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  wavlm_attn_bias_grads_kernel<<<B * H, 256, lds, as_stream(stream)>>>((const bf16*)ds, gate, rb, dgate, drb, T_, H, RB, ldp);
   return launch_status();
 }
 
