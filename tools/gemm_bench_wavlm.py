@@ -53,3 +53,12 @@ run("qkv", M, 2304, 768)
 run("out (+res f32)", M, 768, 768, res=True, out_f32=True)
 run("fc1 (gelu, +pre)", M, 3072, 768, act=L.ACT_GELU)
 run("fc2 (+res f32)", M, 768, 3072, res=True, out_f32=True)
+
+print("weight-gradient (TN) GEMMs, M = 9536; LIDK_TN_TILE=128 forces the 128x128 tile")
+def run_tn(name, n1, n2, sk):
+    X = torch.randn(M, n1, device=dev).bfloat16(); Y = torch.randn(M, n2, device=dev).bfloat16()
+    Cm = torch.zeros(n1, n2, device=dev); cs = torch.zeros(n1, device=dev)
+    us = t(lambda: ops.gemm_tn(X, Y, Cm, colsum=cs, splitk=sk), n=10)
+    print(f"{name:12s} [{n1:5d},{n2:5d}] sk={sk:2d}: {us:8.1f} us  {2.0 * M * n1 * n2 / us / 1e6:7.1f} TF/s")
+for sk in (1, 2, 4):
+    run_tn("dW fc1", 3072, 768, sk); run_tn("dW fc2", 768, 3072, sk); run_tn("dW qkv", 2304, 768, sk); run_tn("dW out", 768, 768, sk)
