@@ -101,6 +101,16 @@ int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
                        const float* gamma, const float* dres, float* dx, void* dxT, float dxT_scale, float* dgamma,
                        float* dbeta, float* partial, int M, int C, int dtype, void* stream);
 int lidk_layernorm_param_grads(const float* partial, int M, int C, float* dgamma, float* dbeta, void* stream);
+/* Two LayerNorms in a row (C <= 256): post_norm of ConformerBlock i followed by the first FeedForward PreNorm of block i + 1
+ * (lid/conformer.py:252-259, 153-171).  y1 = LN1(x) f32, y2 = LN2(y1) in T, statistics of both; one pass over x. */
+int lidk_layernorm2_fwd(const float* x, const float* g1, const float* b1, float* y1, float* mean1, float* rstd1, const float* g2,
+                        const float* b2, void* y2, float* mean2, float* rstd2, int M, int C, float eps, int dtype, void* stream);
+/* Backward of that pair: dy (T) at y2, dres (f32) reaching y1 along the residual path -> dx (f32), dxT = dxT_scale * dx (T, may
+ * be NULL); partial1 / partial2: LN1's / LN2's (dgamma | dbeta) rows as lidk_layernorm_bwd leaves them (finish with
+ * lidk_layernorm_param_grads). */
+int lidk_layernorm2_bwd(const void* dy, const float* dres, const float* y1, const float* mean2, const float* rstd2, const float* g2,
+                        const float* x, const float* mean1, const float* rstd1, const float* g1, float* dx, void* dxT,
+                        float dxT_scale, float* partial1, float* partial2, int M, int C, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ GEMM  C[M][N] = A[M][K] * B[N][K]^T  (+ fused epilogue)
  * Replaces every nn.Linear / 1x1 nn.Conv1d on the path (lid/conformer.py:98-100,163-166,192,199,334; lid/ConformerLangModel.py:350)

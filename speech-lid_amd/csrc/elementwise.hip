@@ -470,6 +470,141 @@ extern "C" int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, 
   return launch_status();
 }
 
+// ------------------------------------------------------------------------------------ two LayerNorms in a row (C <= 256)
+// Between two ConformerBlocks the residual stream passes through post_norm of block i and straight into the first FeedForward's
+// PreNorm of block i+1 (lid/conformer.py:252-259, 153-171): y1 = LN1(x) (f32, kept: it is block i's output and block i+1's
+// residual), y2 = LN2(y1) (T: the GEMM operand).  Row-local, so one launch does both - one read of x instead of two passes.
+// One row per wave; the arithmetic of each LayerNorm is ln_fwd_kernel's, applied to the f32 y1 exactly as stored.
+template <typename T>
+__global__ void __launch_bounds__(256)
+ln2_fwd_c256_kernel(const float* __restrict__ x, const float* __restrict__ g1, const float* __restrict__ b1,
+                    float* __restrict__ y1, float* __restrict__ mean1, float* __restrict__ rstd1,
+                    const float* __restrict__ g2, const float* __restrict__ b2, T* __restrict__ y2, float* __restrict__ mean2,
+                    float* __restrict__ rstd2, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63, c = lane * 4;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const bool ok = c < C;
+  float4 v = make_float4(0, 0, 0, 0), ga = v, ba = v, gb = v, bb = v;
+  if (ok) { v = load4(x + (size_t)row * C + c); ga = load4(g1 + c); ba = load4(b1 + c); gb = load4(g2 + c); bb = load4(b2 + c); }
+  float s = v.x + v.y + v.z + v.w;
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+  if (ok) { float a = v.x - mu, b = v.y - mu, d = v.z - mu, e = v.w - mu; q += a * a + b * b + d * d + e * e; }
+  const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+  float4 o = make_float4(0, 0, 0, 0);
+  if (ok) {
+    o.x = (v.x - mu) * rs * ga.x + ba.x; o.y = (v.y - mu) * rs * ga.y + ba.y;
+    o.z = (v.z - mu) * rs * ga.z + ba.z; o.w = (v.w - mu) * rs * ga.w + ba.w;
+    store4(y1 + (size_t)row * C + c, o);
+  }
+  s = o.x + o.y + o.z + o.w;
+  const float mu2 = wave_sum(s) / (float)C;
+  q = 0.f;
+  if (ok) { float a = o.x - mu2, b = o.y - mu2, d = o.z - mu2, e = o.w - mu2; q += a * a + b * b + d * d + e * e; }
+  const float rs2 = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) { mean1[row] = mu; rstd1[row] = rs; mean2[row] = mu2; rstd2[row] = rs2; }
+  if (ok) {
+    float4 p;
+    p.x = (o.x - mu2) * rs2 * gb.x + bb.x; p.y = (o.y - mu2) * rs2 * gb.y + bb.y;
+    p.z = (o.z - mu2) * rs2 * gb.z + bb.z; p.w = (o.w - mu2) * rs2 * gb.w + bb.w;
+    store4(y2 + (size_t)row * C + c, p);
+  }
+}
+extern "C" int lidk_layernorm2_fwd(const float* x, const float* g1, const float* b1, float* y1, float* mean1, float* rstd1,
+                                   const float* g2, const float* b2, void* y2, float* mean2, float* rstd2, int M, int C, float eps,
+                                   int dtype, void* stream) {
+  if (!x || !g1 || !b1 || !y1 || !mean1 || !rstd1 || !g2 || !b2 || !y2 || !mean2 || !rstd2 || M <= 0 || C <= 0 || (C & 3) || C > 256)
+    return LIDK_ERR_ARG;
+  LIDK_DISPATCH(dtype, ln2_fwd_c256_kernel<T><<<cdiv(M, 4), 256, 0, as_stream(stream)>>>(x, g1, b1, y1, mean1, rstd1, g2, b2, (T*)y2,
+                                                                                        mean2, rstd2, M, C, eps));
+  return launch_status();
+}
+
+// Backward of the same pair: dy (T) is the gradient at y2, dres (f32) the gradient reaching y1 along the residual path.
+//   dv = LN2'(dy; y1, mean2, rstd2, g2) + dres ;  dx = LN1'(dv; x, mean1, rstd1, g1)  -> dx (f32) and dxT = dxT_scale * dx (T)
+// partial1 / partial2 receive the per-workgroup (dgamma | dbeta) rows of LN1 / LN2 in lidk_layernorm_bwd's layout (finish them
+// with lidk_layernorm_param_grads).  The intermediate dv is never written.
+template <typename T>
+__global__ void __launch_bounds__(256)
+ln2_bwd_c256_kernel(const T* __restrict__ dy, const float* __restrict__ dres, const float* __restrict__ y1,
+                    const float* __restrict__ mean2, const float* __restrict__ rstd2, const float* __restrict__ g2,
+                    const float* __restrict__ x, const float* __restrict__ mean1, const float* __restrict__ rstd1,
+                    const float* __restrict__ g1, float* __restrict__ dx, T* __restrict__ dxT, float dxT_scale,
+                    float* __restrict__ partial1, float* __restrict__ partial2, int M, int C) {
+  __shared__ float red[4][4 * 256];                          // [wave][dg1 | db1 | dg2 | db2]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane * 4;
+  const bool ok = c < C;
+  float4 dg1 = make_float4(0, 0, 0, 0), db1 = dg1, dg2 = dg1, db2 = dg1;
+  const float4 gm1 = ok ? load4(g1 + c) : dg1, gm2 = ok ? load4(g2 + c) : dg1;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu2 = mean2[row], rs2 = rstd2[row], mu1 = mean1[row], rs1 = rstd1[row];
+    float4 d = make_float4(0, 0, 0, 0), v = d, r = d, u = d;
+    if (ok) {
+      d = load4(dy + (size_t)row * C + c); v = load4(y1 + (size_t)row * C + c);
+      r = load4(dres + (size_t)row * C + c); u = load4(x + (size_t)row * C + c);
+    }
+    // ---- LN2 backward (+ residual)
+    float4 xh, g;
+    xh.x = (v.x - mu2) * rs2; xh.y = (v.y - mu2) * rs2; xh.z = (v.z - mu2) * rs2; xh.w = (v.w - mu2) * rs2;
+    g.x = d.x * gm2.x; g.y = d.y * gm2.y; g.z = d.z * gm2.z; g.w = d.w * gm2.w;
+    float s1 = 0.f, s2 = 0.f;
+    if (ok) {
+      s1 += g.x + g.y + g.z + g.w;
+      s2 += g.x * xh.x + g.y * xh.y + g.z * xh.z + g.w * xh.w;
+      dg2.x += d.x * xh.x; dg2.y += d.y * xh.y; dg2.z += d.z * xh.z; dg2.w += d.w * xh.w;
+      db2.x += d.x; db2.y += d.y; db2.z += d.z; db2.w += d.w;
+    }
+    float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+    float4 dv;
+    dv.x = rs2 * (g.x - m1 - xh.x * m2) + r.x; dv.y = rs2 * (g.y - m1 - xh.y * m2) + r.y;
+    dv.z = rs2 * (g.z - m1 - xh.z * m2) + r.z; dv.w = rs2 * (g.w - m1 - xh.w * m2) + r.w;
+    // ---- LN1 backward
+    xh.x = (u.x - mu1) * rs1; xh.y = (u.y - mu1) * rs1; xh.z = (u.z - mu1) * rs1; xh.w = (u.w - mu1) * rs1;
+    g.x = dv.x * gm1.x; g.y = dv.y * gm1.y; g.z = dv.z * gm1.z; g.w = dv.w * gm1.w;
+    s1 = 0.f; s2 = 0.f;
+    if (ok) {
+      s1 += g.x + g.y + g.z + g.w;
+      s2 += g.x * xh.x + g.y * xh.y + g.z * xh.z + g.w * xh.w;
+      dg1.x += dv.x * xh.x; dg1.y += dv.y * xh.y; dg1.z += dv.z * xh.z; dg1.w += dv.w * xh.w;
+      db1.x += dv.x; db1.y += dv.y; db1.z += dv.z; db1.w += dv.w;
+    }
+    m1 = wave_sum(s1) / (float)C; m2 = wave_sum(s2) / (float)C;
+    if (ok) {
+      float4 o;
+      o.x = rs1 * (g.x - m1 - xh.x * m2); o.y = rs1 * (g.y - m1 - xh.y * m2);
+      o.z = rs1 * (g.z - m1 - xh.z * m2); o.w = rs1 * (g.w - m1 - xh.w * m2);
+      store4(dx + (size_t)row * C + c, o);
+      if (dxT) {
+        o.x *= dxT_scale; o.y *= dxT_scale; o.z *= dxT_scale; o.w *= dxT_scale;
+        store4(dxT + (size_t)row * C + c, o);
+      }
+    }
+  }
+  if (ok) {
+    store4(&red[wave][c], dg1); store4(&red[wave][C + c], db1);
+    store4(&red[wave][2 * C + c], dg2); store4(&red[wave][3 * C + c], db2);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    partial1[(size_t)blockIdx.x * 2 * C + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    partial2[(size_t)blockIdx.x * 2 * C + i] = red[0][2 * C + i] + red[1][2 * C + i] + red[2][2 * C + i] + red[3][2 * C + i];
+  }
+}
+extern "C" int lidk_layernorm2_bwd(const void* dy, const float* dres, const float* y1, const float* mean2, const float* rstd2,
+                                   const float* g2, const float* x, const float* mean1, const float* rstd1, const float* g1,
+                                   float* dx, void* dxT, float dxT_scale, float* partial1, float* partial2, int M, int C, int dtype,
+                                   void* stream) {
+  if (!dy || !dres || !y1 || !mean2 || !rstd2 || !g2 || !x || !mean1 || !rstd1 || !g1 || !dx || !partial1 || !partial2 || M <= 0 ||
+      C <= 0 || (C & 3) || C > 256)
+    return LIDK_ERR_ARG;
+  const int G = cdiv(M, 4) < LIDK_LN_BWD_BLOCKS ? cdiv(M, 4) : LIDK_LN_BWD_BLOCKS;       // = lidk_layernorm_bwd's partial rows
+  LIDK_DISPATCH(dtype, ln2_bwd_c256_kernel<T><<<G, 256, 0, as_stream(stream)>>>((const T*)dy, dres, y1, mean2, rstd2, g2, x, mean1,
+                                                                               rstd1, g1, dx, (T*)dxT, dxT_scale, partial1,
+                                                                               partial2, M, C));
+  return launch_status();
+}
+
 extern "C" int lidk_layernorm_param_grads(const float* partial, int M, int C, float* dgamma, float* dbeta, void* stream) {
   if (!partial || M <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAX_VEC || (!dgamma && !dbeta)) return LIDK_ERR_ARG;
   int G = cdiv(M, 4) < LIDK_LN_BWD_BLOCKS ? cdiv(M, 4) : LIDK_LN_BWD_BLOCKS;     // the partial rows lidk_layernorm_bwd(M) wrote

@@ -483,11 +483,18 @@ class Engine:
             return w.x0d
         return w.x0
 
-    def _ln_gemm(self, x, P, W, out, h, mean, rstd, **epi):
+    def _ln2_ok(self) -> bool:
+        """The fused LayerNorm pair (post_norm of block i + first PreNorm of block i + 1, forward and backward) is available."""
+        return bool(self._hip and self.cfg.d <= 256 and hasattr(self.k, "layernorm2_fwd") and _os_env("LIDK_LN2", "1") == "1")
+
+    def _ln_gemm(self, x, P, W, out, h, mean, rstd, ln_done: bool = False, **epi):
         """PreNorm + the projection that consumes it: two launches.  LIDK_LN_GEMM=1 opts into the row-panel kernel that does
         both in one (LayerNorm in the operand load); measured SLOWER on MI355X (LN + ff-up 41.7 vs 23.7 us, LN + QKV 20.6 vs
         17.3 us: two 64 KB workgroups per CU hide less latency than the per-tile kernels' 16+ waves), so it is off by default
         and kept for the record (measured and rejected)."""
+        if ln_done:                      # h / mean / rstd were written by the previous block's fused LayerNorm pair
+            self.k.gemm_nt(h, W, out, **epi)
+            return
         M, N = x.shape[0], W.shape[0]
         key = (M, N)
         ok = self._ln_gemm_ok.get(key)
@@ -501,18 +508,19 @@ class Engine:
             self.k.layernorm_fwd(x, P["ln_w"], P["ln_b"], yT=h, mean=mean, rstd=rstd)
             self.k.gemm_nt(h, W, out, **epi)
 
-    def _ff_fwd(self, x, P, h, a, u, xo, mean, rstd):
-        self._ln_gemm(x, P, P["w1"][0], u, h, mean, rstd, bias=P["b1"], act=L.ACT_SWISH, out2=a)
+    def _ff_fwd(self, x, P, h, a, u, xo, mean, rstd, ln_done: bool = False):
+        self._ln_gemm(x, P, P["w1"][0], u, h, mean, rstd, ln_done=ln_done, bias=P["b1"], act=L.ACT_SWISH, out2=a)
         self.k.gemm_nt(u, P["w2"][0], xo, bias=P["b2"], alpha=0.5, res=x)
 
-    def _block_fwd(self, x, bp: _BlockParams, bb: _BlockBuf, w: _Work, training: bool, part: str = "all"):
+    def _block_fwd(self, x, bp: _BlockParams, bb: _BlockBuf, w: _Work, training: bool, part: str = "all",
+                   ff1_ln_done: bool = False):
         """One ConformerBlock up to x4 (before post_norm).  ``part`` splits the launch sequence at the SyncBatchNorm
         collective: 'a' = up to the BatchNorm partial sums, 'b' = from the BatchNorm statistics on, 'all' = both."""
         B, T, M = w.B, w.T, w.M
         C = bp.conv
         ci, K = C["dw"].shape[0], C["dw"].shape[2]
         if part in ("all", "a"):
-            self._ff_fwd(x, bp.ff1, bb.h1, bb.a1, bb.u1, bb.x1, bb.mean[0], bb.rstd[0])
+            self._ff_fwd(x, bp.ff1, bb.h1, bb.a1, bb.u1, bb.x1, bb.mean[0], bb.rstd[0], ln_done=ff1_ln_done)
             A = bp.attn
             self._ln_gemm(bb.x1, A, A["wqkv"][0], bb.qkv, bb.h2, bb.mean[1], bb.rstd[1])
             self.k.attn_fwd(bb.qkv, A["emb"], bb.o, bb.probs, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
@@ -566,19 +574,28 @@ class Engine:
         t = (w.sums if sums is None else sums)[:2 * ci + 1]              # sums + row count in one collective
         return lambda: self.stat_allreduce(t)
 
-    def _enc_block_fwd(self, x, i, w: _Work, training: bool, part: str):
+    def _enc_block_fwd(self, x, i, w: _Work, training: bool, part: str, fuse_next: bool = False, ln_done: bool = False):
+        """fuse_next: block i + 1 follows directly, so post_norm and its first PreNorm run as one launch (which leaves h1 /
+        mean / rstd of block i + 1 in place); ln_done: this block's first PreNorm was already produced that way."""
         bp, bb = self.enc_params[i], w.enc[i]
-        x4 = self._block_fwd(x, bp, bb, w, training, part)
+        x4 = self._block_fwd(x, bp, bb, w, training, part, ff1_ln_done=ln_done)
         if part in ("all", "b"):
-            self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
-                                 dtype=self.act_dtype)
+            if fuse_next:
+                nb, nbb = self.enc_params[i + 1], w.enc[i + 1]
+                self.k.layernorm2_fwd(x4, bp.post["w"], bp.post["b"], bb.out, bb.mean[4], bb.rstd[4], nb.ff1["ln_w"],
+                                      nb.ff1["ln_b"], nbb.h1, nbb.mean[0], nbb.rstd[0])
+            else:
+                self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
+                                     dtype=self.act_dtype)
 
-    def _enc_block_bwd(self, dy, x_in, i, w: _Work, dfeat, part: str, S, wg: bool):
+    def _enc_block_bwd(self, dy, x_in, i, w: _Work, dfeat, part: str, S, wg: bool, post_done: bool = False, fuse=None):
+        """post_done: the block that ran before (in backward order) already produced this block's post_norm backward in its
+        fused LayerNorm pair; fuse: see _ff_bwd."""
         bp, bb = self.enc_params[i], w.enc[i]
-        if part in ("all", "a"):
+        if part in ("all", "a") and not post_done:
             post = dict(ln_w=bp.post["w"], dln_w=bp.post["dw"], dln_b=bp.post["db"])
             self._ln_bwd(w, dy, bb.x4, bb.mean[4], bb.rstd[4], post, S.lnp[0], wg, dx=w.dxa, dxT=S.dyTs[0], dxT_scale=0.5)
-        self._block_bwd(w, x_in, bp, bb, w.dxa, S, dfeat, part, wg)
+        self._block_bwd(w, x_in, bp, bb, w.dxa, S, dfeat, part, wg, fuse=fuse)
 
     def _head_fwd(self, w: _Work, feat, lang, training, seed, logits):
         cfg = self.cfg
@@ -627,8 +644,10 @@ class Engine:
 
             def enc_all():
                 xx = x_first
+                fuse = self._ln2_ok()
                 for i in range(self.cfg.n_blocks):
-                    self._enc_block_fwd(xx, i, w, training, "all")
+                    self._enc_block_fwd(xx, i, w, training, "all", fuse_next=fuse and i + 1 < self.cfg.n_blocks,
+                                        ln_done=fuse and i > 0)
                     xx = w.enc[i].out
 
             self.graphs.run(("efA", id(w), x.data_ptr(), training), enc_all)
@@ -687,8 +706,12 @@ class Engine:
         else:
             self.k.layernorm_bwd(dy, x, mean, rstd, P["ln_w"], lnp, dtype=self.act_dtype, **kw)
 
-    def _ff_bwd(self, w: _Work, dx_res, dyT, x_in, P, h, a, u, mean, rstd, dx_out, dxT_out, dxT_scale, da_buf, wg: bool, lnp):
-        """dyT = 0.5*dx_res (T).  Produces dx_out = dx_res + LN'(dh) and optional T copy for the next stage."""
+    def _ff_bwd(self, w: _Work, dx_res, dyT, x_in, P, h, a, u, mean, rstd, dx_out, dxT_out, dxT_scale, da_buf, wg: bool, lnp,
+                fuse=None):
+        """dyT = 0.5*dx_res (T).  Produces dx_out = dx_res + LN'(dh) and optional T copy for the next stage.
+        fuse = (bb_prev, post_prev, S_prev, forked): x_in is the output of the encoder block that comes NEXT in backward order, so this
+        PreNorm's backward and that block's post_norm backward run as one launch: dx (f32) -> w.dxa, 0.5*dx (T) ->
+        S_prev.dyTs[0], partial rows of both LayerNorms into their own buffers; dx_out is not written."""
         M, d, ff = w.M, self.cfg.d, a.shape[1]
         if wg:
             self._wgrad(w, dyT, u, P["dw2"], d, ff, P["db2"])
@@ -697,10 +720,17 @@ class Engine:
         if wg:
             self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
         self.k.gemm_nt(da, P["w1"][1], w.dh, N=d, K=ff)
+        if fuse is not None:
+            pbb, post, Sp, forked = fuse
+            if forked:          # S_prev's buffers are still read by the weight gradients running on the second stream
+                self._join()
+            self.k.layernorm2_bwd(w.dh, dx_res, x_in, mean, rstd, P["ln_w"], pbb.x4, pbb.mean[4], pbb.rstd[4], post["w"],
+                                  w.dxa, Sp.dyTs[0], 0.5, Sp.lnp[0], lnp)
+            return
         self._ln_bwd(w, w.dh, x_in, mean, rstd, P, lnp, wg, dres=dx_res, dx=dx_out, dxT=dxT_out, dxT_scale=dxT_scale)
 
     def _block_bwd(self, w: _Work, x_in, bp: _BlockParams, bb: _BlockBuf, dx4, S, dx_in_out, part: str = "all",
-                   wg: bool = True):
+                   wg: bool = True, fuse=None):
         """dx4: f32 gradient at x4 (after post_norm backward); S.dyTs[0] = 0.5*dx4 in T.  Writes the gradient w.r.t. the
         block input into dx_in_out (f32) and every weight-gradient operand (dY) into the scratch set S.  ``part`` cuts the
         sequence at the SyncBatchNorm backward all-reduce.  wg=False leaves the weight gradients to _block_wgrads."""
@@ -755,7 +785,7 @@ class Engine:
             dx1 = a
             # ---- ff1
             self._ff_bwd(w, dx1, t3, x_in, bp.ff1, bb.h1, bb.a1, bb.u1, bb.mean[0], bb.rstd[0], dx_in_out, None, 1.0, S.da[1], wg,
-                         S.lnp[4])
+                         S.lnp[4], fuse=fuse)
 
     def _conv_wgrad(self, w: _Work, bp: _BlockParams, bb: _BlockBuf, S):
         """BatchNorm parameter gradients and the depthwise-conv weight gradient: dc is materialised here (off the dgrad
@@ -884,15 +914,24 @@ class Engine:
             # the last block's weight gradients - as one captured sequence per (workspace, language)
             def bwd_all():
                 prv = None
+                fuse_ok = defer and self._ln2_ok()
+                post_done = False
                 for n, (kind, tag, bpk, bbk, x_in, stage) in enumerate(blocks):
                     S = w.sets[n & 1]
+                    # x_in of this block is the output of the block that follows in backward order (an encoder block, unless
+                    # this is encoder block 0): fuse this block's first-PreNorm backward with that block's post_norm backward
+                    fuse = None
+                    if fuse_ok and n + 1 < len(blocks):
+                        nxt = blocks[n + 1]
+                        fuse = (nxt[3], nxt[2].post, w.sets[(n + 1) & 1], prv is not None)
                     if prv is not None:
                         with self._fork():
                             self._block_wgrads(w, prv[1], prv[2], prv[3], prv[0][0] == "enc")
                     if kind == "head":
-                        self._block_bwd(w, x_in, bpk, bbk, w.dxa, S, dfeat, "all", not defer)
+                        self._block_bwd(w, x_in, bpk, bbk, w.dxa, S, dfeat, "all", not defer, fuse=fuse)
                     else:
-                        self._enc_block_bwd(dfeat, x_in, tag, w, dfeat, "all", S, not defer)
+                        self._enc_block_bwd(dfeat, x_in, tag, w, dfeat, "all", S, not defer, post_done=post_done, fuse=fuse)
+                    post_done = fuse is not None
                     if prv is not None:
                         self._join()
                     if defer:

@@ -218,6 +218,20 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, partial, dres=None, dx=None, dxT=Non
                                    dxT_scale, _p(dgamma), _p(dbeta), _p(partial), M, Cc, code, _stream()), "layernorm_bwd")
 
 
+def layernorm2_fwd(x, g1, b1, y1, mean1, rstd1, g2, b2, y2, mean2, rstd2, eps=1e-5):
+    """y1 = LN1(x) (f32), y2 = LN2(y1) (bf16 / f32 by y2's dtype) in one pass; C <= 256."""
+    M, Cc = x.shape
+    check(lib().lidk_layernorm2_fwd(_p(x), _p(g1), _p(b1), _p(y1), _p(mean1), _p(rstd1), _p(g2), _p(b2), _p(y2), _p(mean2),
+                                    _p(rstd2), M, Cc, eps, _code(y2), _stream()), "layernorm2_fwd")
+
+
+def layernorm2_bwd(dy, dres, y1, mean2, rstd2, g2, x, mean1, rstd1, g1, dx, dxT, dxT_scale, partial1, partial2):
+    M, Cc = x.shape
+    check(lib().lidk_layernorm2_bwd(_p(dy), _p(dres), _p(y1), _p(mean2), _p(rstd2), _p(g2), _p(x), _p(mean1), _p(rstd1), _p(g1),
+                                    _p(dx), _p(dxT), dxT_scale, _p(partial1), _p(partial2), M, Cc, _code(dy), _stream()),
+          "layernorm2_bwd")
+
+
 def layernorm_param_grads(partial, M, C, dgamma, dbeta):
     """Finish dgamma/dbeta from the partial rows a ``layernorm_bwd(..., dgamma=None, dbeta=None)`` call left behind."""
     check(lib().lidk_layernorm_param_grads(_p(partial), M, C, _p(dgamma), _p(dbeta), _stream()), "layernorm_param_grads")

@@ -542,6 +542,46 @@ def test_dwconv_wgrad_with_fused_bn_apply_equals_the_two_launch_sequence(B, T, C
     check("dwconv_wgrad_bn_dw", dw1, w.grad, 0.15, 2e-2)        # dc is rounded to bf16 (rel 4e-3) before ~T*B products are summed
 
 
+@pytest.mark.parametrize("M,C", [(9664, 256), (453, 144), (7, 64)])
+def test_double_layernorm_equals_two_single_launches(M, C):
+    """lidk_layernorm2_fwd / _bwd (post_norm of block i + the first PreNorm of block i + 1 in one pass) against two
+    lidk_layernorm_fwd / _bwd launches: same formulas on the same f32 intermediates -> outputs agree to f32 rounding, the bf16
+    operand to one ulp on a vanishing fraction of elements."""
+    dt = torch.bfloat16
+    x = dev(1.5 * torch.randn(M, C, generator=g(150)) + 0.2)
+    g1, b1 = dev(1 + 0.1 * torch.randn(C, generator=g(151))), dev(0.1 * torch.randn(C, generator=g(152)))
+    g2, b2 = dev(1 + 0.1 * torch.randn(C, generator=g(153))), dev(0.1 * torch.randn(C, generator=g(154)))
+    f = lambda *sh: torch.empty(*sh, device=DEV)
+    y1a, m1a, r1a, y2a, m2a, r2a = f(M, C), f(M), f(M), torch.empty(M, C, device=DEV, dtype=dt), f(M), f(M)
+    ops.layernorm_fwd(x, g1, b1, y32=y1a, mean=m1a, rstd=r1a, dtype=dt)
+    ops.layernorm_fwd(y1a, g2, b2, yT=y2a, mean=m2a, rstd=r2a)
+    y1b, m1b, r1b, y2b, m2b, r2b = f(M, C), f(M), f(M), torch.empty(M, C, device=DEV, dtype=dt), f(M), f(M)
+    ops.layernorm2_fwd(x, g1, b1, y1b, m1b, r1b, g2, b2, y2b, m2b, r2b)
+    assert float((y1a - y1b).abs().max()) <= 2e-6 * float(y1a.abs().max()) and float((m1a - m1b).abs().max()) <= 1e-6
+    assert float(((r1a - r1b) / r1a).abs().max()) <= 2e-6 and float(((r2a - r2b) / r2a).abs().max()) <= 1e-5
+    dh = (y2a.float() - y2b.float()).abs()
+    assert float(dh.max()) <= 2.0 ** -7 * float(y2a.float().abs().max()) and float((dh > 0).float().mean()) < 2e-3
+    # backward
+    dy = dev(torch.randn(M, C, generator=g(155)), dt)
+    dres = dev(torch.randn(M, C, generator=g(156)))
+    part = f(L.LN_BWD_BLOCKS * 2 * C)
+    dv, dxa, dxTa = f(M, C), f(M, C), torch.empty(M, C, device=DEV, dtype=dt)
+    dg2a, db2a, dg1a, db1a = [torch.zeros(C, device=DEV) for _ in range(4)]
+    ops.layernorm_bwd(dy, y1a, m2a, r2a, g2, part, dres=dres, dx=dv, dgamma=dg2a, dbeta=db2a, dtype=dt)
+    ops.layernorm_bwd(dv, x, m1a, r1a, g1, part, dx=dxa, dxT=dxTa, dxT_scale=0.5, dgamma=dg1a, dbeta=db1a, dtype=dt)
+    p1, p2 = f(L.LN_BWD_BLOCKS * 2 * C), f(L.LN_BWD_BLOCKS * 2 * C)
+    dxb, dxTb = f(M, C), torch.empty(M, C, device=DEV, dtype=dt)
+    ops.layernorm2_bwd(dy, dres, y1a, m2a, r2a, g2, x, m1a, r1a, g1, dxb, dxTb, 0.5, p1, p2)
+    dg2b, db2b, dg1b, db1b = [torch.zeros(C, device=DEV) for _ in range(4)]
+    ops.layernorm_param_grads(p1, M, C, dg1b, db1b)
+    ops.layernorm_param_grads(p2, M, C, dg2b, db2b)
+    scale = float(dxa.abs().max())
+    assert float((dxa - dxb).abs().max()) <= 1e-5 * scale
+    assert float((dxTa.float() - dxTb.float()).abs().max()) <= 2.0 ** -7 * 0.5 * scale
+    for a, b, n in ((dg1a, dg1b, "dg1"), (db1a, db1b, "db1"), (dg2a, dg2b, "dg2"), (db2a, db2b, "db2")):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max())), n
+
+
 # ------------------------------------------------------------------------------------------------ front-end
 def test_normalize_dither_preemph():
     w = 3.0 + 2.0 * torch.randn(3, 16000, generator=g(50))
