@@ -400,6 +400,120 @@ gemm_nt_bf16_direct_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------ bf16 MFMA kernel, 128x128 tile
+// For long-K large shapes only (WavLM's ffn-down GEMM and its data gradient: K = 3072, hundreds of 128x128 tiles): twice the MFMA
+// work per byte staged through LDS.  Measured at M = 9536 (tools/gemm_bench_wavlm.py): 71 vs 82 us at K = 3072 (631 vs 547 TFLOP/s);
+// at K = 768 / 1536 the 64x64 tiles' many small workgroups still hide latency better (68 vs 66 us, 130 vs 108 us with the two-output
+// GELU epilogue), so the dispatch asks for K >= 2048.  Register plan for two waves per SIMD: 64
+// accumulator registers, ONE set of 8 prefetch registers x 4, operands double-buffered in LDS (2 x 32 KB) so a K tile costs one
+// barrier: issue the loads of tile t+1, multiply tile t from LDS buffer t&1, then park tile t+1 in the other buffer.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gemm_nt_bf16_big_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K, int lda, int ldb, Epi e) {
+  constexpr int BM = 128, BN = 128, TM = 4, TN = 4, CA = 4, CB = 4;
+  const int n_tiles = N / BN;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+  bf16* As = reinterpret_cast<bf16*>(big_smem);                     // [2][BM * BK]
+  bf16* Bs = As + 2 * BM * BK;                                      // [2][BN * BK]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+  const bool pair = !e.out_f32;
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  u32x4 ra[CA], rb[CB];
+  auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int c = tid + i * 256, row = c >> 3, kc = (c & 7) * 8;
+      ra[i] = *reinterpret_cast<const u32x4*>(A + (size_t)min(m0 + row, M - 1) * lda + k0 + kc);
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int c = tid + i * 256, row = c >> 3, kc = (c & 7) * 8;
+      rb[i] = *reinterpret_cast<const u32x4*>(B + (size_t)(n0 + row) * ldb + k0 + kc);
+    }
+  };
+  auto lstore = [&](int buf) __attribute__((always_inline)) {
+    bf16* a = As + buf * BM * BK;
+    bf16* b = Bs + buf * BN * BK;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<u32x4*>(&a[row * BK + ((ch ^ (row & 7)) << 3)]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+      const int rho = pair ? (row & ~31) + (((row >> 2) & 1) << 4) + (((row >> 3) & 3) << 2) + (row & 3) : row;
+      *reinterpret_cast<u32x4*>(&b[rho * BK + ((ch ^ (rho & 7)) << 3)]) = rb[i];
+    }
+  };
+  auto mma = [&](int buf) __attribute__((always_inline)) {
+    const bf16* a = As + buf * BM * BK;
+    const bf16* b = Bs + buf * BN * BK;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; kk += 4) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(&a[(wm * 64 + i * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(&b[(wn * 64 + j * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+  const int nt = K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int t = 0; t + 1 < nt; ++t) {
+    gload((t + 1) * BK);              // unconditional: in flight during the whole multiply of tile t
+    mma(t & 1);
+    lstore((t + 1) & 1);
+    __syncthreads();
+  }
+  mma((nt - 1) & 1);
+
+  const bool vec = !(e.ldo & 7) && (!e.res || !(e.ldres & 3)) && (!e.out2 || !(e.ldo2 & 7)) && (!e.aux || !(e.ldaux & 7));
+#pragma clang loop unroll(full)
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= M) continue;
+    if (pair) {
+#pragma clang loop unroll(full)
+      for (int c = 0; c < TN / 2; ++c) {
+        const int n = n0 + wn * 64 + 32 * c + 8 * fq;
+        const float4 a0 = make_float4(acc[i][2 * c][0], acc[i][2 * c][1], acc[i][2 * c][2], acc[i][2 * c][3]);
+        const float4 a1 = make_float4(acc[i][2 * c + 1][0], acc[i][2 * c + 1][1], acc[i][2 * c + 1][2], acc[i][2 * c + 1][3]);
+        if (vec) {
+          float4 p0, p1;
+          const float4 v0 = epi_math4(e, m, n, a0, &p0);
+          const float4 v1 = epi_math4(e, m, n + 4, a1, &p1);
+          if ((e.act == LIDK_ACT_SWISH || e.act == LIDK_ACT_GELU) && e.out2) st16(e, (bf16*)e.out2 + (size_t)m * e.ldo2 + n, pack8(p0, p1));
+          st16(e, (bf16*)e.out + (size_t)m * e.ldo + n, pack8(v0, v1));
+        } else {
+          epi_store4<bf16>(e, m, n, N, a0);
+          epi_store4<bf16>(e, m, n + 4, N, a1);
+        }
+      }
+    } else {
+#pragma clang loop unroll(full)
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 64 + 16 * j + 4 * fq;
+        epi_store4<bf16>(e, m, n, N, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ bf16 MFMA kernel, pipelined tiles
 // For the wide K = 256 GEMMs (ff up-projection, its data gradient, QKV, pointwise conv 1) the output stores are half of a
 // launch (ablation in DESIGN.md section 5) and, in gemm_nt_bf16_direct_kernel, purely additive: a wave keeps its slot until
@@ -615,6 +729,19 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
 #undef LIDK_PIPE_LAUNCH
         return launch_status();
       }
+    }
+    static const int big_min = getenv("LIDK_GEMM_BIG") ? atoi(getenv("LIDK_GEMM_BIG")) : 256;      // 0 = never
+    if (direct && splitk == 1 && (g->K & 63) == 0 && big_min > 0 && g->K >= 2048 && !(g->N & 127) &&
+        (long)cdiv(g->M, 128) * (g->N / 128) >= big_min) {
+      const int grid = (g->N / 128) * cdiv(g->M, 128);
+      const int lds = 2 * (128 + 128) * BK * 2;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+      }
+      gemm_nt_bf16_big_kernel<<<grid, 256, lds, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->K, g->lda, g->ldb, e);
+      return launch_status();
     }
     if (direct && splitk == 1 && (g->K & 63) == 0) {
       const int grid = cdiv(g->N, 64) * cdiv(g->M, 64);
