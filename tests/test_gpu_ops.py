@@ -542,6 +542,33 @@ def test_dwconv_wgrad_with_fused_bn_apply_equals_the_two_launch_sequence(B, T, C
     check("dwconv_wgrad_bn_dw", dw1, w.grad, 0.15, 2e-2)        # dc is rounded to bf16 (rel 4e-3) before ~T*B products are summed
 
 
+@pytest.mark.parametrize("mode", ["bf16_plain", "f32_bias_res", "gelu_pre"])
+def test_gemm_nt_long_k_large_shape_uses_the_128_tile(mode):
+    """K >= 2048 with >= 256 tiles of 128x128 dispatches gemm_nt_bf16_big_kernel (WavLM's ffn-down shape class); M is not a
+    multiple of 128 so the clamped last row tile is covered.  Reference: f32 matmul of the bf16-rounded operands."""
+    M, N, K = 8192 + 77, 512, 2048
+    A = (torch.randn(M, K, generator=g(160)) * 0.5).bfloat16()
+    B = (torch.randn(N, K, generator=g(161)) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, generator=g(162))
+    ref = A.float() @ B.float().t()
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    if mode == "bf16_plain":
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(Ad, Bd, out)
+        check("gemm_big_bf16", out, ref, 3e-2, 1e-2)
+    elif mode == "f32_bias_res":
+        res = torch.randn(M, N, generator=g(163))
+        out = torch.empty(M, N, device=DEV)
+        ops.gemm_nt(Ad, Bd, out, bias=bias.to(DEV), alpha=0.5, res=res.to(DEV))
+        check("gemm_big_f32", out, 0.5 * (ref + bias) + res, 2e-3, 1e-4)
+    else:
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        pre = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(Ad, Bd, out, bias=bias.to(DEV), act=L.ACT_GELU, out2=pre)
+        check("gemm_big_pre", pre, ref + bias, 3e-2, 1e-2)
+        check("gemm_big_gelu", out, F.gelu(ref + bias), 3e-2, 1e-2)
+
+
 @pytest.mark.parametrize("M,C", [(9664, 256), (453, 144), (7, 64)])
 def test_double_layernorm_equals_two_single_launches(M, C):
     """lidk_layernorm2_fwd / _bwd (post_norm of block i + the first PreNorm of block i + 1 in one pass) against two
