@@ -549,10 +549,11 @@ class Engine:
         return bb.x4
 
     def _whole_graphs(self, keep) -> bool:
-        """One captured sequence for all encoder blocks (forward) / the whole block chain (backward): only without data
-        parallelism (no collective cuts the sequence), with every block kept (stochastic depth changes the sequence from step
-        to step) and with graphs on.  LIDK_WHOLE_GRAPHS=0 restores one graph per block."""
-        return (self.graphs.enabled and self.stat_allreduce is None and self.on_stage_grads_ready is None
+        """One launch sequence for all encoder blocks (forward) / the whole block chain (backward), captured as ONE hipGraph
+        each when graphs are on: only without data parallelism (no collective cuts the sequence) and with every block kept
+        (stochastic depth changes the sequence from step to step).  The choice does not depend on whether graphs are enabled,
+        so the eager and the replayed path issue exactly the same kernels.  LIDK_WHOLE_GRAPHS=0 restores one sequence per block."""
+        return (self._hip and self.stat_allreduce is None and self.on_stage_grads_ready is None
                 and self.cfg.n_blocks > 0 and all(keep) and _os_env("LIDK_WHOLE_GRAPHS", "1") == "1")
 
     def _fused_bn_stats(self) -> bool:
