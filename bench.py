@@ -484,6 +484,7 @@ class _EpochTimer:
 
     def __init__(self):
         self.trainer, self.spans, self._t = None, [], None
+        self.step_stamps, self._stamps = [], []            # host time stamps of every optimizer step, per epoch
 
     def add_trainer(self, trainer):
         self.trainer = trainer
@@ -491,15 +492,21 @@ class _EpochTimer:
     def before_train_epoch(self, value):
         torch.cuda.synchronize()
         self._t = time.perf_counter()
+        self._stamps = []
 
     def after_train_epoch(self, value):
         torch.cuda.synchronize()
-        self.spans.append(time.perf_counter() - self._t)
+        now = time.perf_counter()
+        self.spans.append(now - self._t)
+        self.step_stamps.append(self._stamps + [now])
 
     def after_train_loop(self, value):
+        self._stamps.append(time.perf_counter())
+
+    def _noop(self, value):
         pass
 
-    after_eval_loop = after_eval_epoch = test_loop_end = after_train_loop
+    after_eval_loop = after_eval_epoch = test_loop_end = _noop
 
 
 def fit_throughput(args, cfg, module, sets, params, device):
@@ -521,7 +528,12 @@ def fit_throughput(args, cfg, module, sets, params, device):
     log(f"fit: epoch seconds {[round(x, 2) for x in timer.spans]}, host ms/step by section {host}")
     spans = timer.spans[1:] or timer.spans                        # the first epoch starts the workers and captures graphs
     best = sorted(spans)[len(spans) // 2]
+    # inside an epoch, away from its first batches (the DataLoader re-primes its prefetch queue at every epoch start, which a
+    # 56-batch epoch feels and a real one does not): from the 8th step's stamp to the drained end of the epoch
+    steady = sorted((st[-1] - st[7]) / (len(st) - 8) for st in (timer.step_stamps[1:] or timer.step_stamps) if len(st) > 16)
+    steady_ms = round(steady[len(steady) // 2] * 1e3, 3) if steady else None
     return {"audio_s_per_s": round(n_batches * args.batch * SECONDS / best, 1), "ms_per_step": round(best / n_batches * 1e3, 3),
+            "ms_per_step_within_epoch": steady_ms,
             "batches_per_epoch": n_batches, "epochs_timed": len(spans), "num_workers": args.fit_workers,
             "epoch_seconds": [round(x, 3) for x in timer.spans], "host_ms_per_step_all_epochs": host,
             "includes": "DataLoader worker processes (in-memory corpus), collate with SpecAugment span draws, pinned-memory H2D "
