@@ -181,3 +181,28 @@ def test_collate_with_speed_perturbation(fake_backend):
         assert float(mel[b, f:].abs().max()) == 0.0 if f < max(frames) else True
     wbv = sets["val"].collate_fn([sets["val"][i] for i in range(4)])[0]
     assert wbv.speed is None                                  # no augmentation outside training
+
+
+def test_background_batch_handover_order_errors_and_early_exit():
+    """ccml.trainer._threaded / _lookahead(background=True): same items in the same order, a producer exception reaches the
+    consumer, and a consumer that stops early releases the helper thread (it must not stay blocked on a full queue)."""
+    import threading
+    import time
+    from ccml.trainer import _lookahead, _threaded
+    assert list(_threaded(range(7))) == list(range(7))
+    assert list(_lookahead(range(4), background=True)) == [(0, 1), (1, 2), (2, 3), (3, None)]
+
+    def failing():
+        yield 1
+        raise ValueError("collate failed")
+
+    with pytest.raises(ValueError, match="collate failed"):
+        list(_threaded(failing()))
+    before = {t.name for t in threading.enumerate()}
+    g = _threaded(iter(range(10 ** 6)))
+    assert next(g) == 0 and next(g) == 1
+    g.close()
+    deadline = time.time() + 5
+    while time.time() < deadline and any(t.name == "ccml-batch-prefetch" and t.is_alive() for t in threading.enumerate()):
+        time.sleep(0.05)
+    assert not any(t.name == "ccml-batch-prefetch" and t.is_alive() for t in threading.enumerate()), before
