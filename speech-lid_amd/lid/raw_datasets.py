@@ -268,7 +268,7 @@ class SyntheticMergedDataset(_CollateMixin, Dataset):
 
     def __init__(self, train: bool, langs: Dict[str, int], lang2vocab: Dict[str, int], items_per_lang: int = 64,
                  seconds: float = 3.0, text_len: int = 20, seed: int = 1234, lang2tokenizer: Dict = None,
-                 min_seconds: Optional[float] = None, transcript: str = "random", **feature):
+                 min_seconds: Optional[float] = None, transcript: str = "random", cache: bool = True, **feature):
         """min_seconds: if given, item i lasts U[min_seconds, seconds] (a pure function of (seed, i)): ragged batches."""
         if transcript not in ("random", "tones"):
             raise ValueError(f"transcript must be 'random' or 'tones', got {transcript!r}")
@@ -285,6 +285,10 @@ class SyntheticMergedDataset(_CollateMixin, Dataset):
             s.set_base_value(len(self.datasets))
             self.samplers.append(s)
             self.datasets += [{"locale": lang, "path": f"synthetic://{lang}/{i}"} for i in range(items_per_lang)]
+        # Generating an utterance (resonator filter + tone synthesis) costs ~5 ms of CPU: at 64 utterances per batch the
+        # DataLoader workers, not the GPU, would set the pace of every epoch.  Items are pure functions of (seed, index), so each
+        # worker keeps what it has generated (up to ~1 GB of waveforms per worker); from the second epoch on it only collates.
+        self._cache = {} if cache and len(self.datasets) * self.n_samples * 4 <= (1 << 30) else None
         self._pairs = {}
         if transcript == "tones":
             for lang, k in self.lang2index_dict.items():
@@ -330,4 +334,9 @@ class SyntheticMergedDataset(_CollateMixin, Dataset):
 
     def __getitem__(self, index):
         item = self.datasets[index]
-        return self.waveform(index), self.text(index), item["path"], item["locale"]
+        if self._cache is None:
+            return self.waveform(index), self.text(index), item["path"], item["locale"]
+        hit = self._cache.get(index)
+        if hit is None:
+            hit = self._cache[index] = (self.waveform(index), self.text(index))
+        return hit[0], hit[1], item["path"], item["locale"]
