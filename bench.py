@@ -375,7 +375,7 @@ def roofline(trainer, batches, step_fn):
     if n3 and ms3 > 0:
         f_gbs = by3 / (ms3 * 1e-3) / 1e9
         feat = {"bound": "hbm", "achieved": round(f_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_gbs / HBM_PEAK_GBS, 4),
-                "kernels": "normalize_wav + dither_preemph + stft_mel + db_floor_mask (one batch)", "ms_per_batch": round(ms3, 4),
+                "kernels": "wav_stats + stft_mel (normalise, dither and pre-emphasis in its frame load) + db_floor_mask (one batch)", "ms_per_batch": round(ms3, 4),
                 "algorithmic_bytes_per_batch": int(by3)}
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": (f"{src} (committed rocprofv3 --pmc pass of this command; not measured in this run)"

@@ -64,6 +64,13 @@ int lidk_speed_perturb(const float* x, int B, int Lin, const int32_t* n_in, floa
 int lidk_logmel(const float* wav, const float* window, const float* twiddle, const float* melfb, float* out,
                 float* utt_max, int B, int L, int pad, int hop, int n_mels, const int32_t* spans, int mask_times,
                 float top_db, const int32_t* n_samples, void* stream);
+/* The same from the RAW waveform: normalize_wav, dither and pre-emphasis (lid/audio_processor.py:108-134) are applied in the
+ * STFT's frame load from per-utterance partial sums, so the prepared waveforms never exist in memory: three launches
+ * (statistics, STFT/mel/dB, floor + masks).  stats: scratch of B * 16 doubles.  noise [B][L] (may be NULL): explicit dither
+ * values instead of the counter-based generator (what lidk_dither_preemph takes). */
+int lidk_wav2mel(const float* wav, const float* window, const float* twiddle, const float* melfb, float* out, float* utt_max,
+                 double* stats, int B, int L, int pad, int hop, int n_mels, const int32_t* spans, int mask_times, float top_db,
+                 const int32_t* n_samples, float coef, float dither, uint64_t seed, const float* noise, void* stream);
 
 /* ------------------------------------------------------------------ generic element-wise helpers */
 /* y = scale * x with dtype conversion (x_dtype/y_dtype in {LIDK_F32, LIDK_BF16}). */

@@ -134,10 +134,38 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
 // and the utterance maximum costs one atomic per run (a per-frame atomic on 64 addresses was 40 % of the kernel).
 // One wave per frame.  LDS per wave: re[512], im[512]; shared twiddle[256][2], window[512].
 #define STFT_WAVES 16
+#define WAV_STAT_PARTS 8
+// Raw-waveform form (lidk_wav2mel): the frame load applies normalize_wav ((x - mean) / (std + 1e-6), unbiased std, from the
+// per-utterance partial sums of wav_stats_kernel), the dither and the pre-emphasis (lid/audio_processor.py:108-134) on the fly:
+//   z(s) = (x[s] - mu) * inv + dither * u(b, s) ;  y(s) = z(s) - coef * z(s - 1)  (s > 0),
+// so the normalised and the pre-emphasised waveforms never exist in HBM.  stats == NULL: wav is consumed as it is.
+struct WavPrep { const double* stats; const float* noise; float coef, dither; unsigned long long seed; };
+
+__global__ void __launch_bounds__(256)
+wav_stats_kernel(const float* __restrict__ wav, int L, const int32_t* __restrict__ n_samples, double* __restrict__ stats,
+                 float* __restrict__ utt_max) {
+  __shared__ double red[4][2];
+  const int b = blockIdx.x, part = blockIdx.y;
+  const int Lb = n_samples ? max(2, min(L, n_samples[b])) : L;
+  const int per = (Lb + WAV_STAT_PARTS - 1) / WAV_STAT_PARTS, lo = part * per, hi = min(Lb, lo + per);
+  const float* x = wav + (size_t)b * L;
+  double s = 0.0, q = 0.0;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) { const double v = (double)x[i]; s += v; q += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s; red[threadIdx.x >> 6][1] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stats[((size_t)b * WAV_STAT_PARTS + part) * 2 + 0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    stats[((size_t)b * WAV_STAT_PARTS + part) * 2 + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    if (part == 0) utt_max[b] = -INFINITY;
+  }
+}
+
 __global__ void __launch_bounds__(64 * STFT_WAVES)
 stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window, const float* __restrict__ twiddle,
                 const float* __restrict__ melfb, float* __restrict__ out, float* __restrict__ utt_max, int B, int L,
-                int pad, int hop, int F, int n_mels, int dbg, const int32_t* __restrict__ n_samples) {
+                int pad, int hop, int F, int n_mels, int dbg, const int32_t* __restrict__ n_samples, WavPrep prep) {
   __shared__ float s_re[STFT_WAVES][LIDK_N_FFT];
   __shared__ float s_im[STFT_WAVES][LIDK_N_FFT];
   __shared__ float s_tw[LIDK_N_FFT / 2][2];
@@ -179,12 +207,22 @@ stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window,
   const long per_wave = (nframes + (long)gridDim.x * STFT_WAVES - 1) / ((long)gridDim.x * STFT_WAVES);
   const long fr0 = ((long)blockIdx.x * STFT_WAVES + wave) * per_wave, fr1 = min(nframes, fr0 + per_wave);
   int run_b = -1;
-  float run_max = -INFINITY;
+  float run_max = -INFINITY, mu = 0.f, inv = 1.f;
   for (long fr = fr0; fr < fr1; ++fr) {
     const int b = (int)(fr / F), f = (int)(fr - (long)b * F);
     if (b != run_b) {                                    // wave-uniform
       if (run_b >= 0 && lane == 0 && !(dbg & 4)) atomic_max_float(&utt_max[run_b], run_max);
       run_b = b; run_max = -INFINITY;
+      if (prep.stats) {                                  // this utterance's mean and 1 / (std + 1e-6)
+        const int Ln = n_samples ? max(2, min(L, n_samples[b])) : L;
+        double sm = 0.0, sq = 0.0;
+        for (int p = 0; p < WAV_STAT_PARTS; ++p) { sm += prep.stats[((size_t)b * WAV_STAT_PARTS + p) * 2]; sq += prep.stats[((size_t)b * WAV_STAT_PARTS + p) * 2 + 1]; }
+        const double mean = sm / (double)Ln;
+        double var = (sq - sm * mean) / (double)(Ln - 1);
+        if (var < 0.0) var = 0.0;
+        mu = (float)mean;
+        inv = 1.0f / ((float)sqrt(var) + 1e-6f);
+      }
     }
     const float* x = wav + (size_t)b * L;
     // ragged batch: the utterance has Lb samples and Fb frames of its own; the rows behind them are the zero padding the
@@ -202,7 +240,22 @@ stft_mel_kernel(const float* __restrict__ wav, const float* __restrict__ window,
       if (p < 0) p = -p;
       if (p >= Lp) p = 2 * (Lp - 1) - p;
       int s = p - pad;
-      float v = (s >= 0 && s < Lb) ? x[s] * s_win[n] : 0.f;
+      float v = 0.f;
+      if (s >= 0 && s < Lb) {
+        if (prep.stats) {
+          const size_t gi = (size_t)b * L + s;
+          float z = (x[s] - mu) * inv;
+          if (prep.dither != 0.f) z += prep.dither * (prep.noise ? prep.noise[gi] : uniform_from(prep.seed, gi));
+          if (s > 0) {
+            float z1 = (x[s - 1] - mu) * inv;
+            if (prep.dither != 0.f) z1 += prep.dither * (prep.noise ? prep.noise[gi - 1] : uniform_from(prep.seed, gi - 1));
+            z -= prep.coef * z1;
+          }
+          v = z * s_win[n];
+        } else {
+          v = x[s] * s_win[n];
+        }
+      }
       int r = (int)(__brev((unsigned)n) >> 23);
       re[r] = v; im[r] = 0.f;
     }
@@ -286,7 +339,32 @@ extern "C" int lidk_logmel(const float* wav, const float* window, const float* t
   long nframes = (long)B * F;
   int blocks = (int)((nframes + STFT_WAVES - 1) / STFT_WAVES); if (blocks > 256) blocks = 256;      // one workgroup per CU
   static const int dbg = getenv("LIDK_STFT_DBG") ? atoi(getenv("LIDK_STFT_DBG")) : 0;     // tuning aid: 1 no FFT, 2 no mel, 4 no max
-  stft_mel_kernel<<<blocks, 64 * STFT_WAVES, 0, s>>>(wav, window, twiddle, melfb, out, utt_max, B, L, pad, hop, F, n_mels, dbg, n_samples);
+  stft_mel_kernel<<<blocks, 64 * STFT_WAVES, 0, s>>>(wav, window, twiddle, melfb, out, utt_max, B, L, pad, hop, F, n_mels, dbg, n_samples,
+                                                     WavPrep{nullptr, nullptr, 0.f, 0.f, 0ull});
+  long n = nframes * n_mels;
+  int eb = (int)((n + 255) / 256); if (eb > 8192) eb = 8192;
+  db_floor_mask_kernel<<<eb, 256, 0, s>>>(out, utt_max, spans, mask_times > 0 ? mask_times : 0, F, n_mels, n, top_db, n_samples, L, pad, hop);
+  return launch_status();
+}
+
+// Raw waveform -> log-mel in three launches (statistics, STFT with the waveform preparation in its frame load, floor + masks)
+// instead of five: normalize_wav + dither/pre-emphasis + log-mel of lid/audio_processor.py:72-134.  stats: B * 16 doubles of
+// scratch.  noise (may be NULL): explicit dither values [B][L] instead of the counter-based generator (tests).
+extern "C" int lidk_wav2mel(const float* wav, const float* window, const float* twiddle, const float* melfb, float* out,
+                            float* utt_max, double* stats, int B, int L, int pad, int hop, int n_mels, const int32_t* spans,
+                            int mask_times, float top_db, const int32_t* n_samples, float coef, float dither, uint64_t seed,
+                            const float* noise, void* stream) {
+  if (!wav || !window || !twiddle || !melfb || !out || !utt_max || !stats || B <= 0 || L < 2 || hop <= 0 || pad < 0 || n_mels <= 0)
+    return LIDK_ERR_ARG;
+  if (L + 2 * pad <= LIDK_N_FFT / 2) return LIDK_ERR_ARG;
+  if (mask_times > 0 && !spans) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  const int F = 1 + (L + 2 * pad) / hop;
+  wav_stats_kernel<<<dim3(B, WAV_STAT_PARTS), 256, 0, s>>>(wav, L, n_samples, stats, utt_max);
+  long nframes = (long)B * F;
+  int blocks = (int)((nframes + STFT_WAVES - 1) / STFT_WAVES); if (blocks > 256) blocks = 256;
+  stft_mel_kernel<<<blocks, 64 * STFT_WAVES, 0, s>>>(wav, window, twiddle, melfb, out, utt_max, B, L, pad, hop, F, n_mels, 0, n_samples,
+                                                     WavPrep{stats, noise, coef, dither, (unsigned long long)seed});
   long n = nframes * n_mels;
   int eb = (int)((n + 255) / 256); if (eb > 8192) eb = 8192;
   db_floor_mask_kernel<<<eb, 256, 0, s>>>(out, utt_max, spans, mask_times > 0 ? mask_times : 0, F, n_mels, n, top_db, n_samples, L, pad, hop);

@@ -177,11 +177,15 @@ class WaveBatch:
             raise LidkError("WaveBatch.to_mel: the feature path runs on the GPU only (no CPU fallback)")
         x = self.wav.contiguous()
         ns = self.n_samples.contiguous() if self.n_samples is not None else None
+        spans = self.spans.contiguous() if self.spans is not None else None
+        if self.normalize and self.preemph and self.speed is None and hasattr(_ops, "wav2mel"):
+            # normalise + dither + pre-emphasis inside the STFT's frame load: three launches, no intermediate waveforms
+            return _ops.wav2mel(x, pad=self.pad, n_mels=self.n_mels, spans=spans, n_samples=ns, coef=0.97, dither=1e-5,
+                                seed=self.dither_seed)
         if self.normalize:
             x = _ops.normalize_wav(x, n_samples=ns)
         if self.preemph:
             x = _ops.dither_preemph(x, coef=0.97, dither=1e-5, seed=self.dither_seed)
         if self.speed is not None:          # reference order: dither, pre-emphasis, then the sox speed effect
             x, ns, _ = _ops.speed_perturb(x, self.speed, ns)
-        spans = self.spans.contiguous() if self.spans is not None else None
         return _ops.logmel(x, pad=self.pad, n_mels=self.n_mels, spans=spans, n_samples=ns)

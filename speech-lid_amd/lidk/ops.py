@@ -158,6 +158,22 @@ def logmel(wav, pad=0, hop=160, win_length=400, n_mels=80, spans=None, top_db=80
     return out
 
 
+def wav2mel(wav, pad=0, hop=160, win_length=400, n_mels=80, spans=None, top_db=80.0, out=None, n_samples=None, coef=0.97,
+            dither=1e-5, seed=0, noise=None):
+    """RAW wav (B, L) f32 -> (B, F, n_mels) f32 dB: normalize_wav + dither / pre-emphasis + logmel in three launches (the
+    waveform preparation happens in the STFT's frame load)."""
+    B, Lw = wav.shape
+    F_ = 1 + (Lw + 2 * pad) // hop
+    win, tw, fb = fft_tables(wav.device, win_length, n_mels)
+    out = torch.empty(B, F_, n_mels, device=wav.device, dtype=torch.float32) if out is None else out
+    umax = torch.empty(B, device=wav.device, dtype=torch.float32)
+    stats = torch.empty(B * 16, device=wav.device, dtype=torch.float64)
+    mt = 0 if spans is None else spans.shape[1]
+    check(lib().lidk_wav2mel(_p(wav), _p(win), _p(tw), _p(fb), _p(out), _p(umax), _p(stats), B, Lw, pad, hop, n_mels, _p(spans), mt,
+                             top_db, _p(n_samples), coef, dither, seed, _p(noise), _stream()), "wav2mel")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- element-wise
 def scale_cast(x, out, scale=1.0):
     check(lib().lidk_scale_cast(_p(x), _code(x), _p(out), _code(out), x.numel(), scale, _stream()), "scale_cast")

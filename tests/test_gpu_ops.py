@@ -621,6 +621,37 @@ def test_normalize_dither_preemph():
     check("dither_preemph_gen", out2, of.dither_preemphasis(w), 2.1e-5)        # differs only by the 1e-5*U dither
 
 
+@pytest.mark.parametrize("ragged", [False, True])
+def test_wav2mel_fused_equals_the_three_kernel_path_and_the_oracle(ragged):
+    """lidk_wav2mel (normalise + dither + pre-emphasis inside the STFT's frame load) against normalize_wav -> dither_preemph ->
+    logmel with the same explicit dither values, and against the oracle's composition; SpecAugment spans included."""
+    B, L_, pad = 5, 48000, 16
+    w = 2.0 + 1.5 * torch.randn(B, L_, generator=g(180)) * torch.linspace(0.1, 1.0, L_)
+    noise = torch.rand(B, L_, generator=g(181))
+    ns = torch.tensor([48000, 31000, 47999, 16000, 40123], dtype=torch.int32) if ragged else None
+    if ragged:
+        for i, n in enumerate(ns.tolist()):
+            w[i, n:] = 0.0
+    spans = torch.tensor([[[10, 25, 5, 17]]] * B, dtype=torch.int32)
+    nsd = ns.to(DEV) if ragged else None
+    x1 = ops.normalize_wav(dev(w), n_samples=nsd)
+    x2 = ops.dither_preemph(x1, noise=dev(noise))
+    ref3 = ops.logmel(x2, pad=pad, spans=spans.to(DEV), n_samples=nsd)
+    got = ops.wav2mel(dev(w), pad=pad, spans=spans.to(DEV), n_samples=nsd, noise=dev(noise))
+    assert got.shape == ref3.shape
+    err = (got - ref3).abs()
+    print(f"[wav2mel fused vs 3 kernels, ragged={ragged}] max {float(err.max()):.2e} dB, median {float(err.median()):.2e}")
+    assert float(err.max()) <= 2e-3 and float(err.median()) <= 2e-5
+    # oracle composition (per utterance when ragged)
+    for i in range(B):
+        n = int(ns[i]) if ragged else L_
+        xo = of.dither_preemphasis(of.normalize_wav(w[i:i + 1, :n]), noise[i:i + 1, :n])
+        mo = of.apply_specaug(of.wav2mel(xo, pad=pad)[0], [tuple(spans[i, 0].tolist())]).transpose(0, 1)
+        e = (got[i, :mo.shape[0]].cpu() - mo).abs()
+        assert float(e.max()) <= 5e-3, (i, float(e.max()))
+        assert float(got[i, mo.shape[0]:].abs().max() if mo.shape[0] < got.shape[1] else 0.0) == 0.0
+
+
 @pytest.mark.parametrize("L_,pad,B", [(16000, 0, 4), (48000, 16, 3), (4000, 0, 2)])
 def test_logmel_matches_oracle(L_, pad, B):
     w = of.normalize_wav(torch.randn(B, L_, generator=g(52)) * torch.linspace(0.2, 1.0, L_))
