@@ -194,10 +194,13 @@ class WavLMMutiLangModel(_EngineBoundModel):
         live = {n: params["model.featurizer.model." + n] for n in self._bb_names
                 if params["model.featurizer.model." + n].requires_grad}
         bb._alloc_grads()
-        if any(p.grad is None for p in live.values()):            # zero_grad(set_to_none) since the last backward: new step
+        masked = bb.cfg.get("mask_prob", 0.0) > 0
+        # zero_grad(set_to_none) since the last backward = a new optimizer step: start the arena from zero.  mask_emb never gets
+        # a .grad while nothing is masked, so it must not take part in this test: with it, every micro-batch of an
+        # accumulate_grad > 1 step would wipe the arena and only the last one's gradients would survive.
+        if any(p.grad is None for n, p in live.items() if masked or n != "mask_emb"):
             bb.zero_grads()
         bb.backward(dfeat, *self._bb_shape, wgrads=not frozen)
-        masked = bb.cfg.get("mask_prob", 0.0) > 0
         for n, p in live.items():
             if n == "mask_emb" and not masked:                     # no span was replaced: the reference leaves .grad None
                 continue
