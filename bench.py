@@ -48,8 +48,10 @@ SECONDS = 3.0
 BATCH = 64
 N_LANGS = 14
 SETUP_ROUNDS = 3                    # visits of every language before warm-up (eager, capture, replay of each head's graphs)
-PMC_FILE = os.path.join("profiles", "r02", "pmc_traffic.json")
-PMC_FALLBACK = os.path.join("profiles", "r01", "pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03", "pmc_traffic.json")
+PMC_FALLBACK = os.path.join("profiles", "r02", "pmc_traffic.json")
+ROCPROF_STATS = (os.path.join("profiles", "r03", "bench_kernel_stats.csv"), os.path.join("profiles", "r02", "bench_v2_kernel_stats.csv"))
+FLOP_PER_UTT_TRAIN = 21.67e9       # 7.222 GFLOP forward per 3 s utterance x 3 (one head, stochastic depth off)
 
 
 def build(args, rank, world, device):
@@ -285,14 +287,57 @@ def _pmc_traffic(kernel_prefix):
     return None, None
 
 
+def _rocprof_avg_us(prefixes):
+    """Launch-weighted average duration of the kernels whose name contains one of ``prefixes`` in the committed rocprofv3
+    --kernel-trace --stats summary of this command (profiles/r03/bench_kernel_stats.csv) -> (us, launches, file) or Nones."""
+    import csv
+    for rel in ROCPROF_STATS:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        tot, n = 0.0, 0
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if any(px in row["Name"] for px in prefixes):
+                    tot += float(row["TotalDurationNs"])
+                    n += int(row["Calls"])
+        if n:
+            return round(tot / n / 1e3, 3), n, rel
+    return None, None, None
+
+
+def _replay_ms(calls, reps=9):
+    """Device time of ``calls`` (a list of zero-argument launchers) issued back-to-back from ONE captured hipGraph, median of
+    ``reps`` replays bracketed by two HIP events on the replay stream.  Nothing is subtracted: the figure contains the gaps
+    between consecutive kernel nodes, so it can only under-state the kernels' own rate."""
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        for c in calls:
+            c()
+    g.replay()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    return sorted(times)[len(times) // 2]
+
+
 def roofline(trainer, batches, step_fn):
-    """Bracket every launch of the dominant kernel (gemm_nt: every Linear / 1x1 conv forward and its data gradient) of ONE
-    training step with HIP events on the launch stream, the weight-gradient GEMM (gemm_tn) and the feature path likewise.
+    """The dominant kernel (gemm_nt: every Linear / 1x1 conv forward and its data gradient), the weight-gradient GEMM
+    (gemm_tn) and the feature path, measured live and WITHOUT any calibration constant: one training step runs through the
+    eager launch path with every launch of these kernels recorded (operands are the step's own workspace buffers); the
+    recorded launches of a kind are then captured into ONE hipGraph, back-to-back in step order, and that graph is replayed
+    between two HIP events on its stream: average launch = replay time / launches.  The figure includes the gap between
+    consecutive kernel nodes (it can only under-state the kernel); the launch-weighted average of the same kernels in the
+    committed rocprofv3 --kernel-trace --stats summary of this command is printed beside it (``rocprof_avg_us``).
     With K = 256..1024 these GEMMs sit below the machine balance (about 150 FLOP per algorithmic byte against
     2500 TF/s / 8 TB/s = 312), so the roofline that bounds them is HBM: achieved = algorithmic bytes (operands read once,
-    outputs written once) / measured time.  The MFMA rate of the same launches is reported beside it.
-    The step runs through the eager launch path (events cannot be recorded inside a hipGraph capture); kernels and shapes
-    are those of the timed steps.  The cost of an empty event bracket is measured and subtracted."""
+    outputs written once) / measured time.  The MFMA rate of the same launches is reported beside it."""
     from lid.audio_processor import WaveBatch
     eng = trainer.engine
     k = eng.k
@@ -302,14 +347,6 @@ def roofline(trainer, batches, step_fn):
     def esz(t):
         return t.element_size()
 
-    def bracket(kind, fn, flops, nbytes, *a, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = fn(*a, **kw)
-        e1.record()
-        rec[kind].append((e0, e1, flops, nbytes))
-        return r
-
     def timed_nt(A, B, out, *a, M=None, N=None, K=None, **kw):
         m, kk, n = (A.shape[0] if M is None else M), (A.shape[1] if K is None else K), (B.shape[0] if N is None else N)
         a_cols = min(kk, A.stride(0))                 # a strided-view convolution operand: each input value is read once
@@ -317,19 +354,25 @@ def roofline(trainer, batches, step_fn):
         for key in ("out2", "aux", "res"):
             if kw.get(key) is not None:
                 nbytes += m * n * esz(kw[key])
+        for key in ("A2",):                           # recompute epilogues read a second operand panel
+            if kw.get(key) is not None:
+                nbytes += m * kw[key].shape[1] * esz(kw[key])
         if kw.get("bias") is not None:
             nbytes += n * 4
-        return bracket("nt", orig_nt, 2.0 * m * n * kk, nbytes, A, B, out, *a, M=M, N=N, K=K, **kw)
+        rec["nt"].append((lambda: orig_nt(A, B, out, *a, M=M, N=N, K=K, **kw), 2.0 * m * n * kk, nbytes))
+        return orig_nt(A, B, out, *a, M=M, N=N, K=K, **kw)
 
     def timed_tn(X, Y, C, *a, M=None, N1=None, N2=None, **kw):
         m, n1, n2 = (X.shape[0] if M is None else M), (X.shape[1] if N1 is None else N1), (Y.shape[1] if N2 is None else N2)
         nbytes = m * n1 * esz(X) + m * n2 * esz(Y) + n1 * n2 * 4
-        return bracket("tn", orig_tn, 2.0 * m * n1 * n2, nbytes, X, Y, C, *a, M=M, N1=N1, N2=N2, **kw)
+        rec["tn"].append((lambda: orig_tn(X, Y, C, *a, M=M, N1=N1, N2=N2, **kw), 2.0 * m * n1 * n2, nbytes))
+        return orig_tn(X, Y, C, *a, M=M, N1=N1, N2=N2, **kw)
 
     def timed_mel(self):
         Bn, Ln = self.wav.shape
         F_ = 1 + (Ln + 2 * self.pad) // 160
-        return bracket("feat", lambda: orig_mel(self), 0.0, Bn * (4 * Ln + 4 * self.n_mels * F_))
+        rec["feat"].append((lambda: orig_mel(self), 0.0, Bn * (4 * Ln + 4 * self.n_mels * F_)))
+        return orig_mel(self)
 
     graphs_on = eng.graphs.enabled
     eng.graphs.enabled = False
@@ -342,30 +385,31 @@ def roofline(trainer, batches, step_fn):
     finally:
         k.gemm_nt, k.gemm_tn, WaveBatch._compute_mel = orig_nt, orig_tn, orig_mel
         eng.graphs.enabled = graphs_on
-    empty = []
-    for _ in range(200):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); e1.record()
-        empty.append((e0, e1))
-    torch.cuda.synchronize()
-    ovh = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]          # median, ms
 
     def tot(kind):
-        ms = sum(max(a.elapsed_time(b) - ovh, 0.0) for a, b, _, _ in rec[kind])
-        return ms, sum(f for _, _, f, _ in rec[kind]), sum(n for _, _, _, n in rec[kind]), len(rec[kind])
+        if not rec[kind]:
+            return 0.0, 0.0, 0, 0
+        ms = _replay_ms([c for c, _, _ in rec[kind]])
+        return ms, sum(f for _, f, _ in rec[kind]), sum(n for _, _, n in rec[kind]), len(rec[kind])
 
     ms, fl, by, n = tot("nt")
     ms2, fl2, by2, n2 = tot("tn")
     ms3, _, by3, n3 = tot("feat")
+    trainer._zero_grad()                               # the replayed weight-gradient launches accumulated into the arena
+    torch.cuda.synchronize()
     gbs = by / (ms * 1e-3) / 1e9
     tfs = fl / (ms * 1e-3) / 1e12
+    method = ("all launches of one step captured back-to-back into one hipGraph, replay time / launches between two HIP events "
+              "(nothing subtracted; contains the inter-node gaps)")
+    rp_us, rp_n, rp_src = _rocprof_avg_us(("gemm_nt_bf16_",))
+    rp2_us, _, _ = _rocprof_avg_us(("gemm_tn_bf16_kernel",))
     if fl / max(by, 1) > MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):          # above the machine balance: MFMA-bound
         return {"bound": "mfma", "achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tfs / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "traffic_source": None,
                 "kernel": "gemm_nt (gemm_nt_bf16_direct_kernel, 64x64 tiles: strided-view convolutions, projections, FFN)",
                 "launches_per_step": n, "avg_launch_us": round(ms * 1e3 / n, 2), "kernel_ms_per_step": round(ms, 3),
                 "flops_per_launch": round(fl / n), "algorithmic_bytes_per_launch": round(by / n),
-                "flop_per_byte": round(fl / max(by, 1), 1), "event_bracket_overhead_us": round(ovh * 1e3, 2),
+                "flop_per_byte": round(fl / max(by, 1), 1), "method": method,
                 "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
                 "wgrad_kernel": {"kernel": "gemm_tn_bf16_kernel<64,64>", "launches_per_step": n2,
                                  "avg_launch_us": round(ms2 * 1e3 / max(n2, 1), 2)} if n2 else None}
@@ -375,18 +419,21 @@ def roofline(trainer, batches, step_fn):
     if n3 and ms3 > 0:
         f_gbs = by3 / (ms3 * 1e-3) / 1e9
         feat = {"bound": "hbm", "achieved": round(f_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_gbs / HBM_PEAK_GBS, 4),
-                "kernels": "wav_stats + stft_mel (normalise, dither and pre-emphasis in its frame load) + db_floor_mask (one batch)", "ms_per_batch": round(ms3, 4),
-                "algorithmic_bytes_per_batch": int(by3)}
+                "kernels": "waveform statistics + STFT/mel (normalise, dither and pre-emphasis in its frame load) + dB floor / SpecAugment (one batch)",
+                "ms_per_batch": round(ms3, 4), "algorithmic_bytes_per_batch": int(by3)}
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": (f"{src} (committed rocprofv3 --pmc pass of this command; not measured in this run)"
                                                    if src else None),
             "kernel": "gemm_nt (gemm_nt_bf16_pipe_kernel + gemm_nt_bf16_direct_kernel, 64x64 tiles)",
             "launches_per_step": n, "avg_launch_us": round(ms * 1e3 / n, 2), "kernel_ms_per_step": round(ms, 3),
-            "algorithmic_bytes_per_launch": round(by / n), "event_bracket_overhead_us": round(ovh * 1e3, 2),
+            "algorithmic_bytes_per_launch": round(by / n), "method": method,
+            "rocprof_avg_us": rp_us, "rocprof_launches": rp_n, "rocprof_source": rp_src,
+            "frac_from_rocprof": (round(by / n / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rp_us else None),
             "mfma": {"achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
             "wgrad_kernel": {"kernel": "gemm_tn_bf16_kernel<64,64>", "launches_per_step": n2,
-                             "avg_launch_us": round(ms2 * 1e3 / n2, 2), "GB/s": round(by2 / (ms2 * 1e-3) / 1e9, 1),
+                             "avg_launch_us": round(ms2 * 1e3 / n2, 2), "rocprof_avg_us": rp2_us,
+                             "GB/s": round(by2 / (ms2 * 1e-3) / 1e9, 1),
                              "TFLOP/s": round(fl2 / (ms2 * 1e-3) / 1e12, 1), "traffic": traffic2},
             "features": feat}
 

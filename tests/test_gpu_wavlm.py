@@ -202,8 +202,15 @@ def test_head_training_step_on_frozen_backbone_against_the_reference(dt):
 
 
 def _cmp_grads(g, grad_of, tag, cos_min=0.99, nrel_max=0.08, skip=()):
+    """Norm + sampled direction of every gradient tensor against the reference's autograd.
+
+    ``grep_linear.bias`` (the GRU gate's bias) is held to an ABSOLUTE bound instead: its two distinct values are sums of the
+    same signed per-(row, head) terms whose |.|-weighted sums make up ``grep_linear.weight``'s gradient, and they cancel almost
+    completely (reference: |d bias| = 0.013 against |d weight| = 3.55 on the ragged batch, 0.18 against 1.5 on the 1 s batch),
+    so bf16 rounding of dS is judged against the uncancelled scale: |got - ref| <= 1 % of |d grep_linear.weight| / sqrt(dh)."""
     big = float(g["grad_norms"].max())
-    worst_cos, worst_n, bad, n = 1.0, 0.0, [], 0
+    norms = {str(n): float(v) for n, v in zip(g["grad_names"], g["grad_norms"])}
+    worst_cos, worst_n, bad, n, rows = 1.0, 0.0, [], 0, []
     for name, ref_norm in zip(g["grad_names"], g["grad_norms"]):
         name = str(name)
         if ref_norm < 1e-6 * big or name in skip:
@@ -214,12 +221,23 @@ def _cmp_grads(g, grad_of, tag, cos_min=0.99, nrel_max=0.08, skip=()):
         idx = (torch.randperm(got.numel(), generator=torch.Generator().manual_seed(wc._seed(name)))[:2048].sort().values
                if got.numel() > 2048 else torch.arange(got.numel()))
         gs, rs = got[idx.to(got.device)].cpu().double(), torch.from_numpy(g["gs::" + name]).double()
+        if name.endswith("grep_linear.bias"):
+            scale = norms[name.replace("grep_linear.bias", "grep_linear.weight")] / 8.0
+            err = float((gs - rs).abs().max())
+            rows.append((round(err / scale, 5), name, "abs/|dW|"))
+            n += 1
+            if err > 1e-2 * scale:
+                bad.append((name, "abs", err, scale))
+            continue
         cos = float((gs @ rs) / (gs.norm() * rs.norm() + 1e-300))
         nrel = abs(float(got.double().norm()) - ref_norm) / ref_norm
         worst_cos, worst_n, n = min(worst_cos, cos), max(worst_n, nrel), n + 1
+        rows.append((round(max(1 - cos, nrel), 5), name, f"cos {cos:.5f} nrel {nrel:.4f}"))
         if cos < cos_min or nrel > nrel_max:
             bad.append((name, round(cos, 5), round(nrel, 4)))
-    print(f"[{tag}] {n} gradient tensors: worst sampled cosine {worst_cos:.5f}, worst norm rel err {worst_n:.3e}")
+    rows.sort(reverse=True)
+    print(f"[{tag}] {n} gradient tensors: worst sampled cosine {worst_cos:.5f}, worst norm rel err {worst_n:.3e}; "
+          f"furthest: {rows[:4]}")
     assert not bad, bad[:10]
     return n
 
