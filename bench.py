@@ -738,6 +738,13 @@ def main():
                 "value_at_median": round(world * args.batch * SECONDS / (med * 1e-3), 1),
                 "loss_first_last": [round(float(loss_vals[0]), 4), round(float(loss_vals[-1]), 4)], "loss_finite": finite,
                 "host_issue_ms_per_step": round(host_issue * 1e3, 3), "phases_ms": phases, "roofline": roof,
+                # whole step against the MFMA roof: SURVEY 8d's algorithmic FLOPs (21.67 GFLOP per 3 s utterance: one head,
+                # every block) over the timed wall clock - only meaningful for the headline Conformer workload
+                "whole_step_tflops": (round(world * args.batch * FLOP_PER_UTT_TRAIN * args.steps / elapsed / 1e12, 1)
+                                      if args.model == "conformer" and args.blocks == 12 and not args.stochastic_depth else None),
+                "whole_step_mfma_frac": (round(world * args.batch * FLOP_PER_UTT_TRAIN * args.steps / elapsed / 1e12
+                                               / (MFMA_BF16_PEAK_TFLOPS * world), 4)
+                                         if args.model == "conformer" and args.blocks == 12 and not args.stochastic_depth else None),
                 "val_cavg": cavg["val_cavg"] if cavg else None, "cavg": cavg, "fit": fit, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1:

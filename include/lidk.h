@@ -338,6 +338,26 @@ int lidk_wavlm_attn_fwd_probs(const void* qkv, const float* gate, const float* r
 int lidk_wavlm_attn_bias_grads(const void* ds, const float* gate, const float* rb, float* dgate, float* drb, int B, int T, int H,
                                int RB, int ldp, void* stream);
 
+/* ------------------------------------------------------------------ key-tiled attention of the transformer backbones
+ * Replaces F.multi_head_attention_forward as lid/wavlm/modules.py:505-700 calls it (WavLM: additive gated relative-position bias,
+ * attention dropout) and fairseq's MultiheadAttention as lid/s3prl_updream/wav2vec/wav2vec2.py:1009-1078 calls it (wav2vec2:
+ * key_padding_mask, attention dropout).  qkv [B*T][3*H*dh] bf16 (q | k | v blocks), out [B*T][H*dh] bf16, dh = 64, any
+ * T <= lidk_xattn_max_frames(dh):
+ *   S[i][j] = q_i.k_j / sqrt(dh) + gate[b][h][i] * rb[h][j - i + RB - 1]   (gate [B][H][T], rb [H][2*RB-1] f32, RB >= T; both NULL:
+ *             no bias);  keys j >= klen[b] are masked out (klen [B] int32, NULL: none; padding is a suffix);
+ *   A = softmax_j S;  with drop_p > 0 or a forced mask `keep` [B][H][T][T] u8: Ad = A * keep / (1 - drop_p), the decision for
+ *   element (b, h, i, j) being keep[...] != 0 or uniform(seed, ((b*H + h)*T + i)*T + j) >= drop_p;  out = Ad . v.
+ * No T x T tensor reaches HBM: lse [B][H][T] f32 (log-sum-exp of each score row) is all the backward needs besides out.
+ * lidk_xattn_bwd: dqkv [B*T][3*H*dh] bf16 (dq | dk | dv) is written; delta [B][H][T] f32 is scratch; dgate [B][H][T] f32 is
+ * written and drb [H][2*RB-1] f32 ACCUMULATED (either may be NULL; both ignored without a bias). */
+int lidk_xattn_max_frames(int dh);
+int lidk_xattn_fwd(const void* qkv, const float* gate, const float* rb, const int* klen, void* out, float* lse,
+                   const unsigned char* keep, float drop_p, unsigned long long seed, int B, int T, int H, int dh, int RB,
+                   void* stream);
+int lidk_xattn_bwd(const void* qkv, const float* gate, const float* rb, const int* klen, const void* out, const void* dout,
+                   const float* lse, const unsigned char* keep, float drop_p, unsigned long long seed, void* dqkv, float* delta,
+                   float* dgate, float* drb, int B, int T, int H, int dh, int RB, void* stream);
+
 /* ------------------------------------------------------------------ fused clip + Novograd over the flat arenas
  * ccml/trainer.py:541-543 clip_grad_norm_(max_norm) + ccml/optim/novograd.py:75-145 (amsgrad=False, luc=False).
  * work [n_work][3] int64 = (tensor id, element offset into the flat arenas, length <= LIDK_OPT_CHUNK); items of one tensor

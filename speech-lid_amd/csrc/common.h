@@ -82,6 +82,28 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* X, int ld, int k0, int n0,
   return u.v;
 }
 
+// Counter-based generator: splitmix64 of (seed, element index) -> 24-bit uniform.  Stateless, so the same (seed, index) gives
+// the same decision on every rank and in the backward pass (lidk_dropout, attention dropout of lidk_xattn_*).
+__device__ __forceinline__ float uniform_from(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// Like tr_frag, for an MFMA whose 32 contraction slots are PERMUTED: slot (fq, jj) stands for row k0 + 4*fq + jj (jj < 4) and
+// k0 + 16 + 4*fq + (jj - 4) (jj >= 4).  That is the order in which a lane holds two stacked 16x16 accumulator tiles
+// (rows 4*fq + r of the first, 16 + 4*fq + r of the second), so those accumulators - packed to bf16 - ARE the other operand:
+// P^T.dO, dS^T.Q, P.V and dS.K need no transposition through LDS.
+__device__ __forceinline__ bf16x8 tr_frag_split(const bf16* X, int ld, int k0, int n0, int fq, int fr) {
+  const bf16* p0 = X + (size_t)(k0 + 4 * fq + (fr >> 2)) * ld + n0 + 4 * (fr & 3);
+  union { struct { s16x4_t lo, hi; } h; bf16x8 v; } u;
+  u.h.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)p0);
+  u.h.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p0 + 16 * ld));
+  return u.v;
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? LIDK_OK : LIDK_ERR_LAUNCH; }
 

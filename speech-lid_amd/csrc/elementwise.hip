@@ -64,16 +64,7 @@ extern "C" int lidk_scale_cast_2d(const void* x, int ldx, int xd, void* y, int l
 }
 
 // ------------------------------------------------------------------------------------ dropout
-// Counter-based generator: splitmix64 of (seed, element index) -> 24-bit uniform.  Stateless, so the same
-// (seed, index) gives the same decision on every rank and in the backward pass.
-__device__ __forceinline__ float uniform_from(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
-
+// Counter-based generator uniform_from(seed, index): common.h
 template <typename TI, typename TO>
 __global__ void dropout_kernel(const TI* __restrict__ x, TO* __restrict__ y, const uint8_t* __restrict__ keep_in,
                                uint8_t* __restrict__ keep_out, long n, float p, float inv_keep, uint64_t seed) {

@@ -44,13 +44,7 @@ extern "C" int lidk_normalize_wav(const float* wav, float* out, int B, int L, co
 }
 
 // ------------------------------------------------------------------------------------ dither + pre-emphasis
-__device__ __forceinline__ float uniform_from(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
+// uniform_from(seed, index): common.h
 
 __global__ void dither_preemph_kernel(const float* __restrict__ wav, float* __restrict__ out, const float* __restrict__ noise,
                                       int L, long n, float coef, float dither, uint64_t seed) {

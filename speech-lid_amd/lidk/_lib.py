@@ -100,6 +100,9 @@ SIGNATURES = {
     "lidk_wavlm_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lidk_wavlm_attn_fwd_probs": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lidk_wavlm_attn_bias_grads": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lidk_xattn_max_frames": (_I, [_I]),
+    "lidk_xattn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _U64, _I, _I, _I, _I, _I, _P]),
+    "lidk_xattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lidk_ctc_greedy": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "lidk_lid_mlp": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_novograd_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P]),

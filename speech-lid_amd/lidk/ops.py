@@ -577,6 +577,33 @@ def wavlm_attn_bwd(qkv, probs, dout, gate, rb, dqkv, dgate, drb, dscores, B, T, 
                                     B, T, H, dh, RB, _stream()), "wavlm_attn_bwd")
 
 
+def xattn_max_frames(dh):
+    return lib().lidk_xattn_max_frames(dh)
+
+
+def xattn_fwd(qkv, out, lse, B, T, H, dh, gate=None, rb=None, klen=None, keep=None, drop_p=0.0, seed=0):
+    """Key-tiled attention forward (any T): out (B*T, H*dh) bf16, lse (B, H, T) f32.  gate (B, H, T) + rb (H, 2*RB-1): WavLM's
+    gated relative-position bias; klen (B,) int32: keys at or beyond it are masked (wav2vec2's key padding mask); keep
+    (B, H, T, T) uint8 forces the attention-dropout mask (tests), drop_p > 0 draws it from (seed, element index)."""
+    if (gate is None) != (rb is None):
+        raise LidkError("xattn_fwd: gate and rb come together")
+    RB = (rb.shape[1] + 1) // 2 if rb is not None else T
+    if klen is not None and klen.dtype != torch.int32:
+        raise LidkError("xattn_fwd: klen must be int32")
+    check(lib().lidk_xattn_fwd(_p(qkv), _p(gate), _p(rb), _p(klen), _p(out), _p(lse), _p(keep), float(drop_p), int(seed), B, T, H,
+                               dh, RB, _stream()), "xattn_fwd")
+    return out
+
+
+def xattn_bwd(qkv, out, dout, lse, dqkv, delta, B, T, H, dh, gate=None, rb=None, klen=None, keep=None, drop_p=0.0, seed=0,
+              dgate=None, drb=None):
+    """Backward of xattn_fwd from out, lse and dout: dqkv (dq | dk | dv) written, dgate written, drb accumulated."""
+    RB = (rb.shape[1] + 1) // 2 if rb is not None else T
+    check(lib().lidk_xattn_bwd(_p(qkv), _p(gate), _p(rb), _p(klen), _p(out), _p(dout), _p(lse), _p(keep), float(drop_p), int(seed),
+                               _p(dqkv), _p(delta), _p(dgate), _p(drb), B, T, H, dh, RB, _stream()), "xattn_bwd")
+    return dqkv
+
+
 def wavlm_gate_bwd(x, wg, bg, grep_a, dgate, dx, dwg, dbg, dgrep_a, B, T, H, dh):
     check(lib().lidk_wavlm_gate_bwd(_p(x), _p(wg), _p(bg), _p(grep_a), _p(dgate), _p(dx), _p(dwg), _p(dbg), _p(dgrep_a), B, T, H,
                                     dh, _stream()), "wavlm_gate_bwd")
