@@ -83,6 +83,10 @@ int lidk_scale_cast_2d(const void* x, int ldx, int x_dtype, void* y, int ldy, in
  * non-NULL, written there. */
 int lidk_dropout(const void* x, int x_dtype, void* y, int y_dtype, const uint8_t* keep_in, uint8_t* keep_out, long n,
                  float p, uint64_t seed, void* stream);
+/* out[i] = res[i] + dropout(x)[i] (f32), same decisions as lidk_dropout for the same (seed, index) / forced mask: the transformer
+ * layers' dropout1 / dropout3 in front of the residual add (lid/wavlm/WavLM.py:745-771). */
+int lidk_dropout_add(const float* x, const float* res, float* out, const uint8_t* keep_in, long n, float p, uint64_t seed,
+                     void* stream);
 /* dx = dy * (y > 0)   (backward of nn.ReLU in Conv1dSubSampling2, lid/conformer.py:331-333). */
 int lidk_relu_bwd(const void* dy, const void* y, void* dx, long n, int dtype, void* stream);
 /* out[n] += scale * sum_m x[m][n]   (bias gradients).  partial: >= LIDK_LN_PARTIAL_BLOCKS*N floats. */
@@ -337,6 +341,19 @@ int lidk_wavlm_attn_fwd_probs(const void* qkv, const float* gate, const float* r
  * lid/wavlm/modules.py:505-560 on the MFMA path. */
 int lidk_wavlm_attn_bias_grads(const void* ds, const float* gate, const float* rb, float* dgate, float* drb, int B, int T, int H,
                                int RB, int ldp, void* stream);
+
+/* ------------------------------------------------------------------ wav2vec2 pieces
+ * lidk_zero_padded_rows: x [B][T][C] f32, rows t >= klen[b] become zero - TransformerEncoder.extract_features zeroes padded frames
+ * before the positional convolution (lid/s3prl_updream/wav2vec/wav2vec2.py:906-907); the backward zeroes the same gradient rows.
+ * lidk_hidden_mix_*: s3prl Featurizer._weighted_sum (lid/s3prl_updream/interfaces.py:227-252), feature = sum_l softmax(w)[l] * h_l
+ * over the n_states = L + 1 hidden states (w [n_states] f32, the trainable `model.featurizer.weights`):
+ *   axpy : out[n] = (overwrite ? 0 : out[n]) + softmax(w)[l] * h[n]      (forward accumulation; backward dh_l += sm[l] * dfeat)
+ *   dot  : *dot += <a, b>                                                  (dots[l] = <dfeat, h_l>)
+ *   wgrad: dw[l] += sm[l] * (dots[l] - sum_k sm[k] * dots[k])              (softmax backward, one launch) */
+int lidk_zero_padded_rows(float* x, const int* klen, int B, int T, int C, void* stream);
+int lidk_hidden_mix_axpy(const float* h, const float* w, int n_states, int l, float* out, long n, int overwrite, void* stream);
+int lidk_hidden_mix_dot(const float* a, const float* b, float* dot, long n, void* stream);
+int lidk_hidden_mix_wgrad(const float* w, const float* dots, float* dw, int n_states, void* stream);
 
 /* ------------------------------------------------------------------ key-tiled attention of the transformer backbones
  * Replaces F.multi_head_attention_forward as lid/wavlm/modules.py:505-700 calls it (WavLM: additive gated relative-position bias,

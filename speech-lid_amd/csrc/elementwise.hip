@@ -98,6 +98,27 @@ extern "C" int lidk_dropout(const void* x, int xd, void* y, int yd, const uint8_
   return LIDK_ERR_ARG;
 }
 
+// out = res + dropout(x): the transformer layers' dropout1 / dropout3 in front of the residual add (lid/wavlm/WavLM.py:745-771),
+// same decisions as dropout_kernel for the same (seed, index).
+__global__ void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ out,
+                                   const uint8_t* __restrict__ keep_in, long n, float p, float inv_keep, uint64_t seed) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const bool keep = keep_in ? (keep_in[i] != 0) : (uniform_from(seed, (uint64_t)i) >= p);
+    out[i] = res[i] + (keep ? x[i] * inv_keep : 0.0f);
+  }
+}
+extern "C" int lidk_dropout_add(const float* x, const float* res, float* out, const uint8_t* keep_in, long n, float p,
+                                uint64_t seed, void* stream) {
+  if (!x || !res || !out || n < 0 || p < 0.f || p >= 1.f) return LIDK_ERR_ARG;
+  if (n == 0) return LIDK_OK;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  dropout_add_kernel<<<blocks, 256, 0, as_stream(stream)>>>(x, res, out, keep_in, n, p, 1.0f / (1.0f - p), seed);
+  return launch_status();
+}
+
 // ------------------------------------------------------------------------------------ relu backward
 template <typename T>
 __global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long n) {

@@ -703,3 +703,76 @@ extern "C" int lidk_wavlm_posconv_dprep(const float* dy, const void* pre, void* 
                                                                     G > 0 ? G : 1, goff, rows_total);
   return launch_status();
 }
+
+// =====================================================================================================================
+// wav2vec2 pieces (lid/s3prl_updream/wav2vec/wav2vec2.py, lid/s3prl_updream/interfaces.py).
+// =====================================================================================================================
+// x[b][t][:] = 0 for t >= klen[b]: TransformerEncoder.extract_features zeroes the padded frames before the positional
+// convolution (wav2vec2.py:906-907 index_put(x, padding_mask, 0)); the same launch zeroes their gradient rows in backward.
+__global__ void zero_padded_rows_kernel(float* __restrict__ x, const int* __restrict__ klen, int T_, int C, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C;
+    const int b = (int)(row / T_), t = (int)(row % T_);
+    if (t >= klen[b]) x[i] = 0.f;
+  }
+}
+extern "C" int lidk_zero_padded_rows(float* x, const int* klen, int B, int T_, int C, void* stream) {
+  if (!x || !klen || B <= 0 || T_ <= 0 || C <= 0) return LIDK_ERR_ARG;
+  const long n = (long)B * T_ * C;
+  int blocks = (int)((n + 255) / 256); if (blocks > 8192) blocks = 8192;
+  zero_padded_rows_kernel<<<blocks, 256, 0, as_stream(stream)>>>(x, klen, T_, C, n);
+  return launch_status();
+}
+
+// s3prl Featurizer._weighted_sum (interfaces.py:227-252): feature = sum_l softmax(weights)[l] * hidden_state_l over the L + 1
+// hidden states (the input of every transformer layer and the encoder output).  One launch per state:
+//   fwd : feat = (l == 0 ? 0 : feat) + sm[l] * h_l
+//   bwd : dots[l] = <dfeat, h_l> ; dh_l += sm[l] * dfeat (axpy) ; dw[l] += sm[l] * (dots[l] - sum_k sm[k] dots[k])
+#define HM_MAX 64
+__device__ __forceinline__ float hm_softmax_at(const float* __restrict__ w, int n_states, int l) {
+  float mx = -INFINITY, sum = 0.f;
+  for (int k = 0; k < n_states; ++k) mx = fmaxf(mx, w[k]);
+  for (int k = 0; k < n_states; ++k) sum += __expf(w[k] - mx);
+  return __expf(w[l] - mx) / sum;
+}
+__global__ void hidden_mix_axpy_kernel(const float* __restrict__ h, const float* __restrict__ w, int n_states, int l,
+                                       float* __restrict__ out, long n, int overwrite) {
+  const float s = hm_softmax_at(w, n_states, l);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = (overwrite ? 0.f : out[i]) + s * h[i];
+}
+extern "C" int lidk_hidden_mix_axpy(const float* h, const float* w, int n_states, int l, float* out, long n, int overwrite,
+                                    void* stream) {
+  if (!h || !w || !out || n_states <= 0 || n_states > HM_MAX || l < 0 || l >= n_states || n <= 0) return LIDK_ERR_ARG;
+  int blocks = (int)((n + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hidden_mix_axpy_kernel<<<blocks, 256, 0, as_stream(stream)>>>(h, w, n_states, l, out, n, overwrite);
+  return launch_status();
+}
+__global__ void hidden_mix_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dot, long n) {
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) acc = fmaf(a[i], b[i], acc);
+  acc = wave_sum(acc);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dot, red[0] + red[1] + red[2] + red[3]);
+}
+extern "C" int lidk_hidden_mix_dot(const float* a, const float* b, float* dot, long n, void* stream) {
+  if (!a || !b || !dot || n <= 0) return LIDK_ERR_ARG;
+  int blocks = (int)((n + 255) / 256); if (blocks > 1024) blocks = 1024;
+  hidden_mix_dot_kernel<<<blocks, 256, 0, as_stream(stream)>>>(a, b, dot, n);
+  return launch_status();
+}
+__global__ void hidden_mix_wgrad_kernel(const float* __restrict__ w, const float* __restrict__ dots, float* __restrict__ dw,
+                                        int n_states) {
+  const int l = threadIdx.x;
+  if (l >= n_states) return;
+  float mean = 0.f;
+  for (int k = 0; k < n_states; ++k) mean = fmaf(hm_softmax_at(w, n_states, k), dots[k], mean);
+  dw[l] += hm_softmax_at(w, n_states, l) * (dots[l] - mean);
+}
+extern "C" int lidk_hidden_mix_wgrad(const float* w, const float* dots, float* dw, int n_states, void* stream) {
+  if (!w || !dots || !dw || n_states <= 0 || n_states > HM_MAX) return LIDK_ERR_ARG;
+  hidden_mix_wgrad_kernel<<<1, HM_MAX, 0, as_stream(stream)>>>(w, dots, dw, n_states);
+  return launch_status();
+}

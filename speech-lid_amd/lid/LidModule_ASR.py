@@ -1,12 +1,12 @@
 """LidModule - the reference's CCMLModule for the pretrained-backbone LID models (lid/LidModule_ASR.py:17-409): joint per-language
-CTC + ASR-confidence LID on a WavLM backbone (``use_wav2vec=False``).  Same constructor keywords (YAML ``module:`` + ``model:``
+CTC + ASR-confidence LID on a WavLM backbone (``use_wav2vec=False``) or a wav2vec2 backbone (``use_wav2vec=True``, BASELINE config 5).  Same constructor keywords (YAML ``module:`` + ``model:``
 of lid/conf/xf_asr_wavlm*.yaml), hooks, logged names and quirks; the arithmetic runs on the lidk kernels: waveform
 normalisation / dither / pre-emphasis on the GPU, the WavLM backbone forward (lidk/wavlm.py), Conformer heads forward + backward
 (lidk Engine), fused log-softmax + CTC, LID scoring, device-side greedy decode.
 
 The reference launcher imports this name unconditionally (lid/main.py:13) and builds it when the YAML says ``supervised: false``.
-Scope of this build: WavLM with a FROZEN backbone (the reference's regime until ``freeze_tranformer_epoch`` /
-``freeze_encoder_epoch`` pass); the wav2vec2 backbone (``use_wav2vec: true``, row N2) is not built and raises.
+Scope of this build: WavLM / wav2vec2 (Base architecture) with the conv feature extractor frozen (the reference's regime
+until ``freeze_encoder_epoch`` = 100 passes) and the transformer frozen or fine-tuned (``freeze_tranformer_epoch``).
 """
 import logging
 from typing import Any, Dict, List
@@ -38,9 +38,7 @@ class LidModule(CCMLModule):
                          double_swish=double_swish, mask_channel_prob=mask_channel_prob, mask_prob=mask_prob,
                          keep_train_lang=keep_train_lang, use_mask=use_mask, dim_head=dim_head, num_head=num_head,
                          dropout=dropout, use_pre_train=use_pre_train, sr=sr, wavlm_cfg=wavlm_cfg)
-        if use_wav2vec:
-            raise NotImplementedError("LidModule(use_wav2vec=True): the wav2vec2 backbone (SURVEY 8f N2; its arithmetic lives in the "
-                                      "un-vendored fairseq) has no HIP path in this build")
+        from lid.Wav2vecMutiLangModel import Wav2vecMutiLangModel
         from lid.WavLMMutiLangModel import WavLMMutiLangModel
         self.optimizer_name, self.optimizer_param = optimizer_name, dict(optimizer_param or {})
         self.scheduler, self.scheduler_param = scheduler, dict(scheduler_param or {})
@@ -51,12 +49,19 @@ class LidModule(CCMLModule):
         self.sr, self.extrme_mode, self.keep_train_lang = sr, extrme_mode, keep_train_lang
         self.index2lang_dict = {v: k for k, v in lang2index_dict.items()}
         logging.info("sample rate: %s, double swish: %s, mask channel prob %s", sr, double_swish, mask_channel_prob)
-        self.model = WavLMMutiLangModel(
-            pt_path=pt_path, feature_selection=feature_selection, dropout=dropout, linear_dim=linear_dim, mask=mask,
-            num_layers=num_layers, lang2vocab=lang2vocab, lang2index=lang2index_dict, hidden_dim=hidden_dim,
-            conformer_linear=conformer_linear, double_swish=double_swish, use_pre_train=use_pre_train,
-            mask_channel_prob=mask_channel_prob, mask_prob=mask_prob, conformer_pure=conformer_pure, use_mask=use_mask,
-            dim_head=dim_head, num_head=num_head, wavlm_cfg=wavlm_cfg, train_input_norm=train_input_norm)
+        if use_wav2vec:                    # reference :95-110 (no double_swish / use_pre_train / mask probabilities on this branch)
+            self.model = Wav2vecMutiLangModel(
+                pt_path=pt_path, feature_selection=feature_selection, dropout=dropout, linear_dim=linear_dim, mask=mask,
+                num_layers=num_layers, lang2vocab=lang2vocab, lang2index=lang2index_dict, hidden_dim=hidden_dim,
+                conformer_linear=conformer_linear, use_mask=use_mask, dim_head=dim_head, num_head=num_head,
+                wav2vec_cfg=kwargs.get("wav2vec_cfg"), train_input_norm=train_input_norm)
+        else:
+            self.model = WavLMMutiLangModel(
+                pt_path=pt_path, feature_selection=feature_selection, dropout=dropout, linear_dim=linear_dim, mask=mask,
+                num_layers=num_layers, lang2vocab=lang2vocab, lang2index=lang2index_dict, hidden_dim=hidden_dim,
+                conformer_linear=conformer_linear, double_swish=double_swish, use_pre_train=use_pre_train,
+                mask_channel_prob=mask_channel_prob, mask_prob=mask_prob, conformer_pure=conformer_pure, use_mask=use_mask,
+                dim_head=dim_head, num_head=num_head, wavlm_cfg=wavlm_cfg, train_input_norm=train_input_norm)
         self.count, self.avg_loss, self.avg_wer = 1, 0.0, 0.0
         self.predict_texts, self.label_texts, self.wer = None, None, 0.0
         self.countdown_20 = 0
@@ -67,8 +72,9 @@ class LidModule(CCMLModule):
     def config_optim(self, *args, **kwargs):
         # all parameters, like the reference (:140-150): frozen ones carry no gradient, so the optimizer skips them (and
         # allocates no state) until freeze_tranformer_epoch has passed; the never-trained conv extractor is left out
+        pre = self.model.BB_PREFIX
         never = {id(p) for n, p in self.model.named_parameters()
-                 if n.startswith(("model.featurizer.model.feature_extractor.", "model.featurizer.model.post_extract_proj."))}
+                 if n.startswith((pre + "feature_extractor.", pre + "post_extract_proj."))}
         params = [p for p in self.model.parameters() if id(p) not in never]
         name = self.optimizer_name
         if name == "sgd":

@@ -32,12 +32,15 @@ from lidk._lib import LidkError
 
 
 class WavLMMutiLangModel(_EngineBoundModel):
+    BB_PREFIX = "model.featurizer.model."         # where the backbone's parameters sit in the reference state_dict
+    MIX_NAME = None                               # wav2vec2: the s3prl Featurizer's layer-mixing logits
+
     def __init__(self, pt_path: str = None, feature_selection: str = "hidden_states", dropout: float = 0.0, linear_dim: int = 768,
                  mask: bool = True, num_layers: int = 1, lang2vocab: Dict = None, lang2index: Dict = None, hidden_dim: int = 128,
                  conformer_linear: bool = False, double_swish: bool = False, use_pre_train: bool = True,
                  mask_channel_prob: float = 0, mask_prob: float = 0.0, conformer_pure: bool = False, use_mask: bool = False,
                  dim_head: int = 32, num_head: int = 8, compute_dtype=torch.bfloat16, wavlm_cfg: Optional[Dict] = None,
-                 train_input_norm: bool = True, **_ignored):
+                 train_input_norm: bool = True, _weights: Optional[Dict] = None, **_ignored):
         super().__init__()
         if not conformer_linear:
             raise NotImplementedError("LSTM heads (conformer_linear=False) are outside the lidk path (SURVEY 2 #3)")
@@ -47,7 +50,7 @@ class WavLMMutiLangModel(_EngineBoundModel):
             ckpt = torch.load(pt_path, map_location="cpu", weights_only=False)       # {"cfg": dict, "model": state_dict}
             cfg, weights = dict(ckpt["cfg"]), (ckpt["model"] if use_pre_train else None)
         elif wavlm_cfg is not None:                                                   # tests / synthetic runs: no checkpoint file
-            cfg, weights = dict(wavlm_cfg), None
+            cfg, weights = dict(wavlm_cfg), _weights
         else:
             raise ValueError("WavLMMutiLangModel needs pt_path (a WavLM checkpoint with 'cfg' and 'model') or wavlm_cfg")
         cfg["mask_prob"] = mask_prob if mask else 0.0
@@ -63,7 +66,7 @@ class WavLMMutiLangModel(_EngineBoundModel):
         self._bb_names: List[str] = []
         sd = weights if weights is not None else self._random_backbone(cfg)
         for name, t in sd.items():
-            *path, leaf = ("model.featurizer.model." + name).split(".")
+            *path, leaf = (self.BB_PREFIX + name).split(".")
             _child(self, path).register_parameter(leaf, nn.Parameter(t.detach().clone().float(), requires_grad=False))
             self._bb_names.append(name)
         self._sync_backbone()
@@ -82,7 +85,7 @@ class WavLMMutiLangModel(_EngineBoundModel):
         # the gradient at the features (backbone forward = two captured graphs, nothing saved: the fast frozen regime).
         self.train_input_norm = bool(train_input_norm)
         for n in WavLMBackbone.INPUT_SIDE:
-            dict(self.named_parameters())["model.featurizer.model." + n].requires_grad = self.train_input_norm
+            dict(self.named_parameters())[self.BB_PREFIX + n].requires_grad = self.train_input_norm
         self.on_backbone_grads_ready = None       # data parallelism: called with the backbone's flat gradient arena
 
     @staticmethod
@@ -106,7 +109,7 @@ class WavLMMutiLangModel(_EngineBoundModel):
 
     def _backbone_params(self) -> Dict[str, torch.Tensor]:
         params = dict(self.named_parameters())
-        return {n: params["model.featurizer.model." + n].data for n in self._bb_names}
+        return {n: params[self.BB_PREFIX + n].data for n in self._bb_names}
 
     def _sync_backbone(self):
         self.backbone.load_state_dict(self._backbone_params(), share=True)      # optimizer updates reach backbone.refresh()
@@ -114,9 +117,14 @@ class WavLMMutiLangModel(_EngineBoundModel):
 
     def _moved(self, device):
         for n in self._bb_names:                                   # the frozen backbone's parameters follow the model
-            *path, leaf = ("model.featurizer.model." + n).split(".")
+            *path, leaf = (self.BB_PREFIX + n).split(".")
             mod = _child(self, path)
             mod._parameters[leaf].data = mod._parameters[leaf].data.to(device)
+        if self.MIX_NAME is not None:                              # the Featurizer's mixing logits live outside the engine arena
+            mp = dict(self.named_parameters()).get(self.MIX_NAME)
+            if mp is not None:
+                mp.data = mp.data.to(device)
+                self._mix_grad = None
         self.backbone.to(device)
         self._sync_backbone()
 
@@ -140,9 +148,11 @@ class WavLMMutiLangModel(_EngineBoundModel):
             self.backbone.refresh()
             self._bb_stale = False
         self._bb_shape = tuple(wav.shape)
+        mix_w = self._mix_w()
         with torch.no_grad():
-            feats = self.backbone.forward(wav.contiguous(), mask=self.training, n_samples=n_samples,
-                                          train=grad_path and (self.train_input_norm or not self._backbone_frozen["encoder"]))
+            feats = self.backbone.forward(wav.contiguous(), mask=self.training, n_samples=n_samples, mix_w=mix_w,
+                                          train=grad_path and (self.train_input_norm or not self._backbone_frozen["encoder"]
+                                                               or mix_w is not None))
         eng = self.lidk_engine
         if grad_path:
             if self._anchor is None or self._anchor.device != feats.device:
@@ -155,13 +165,20 @@ class WavLMMutiLangModel(_EngineBoundModel):
             return out, (None, None)
         return out, self.lang_discriminator_forward(out)
 
+    def _mix_w(self):
+        """Device tensor of the hidden-state mixing logits (``model.featurizer.weights``), or None (last hidden state)."""
+        if self.MIX_NAME is None:
+            return None
+        p = dict(self.named_parameters()).get(self.MIX_NAME)
+        return None if p is None else p.data
+
     # ------------------------------------------------------------------ reference helper surface
     def freeze_feature_extractor(self):
         self._backbone_frozen["extractor"] = True
 
     def _encoder_parameters(self):
         params = dict(self.named_parameters())
-        return {n: params["model.featurizer.model." + n] for n in self._bb_names if n.startswith(WavLMBackbone.TRAINABLE_PREFIX)}
+        return {n: params[self.BB_PREFIX + n] for n in self._bb_names if n.startswith(WavLMBackbone.TRAINABLE_PREFIX)}
 
     def freeze_tranformer_encoder(self):                                      # noqa: F811 (reference spelling)
         self._backbone_frozen["encoder"] = True
@@ -175,11 +192,6 @@ class WavLMMutiLangModel(_EngineBoundModel):
 
     def unfreeze_tranformer_encoder(self):
         """lid/WavLMMutiLangModel.py:106-112: the transformer encoder's parameters take gradients from now on."""
-        if any(float(self.backbone.cfg.get(k, 0.0)) > 0 for k in ("dropout", "attention_dropout", "activation_dropout")) \
-                and not getattr(self, "_warned_dropout", False):
-            logging.warning("WavLM encoder dropout / attention_dropout / activation_dropout are not applied by the lidk backbone "
-                            "(LayerDrop and span masking are); set them to 0 in the checkpoint cfg to silence this")
-            self._warned_dropout = True
         self._backbone_frozen["encoder"] = False
         for p in self._encoder_parameters().values():
             p.requires_grad = True
@@ -187,12 +199,13 @@ class WavLMMutiLangModel(_EngineBoundModel):
     def _backbone_backward(self, dfeat: torch.Tensor):
         """Called by the autograd node after the heads' backward: encoder gradients from d(loss)/d(features)."""
         frozen = self._backbone_frozen["encoder"]
-        if frozen and not self.train_input_norm:
+        mix_w = self._mix_w()
+        if frozen and not self.train_input_norm and mix_w is None:
             return
         bb = self.backbone
         params = dict(self.named_parameters())
-        live = {n: params["model.featurizer.model." + n] for n in self._bb_names
-                if params["model.featurizer.model." + n].requires_grad}
+        live = {n: params[self.BB_PREFIX + n] for n in self._bb_names
+                if params[self.BB_PREFIX + n].requires_grad}
         bb._alloc_grads()
         masked = bb.cfg.get("mask_prob", 0.0) > 0
         # zero_grad(set_to_none) since the last backward = a new optimizer step: start the arena from zero.  mask_emb never gets
@@ -200,7 +213,18 @@ class WavLMMutiLangModel(_EngineBoundModel):
         # accumulate_grad > 1 step would wipe the arena and only the last one's gradients would survive.
         if any(p.grad is None for n, p in live.items() if masked or n != "mask_emb"):
             bb.zero_grads()
-        bb.backward(dfeat, *self._bb_shape, wgrads=not frozen)
+        mix_dw = None
+        if mix_w is not None:
+            mp = params[self.MIX_NAME]
+            if getattr(self, "_mix_grad", None) is None or self._mix_grad.device != mix_w.device:
+                self._mix_grad = torch.zeros_like(mix_w)
+            if mp.grad is None:
+                self._mix_grad.zero_()
+            mix_dw = self._mix_grad if mp.requires_grad else None
+        bb.backward(dfeat, *self._bb_shape, wgrads=not frozen, mix_w=mix_w, mix_dw=mix_dw,
+                    data_grads=not (frozen and not self.train_input_norm))
+        if mix_dw is not None:
+            params[self.MIX_NAME].grad = self._mix_grad
         for n, p in live.items():
             if n == "mask_emb" and not masked:                     # no span was replaced: the reference leaves .grad None
                 continue

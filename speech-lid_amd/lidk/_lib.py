@@ -44,6 +44,7 @@ SIGNATURES = {
     "lidk_scale_cast": (_I, [_P, _I, _P, _I, _L, _F, _P]),
     "lidk_scale_cast_2d": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _F, _P]),
     "lidk_dropout": (_I, [_P, _I, _P, _I, _P, _P, _L, _F, _U64, _P]),
+    "lidk_dropout_add": (_I, [_P, _P, _P, _P, _L, _F, _U64, _P]),
     "lidk_relu_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
     "lidk_colsum": (_I, [_P, _I, _I, _P, _P, _I, _I, _F, _P]),
     "lidk_transpose": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
@@ -100,6 +101,10 @@ SIGNATURES = {
     "lidk_wavlm_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lidk_wavlm_attn_fwd_probs": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lidk_wavlm_attn_bias_grads": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lidk_zero_padded_rows": (_I, [_P, _P, _I, _I, _I, _P]),
+    "lidk_hidden_mix_axpy": (_I, [_P, _P, _I, _I, _P, _L, _I, _P]),
+    "lidk_hidden_mix_dot": (_I, [_P, _P, _P, _L, _P]),
+    "lidk_hidden_mix_wgrad": (_I, [_P, _P, _P, _I, _P]),
     "lidk_xattn_max_frames": (_I, [_I]),
     "lidk_xattn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _U64, _I, _I, _I, _I, _I, _P]),
     "lidk_xattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -193,6 +193,12 @@ def dropout(x, out, p, seed=0, keep_in=None, keep_out=None):
     return out
 
 
+def dropout_add(x, res, out, p, seed=0, keep_in=None):
+    """out = res + dropout(x) (f32), decisions as ``dropout`` for the same seed / forced mask."""
+    check(lib().lidk_dropout_add(_p(x), _p(res), _p(out), _p(keep_in), x.numel(), float(p), int(seed), _stream()), "dropout_add")
+    return out
+
+
 def relu_bwd(dy, y, dx):
     check(lib().lidk_relu_bwd(_p(dy), _p(y), _p(dx), dy.numel(), _code(dy), _stream()), "relu_bwd")
     return dx
@@ -575,6 +581,26 @@ def wavlm_attn_bwd(qkv, probs, dout, gate, rb, dqkv, dgate, drb, dscores, B, T, 
     RB = (rb.shape[1] + 1) // 2
     check(lib().lidk_wavlm_attn_bwd(_p(qkv), _p(probs), _p(dout), _p(gate), _p(rb), _p(dqkv), _p(dgate), _p(drb), _p(dscores),
                                     B, T, H, dh, RB, _stream()), "wavlm_attn_bwd")
+
+
+def zero_padded_rows(x, klen, B, T):
+    """x (B*T, C) f32 in place: rows t >= klen[b] become zero (wav2vec2 zeroes padded frames in front of the positional conv)."""
+    check(lib().lidk_zero_padded_rows(_p(x), _p(klen), B, T, x.shape[-1], _stream()), "zero_padded_rows")
+    return x
+
+
+def hidden_mix_axpy(h, w, l, out, overwrite=False):
+    """out = (0 if overwrite else out) + softmax(w)[l] * h  (s3prl Featurizer weighted sum, one hidden state per launch)."""
+    check(lib().lidk_hidden_mix_axpy(_p(h), _p(w), w.numel(), l, _p(out), h.numel(), int(overwrite), _stream()), "hidden_mix_axpy")
+    return out
+
+
+def hidden_mix_dot(a, b, dot):
+    check(lib().lidk_hidden_mix_dot(_p(a), _p(b), _p(dot), a.numel(), _stream()), "hidden_mix_dot")
+
+
+def hidden_mix_wgrad(w, dots, dw):
+    check(lib().lidk_hidden_mix_wgrad(_p(w), _p(dots), _p(dw), w.numel(), _stream()), "hidden_mix_wgrad")
 
 
 def xattn_max_frames(dh):

@@ -17,7 +17,7 @@ MI355X-first design of the pieces:
   * the grouped positional convolution (k128, 16 groups) runs as 16 GEMMs with lda = 48 over a group-major zero-padded copy;
   * q/k/v projections are one fused [3d, d] GEMM; the bucketed relative position bias is a per-head 1-D table over the offset
     j - i (built once from the layer-0 embedding), gated per (batch, head, query) by a GRU-style gate of the layer input and
-    added inside the MFMA attention kernel (lidk_wavlm_attn_fwd).
+    added inside the key-tiled attention kernel (lidk_xattn_fwd: any T, nothing T x T in HBM).
 """
 import math
 from typing import Dict, List
@@ -101,18 +101,30 @@ def _copy_tree(dst, src):
 
 
 class WavLMBackbone:
-    RB = 1024                       # the bias table covers offsets |j - i| < RB
+    RB = 2048                       # the bias table covers offsets |j - i| < RB (buckets saturate at max_distance = 800)
+
+    # WavLMConfig's own defaults for the keys a checkpoint cfg may leave out (lid/wavlm/WavLM.py:181-196)
+    CFG_DEFAULTS = dict(dropout=0.1, attention_dropout=0.1, activation_dropout=0.0, encoder_layerdrop=0.0, dropout_input=0.0,
+                        dropout_features=0.0)
 
     def __init__(self, cfg: Dict):
-        self.cfg = dict(cfg)
+        self.cfg = {**self.CFG_DEFAULTS, **dict(cfg)}
         self.layers_spec = eval(cfg.get("conv_feature_layers", "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"))
         self.C = self.layers_spec[0][0]
         if any(c != self.C for c, _, _ in self.layers_spec) or self.layers_spec[0][1:] != (10, 5):
             raise NotImplementedError("lidk WavLM: conv feature extractor of the (C,10,5) + (C,k,s)* form with one width")
         if cfg.get("extractor_mode", "default") != "default" or cfg.get("conv_bias", False) or cfg.get("layer_norm_first", False):
             raise NotImplementedError("lidk WavLM: extractor_mode=default, conv_bias=False, layer_norm_first=False (WavLM-Base/Base+)")
-        if not (cfg.get("relative_position_embedding", False) and cfg.get("gru_rel_pos", False)):
-            raise NotImplementedError("lidk WavLM: relative_position_embedding + gru_rel_pos (every released WavLM checkpoint)")
+        # WavLM: bucketed relative-position bias with GRU gating (every released WavLM checkpoint).  wav2vec2 (SURVEY 8f N2:
+        # lid/s3prl_updream/wav2vec/wav2vec2.py): neither, but the encoder receives the key padding mask
+        # (``encoder_padding_mask``; the reference's WavLM call leaves it out, WavLM.py:390-394).
+        if bool(cfg.get("relative_position_embedding", False)) != bool(cfg.get("gru_rel_pos", False)):
+            raise NotImplementedError("lidk backbone: relative_position_embedding and gru_rel_pos come together (WavLM) or not at all "
+                                      "(wav2vec2)")
+        self.rel_pos = bool(cfg.get("relative_position_embedding", False))
+        self.pad_mask = bool(cfg.get("encoder_padding_mask", False))
+        self.seed, self.step = 0, 0               # dropout decisions are functions of (seed, step, site, element index)
+        self.forced_keep: Dict = {}               # tests: site -> uint8 keep mask (reference-captured dropout masks)
         self.d = cfg.get("encoder_embed_dim", 768)
         self.ffn = cfg.get("encoder_ffn_embed_dim", 3072)
         self.H = cfg.get("encoder_attention_heads", 12)
@@ -146,12 +158,14 @@ class WavLMBackbone:
                   "encoder.pos_conv.0.weight_g": (1, 1, kpos), "encoder.pos_conv.0.weight_v": (d, d // gpos, kpos)})
         for i in range(cfg.get("encoder_layers", 12)):
             p = f"encoder.layers.{i}."
-            s[p + "self_attn.grep_a"] = (1, H, 1, 1)
-            if i == 0:
-                s[p + "self_attn.relative_attention_bias.weight"] = (cfg.get("num_buckets", 320), H)
+            if cfg.get("relative_position_embedding", False):
+                s[p + "self_attn.grep_a"] = (1, H, 1, 1)
+                if i == 0:
+                    s[p + "self_attn.relative_attention_bias.weight"] = (cfg.get("num_buckets", 320), H)
             for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
                 s[p + f"self_attn.{n}.weight"], s[p + f"self_attn.{n}.bias"] = (d, d), (d,)
-            s[p + "self_attn.grep_linear.weight"], s[p + "self_attn.grep_linear.bias"] = (8, d // H), (8,)
+            if cfg.get("relative_position_embedding", False):
+                s[p + "self_attn.grep_linear.weight"], s[p + "self_attn.grep_linear.bias"] = (8, d // H), (8,)
             s[p + "self_attn_layer_norm.weight"], s[p + "self_attn_layer_norm.bias"] = (d,), (d,)
             s[p + "fc1.weight"], s[p + "fc1.bias"], s[p + "fc2.weight"], s[p + "fc2.bias"] = (ffn, d), (ffn,), (d, ffn), (d,)
             s[p + "final_layer_norm.weight"], s[p + "final_layer_norm.bias"] = (d,), (d,)
@@ -193,13 +207,12 @@ class WavLMBackbone:
         W["pos_w"] = [w[i * cg:(i + 1) * cg].permute(0, 2, 1).reshape(cg, -1).to(bf).contiguous() for i in range(self.gpos)]
         W["pos_b"] = g("encoder.pos_conv.0.bias")
         W["enc_ln_w"], W["enc_ln_b"] = g("encoder.layer_norm.weight"), g("encoder.layer_norm.bias")
-        emb = g("encoder.layers.0.self_attn.relative_attention_bias.weight")      # [buckets][H], shared by every layer
-        r = torch.arange(-(self.RB - 1), self.RB, device=dev)
-        bucket = relative_buckets(r, self.cfg.get("num_buckets", 320), self.cfg.get("max_distance", 800))
-        W["rb"] = emb[bucket].t().contiguous()                                   # [H][2*RB-1], entry r + RB - 1
-        W["rb_bucket"] = bucket
-        W["zero_emb"] = torch.zeros(2 * 256 + 1, self.dh, device=dev)          # operands of the MFMA attention backward
-        W["zero_embT"] = torch.zeros(2 * 256 + 1, self.dh, device=dev, dtype=bf)
+        if self.rel_pos:
+            emb = g("encoder.layers.0.self_attn.relative_attention_bias.weight")      # [buckets][H], shared by every layer
+            r = torch.arange(-(self.RB - 1), self.RB, device=dev)
+            bucket = relative_buckets(r, self.cfg.get("num_buckets", 320), self.cfg.get("max_distance", 800))
+            W["rb"] = emb[bucket].t().contiguous()                                   # [H][2*RB-1], entry r + RB - 1
+            W["rb_bucket"] = bucket
         W["mask_emb"] = g("mask_emb")
         W["proj_wT"] = W["proj_w"].t().contiguous()                              # data gradient of post_extract_proj
         # pos-conv data gradient = the same strided-view GEMM with the kernel flipped: [c][j'*cg + o] = w[o][c][k-1-j']
@@ -212,7 +225,8 @@ class WavLMBackbone:
                 wqkv=torch.cat([g(a + "q_proj.weight"), g(a + "k_proj.weight"), g(a + "v_proj.weight")]).to(bf).contiguous(),
                 bqkv=torch.cat([g(a + "q_proj.bias"), g(a + "k_proj.bias"), g(a + "v_proj.bias")]).contiguous(),
                 wo=g(a + "out_proj.weight").to(bf), bo=g(a + "out_proj.bias"),
-                wg=g(a + "grep_linear.weight"), bg=g(a + "grep_linear.bias"), grep_a=g(a + "grep_a").reshape(-1).contiguous(),
+                **(dict(wg=g(a + "grep_linear.weight"), bg=g(a + "grep_linear.bias"),
+                        grep_a=g(a + "grep_a").reshape(-1).contiguous()) if self.rel_pos else {}),
                 ln1_w=g(q + "self_attn_layer_norm.weight"), ln1_b=g(q + "self_attn_layer_norm.bias"),
                 w1=g(q + "fc1.weight").to(bf), b1=g(q + "fc1.bias"), w2=g(q + "fc2.weight").to(bf), b2=g(q + "fc2.bias"),
                 ln2_w=g(q + "final_layer_norm.weight"), ln2_b=g(q + "final_layer_norm.bias")))
@@ -243,9 +257,10 @@ class WavLMBackbone:
         T = self.frame_counts(Lw)
         if T[-1] < 1:
             raise LidkError(f"WavLM: {Lw} samples are too few for the feature extractor")
-        if T[-1] > ops.wavlm_attn_max_frames(self.dh):
+        lim = min(ops.xattn_max_frames(self.dh), self.RB - 1)
+        if T[-1] > lim:
             raise LidkError(f"WavLM: {T[-1]} frames ({Lw / 16000:.1f} s) exceed the attention kernel's limit of "
-                            f"{ops.wavlm_attn_max_frames(self.dh)} frames (dh = {self.dh})")
+                            f"{lim} frames (dh = {self.dh}): lower data.max_duration")
         n = len(T)
         # row pitches with P_l = stride_{l+1} * P_{l+1}, large enough for every layer's valid rows
         mult = [1] * n
@@ -266,7 +281,9 @@ class WavLMBackbone:
                   xg=torch.empty(self.gpos, B * Pp + self.kpos, d // self.gpos, device=dev, dtype=bf),
                   pc=torch.empty(B * Pp, d, device=dev), qkv=torch.empty(M, 3 * d, device=dev, dtype=bf),
                   o=torch.empty(M, d, device=dev, dtype=bf), hm=torch.empty(M, self.ffn, device=dev, dtype=bf),
-                  gate=torch.empty(B, self.H, Tn, device=dev))
+                  gate=torch.empty(B, self.H, Tn, device=dev), lse=torch.empty(B, self.H, Tn, device=dev),
+                  klen=torch.full((B,), Tn, device=dev, dtype=torch.int32), feat=torch.empty(M, d, device=dev),
+                  tmp=torch.empty(M, d, device=dev))
         if len(self._ws) > 8:
             self._ws.clear()
             self.graphs.clear()
@@ -280,26 +297,40 @@ class WavLMBackbone:
         dev, bf, d, M, Tn, H = self.device, torch.bfloat16, self.d, ws["M"], ws["Tn"], self.H
         e = lambda *sh: torch.empty(*sh, device=dev, dtype=bf)
         f = lambda *sh: torch.empty(*sh, device=dev)
-        ldp = ops.wavlm_attn_ldp(Tn)
         layers = []
         for _ in range(self.n_layers):
-            layers.append(dict(xin=f(M, d), xinb=e(M, d), qkv=e(M, 3 * d), gate=f(B, H, Tn), probs=e(B, H, Tn, ldp), o=e(M, d),
+            layers.append(dict(xin=f(M, d), xinb=e(M, d), qkv=e(M, 3 * d), gate=f(B, H, Tn), lse=f(B, H, Tn), o=e(M, d),
                                y1=f(M, d), mean1=f(M), rstd1=f(M), x1=f(M, d), x1b=e(M, d), pre=e(M, self.ffn), hm=e(M, self.ffn),
                                y2=f(M, d), mean2=f(M), rstd2=f(M)))
         Pp = ws["Pp"]
         sv = dict(layers=layers, y0=f(M, d), mean0=f(M), rstd0=f(M), pcp=e(B * Pp, d),
                   dxa=f(M, d), dxb=f(M, d), da=f(M, d), dab=e(M, d), dpre=e(M, self.ffn), dx1=f(M, d), db=f(M, d), dbb=e(M, d),
-                  do=e(M, d), dqkv=e(M, 3 * d), dgate=f(B, H, Tn), dsc=f(B, H, Tn, ldp), partial=f(L.LN_BWD_BLOCKS * 2 * d),
+                  do=e(M, d), dqkv=e(M, 3 * d), dgate=f(B, H, Tn), delta=f(B, H, Tn), partial=f(L.LN_BWD_BLOCKS * 2 * d),
                   dpc=torch.zeros(B * Pp + self.kpos, d, device=dev, dtype=bf), dy0=f(M, d),
                   dpg=torch.zeros(self.gpos, B * Pp + self.kpos, d // self.gpos, device=dev, dtype=bf), dxp=f(B * Pp, d),
-                  dxc=f(M, self.C))
+                  dxc=f(M, self.C), dots=f(self.n_layers + 1), dm=e(M, d))
         ws["save"] = sv
         return sv
+
+    def _key_lengths(self, ws, B, Tn, Lw, n_samples):
+        """wav2vec2 (encoder_padding_mask): frames of utterance b beyond the conv stack's output length of its TRUE sample count are
+        padding (Wav2Vec2Model._get_feat_extract_output_lengths, wav2vec2.py:521-539,564-583) -> ws["klen"] on the device and the
+        host list; None when nothing is padded (the reference then passes no mask at all)."""
+        if not self.pad_mask or n_samples is None or all(int(n) >= Lw for n in n_samples):
+            ws["klen_host"] = None
+            return None
+        lens = [min(max(self.frame_counts(int(n))[-1], 1), Tn) for n in n_samples]
+        ws["klen_host"] = lens
+        return self._upload_mask(ws, "klen", np.asarray(lens, dtype=np.int32))
 
     def _apply_mask(self, ws, B, Tn, Lw, n_samples):
         cfg, dev = self.cfg, self.device
         pad = None
-        if n_samples is not None:       # the model surface ALWAYS hands WavLM a padding mask (lid/WavLMMutiLangModel.py:271-274),
+        if self.pad_mask:                 # wav2vec2: the frame mask of the conv-length formula, None without padding
+            lens = ws.get("klen_host")
+            if lens is not None:
+                pad = np.arange(Tn)[None, :] >= np.asarray(lens)[:, None]
+        elif n_samples is not None:     # the model surface ALWAYS hands WavLM a padding mask (lid/WavLMMutiLangModel.py:271-274),
             # even when nothing is padded - which changes compute_mask_indices' draw order (one rounding draw per row).
             # WavLM.forward_padding_mask: a frame is padding if all of its Lw // T samples are (remainder samples dropped), i.e.
             # frame t of an utterance of n samples is padding iff t * per >= n.  (Closed form: no (B, Lw) host tensor per step.)
@@ -321,13 +352,13 @@ class WavLMBackbone:
         """Host-drawn spans -> the device mask through one of two PINNED staging buffers (a copy from pageable memory would
         block the host until the stream drains); a buffer is reused two steps later, after its copy's event has passed."""
         dst = ws[name]
-        st = ws.setdefault(name + "_stage", dict(bufs=[torch.empty(dst.shape, dtype=torch.uint8).pin_memory() for _ in range(2)],
+        st = ws.setdefault(name + "_stage", dict(bufs=[torch.empty(dst.shape, dtype=dst.dtype).pin_memory() for _ in range(2)],
                                                  events=[None, None], turn=0))
         i = st["turn"]
         st["turn"] = 1 - i
         if st["events"][i] is not None:
             st["events"][i].synchronize()
-        st["bufs"][i].numpy()[...] = m.view("uint8")
+        st["bufs"][i].numpy()[...] = m.view("uint8") if dst.dtype == torch.uint8 else m
         dst.copy_(st["bufs"][i], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -353,13 +384,24 @@ class WavLMBackbone:
         if taps is not None:
             taps["proj"] = ws["x"].view(B, Tn, d).clone()
 
-    def _fwd_post(self, ws, B, taps, save=None):
-        """Positional convolution + LayerNorm, transformer layers -> ws["x"].  ``save``: the training buffers (activations kept
-        for ``backward``); None on the inference / frozen path."""
+    def _attn_bias(self, gate, active=None):
+        """(gate, rb) of the gated relative-position bias, or (None, None): wav2vec2 has none, and in WavLM only layer 0 owns
+        the bucket embedding (modules.py:500), so when LayerDrop skips layer 0 the layers that do run get ``position_bias``
+        None - no bias and no gate for that step (WavLM.py:620-631, modules.py:516-531)."""
+        if not self.rel_pos or (active is not None and 0 not in active):
+            return None, None
+        return gate, self.W["rb"]
+
+    def _fwd_post(self, ws, B, taps, save=None, klen=None, mix_w=None):
+        """Positional convolution + LayerNorm, transformer layers -> ws["x"] (and, with ``mix_w``, the softmax-weighted sum of
+        the hidden states -> ws["feat"]).  ``save``: the training buffers (activations kept for ``backward``); None on the
+        inference / frozen path.  klen: device int32 (B,) key lengths (wav2vec2 padding mask) or None."""
         if save is not None:
-            return self._fwd_post_train(ws, B, save)
+            return self._fwd_post_train(ws, B, save, klen, mix_w)
         W, k = self.W, ops
         Tn, M, Pp, d = ws["Tn"], ws["M"], ws["Pp"], self.d
+        if klen is not None:
+            k.zero_padded_rows(ws["x"], klen, B, Tn)
         # positional convolution + residual + LayerNorm
         cg = d // self.gpos
         k.wavlm_posconv_prep(ws["x"], ws["xg"], B, Tn, self.gpos, Pp, self.kpos // 2)
@@ -371,12 +413,18 @@ class WavLMBackbone:
         k.layernorm_fwd(ws["y"], W["enc_ln_w"], W["enc_ln_b"], yT=ws["xb"], y32=ws["x"])
         if taps is not None:
             taps["enc_in"] = ws["x"].view(B, Tn, d).clone()
+        nL = len(W["layers"])
         for i, Lw_ in enumerate(W["layers"]):
+            if mix_w is not None:
+                k.hidden_mix_axpy(ws["x"], mix_w, i, ws["feat"], overwrite=(i == 0))
             k.gemm_nt(ws["xb"], Lw_["wqkv"], ws["qkv"], bias=Lw_["bqkv"])
-            k.wavlm_gate(ws["x"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], ws["gate"], B, Tn, self.H, self.dh)
-            if taps is not None and i == 0:
-                taps["gate0"] = ws["gate"].clone()
-            k.wavlm_attn_fwd(ws["qkv"], ws["gate"], W["rb"], ws["o"], B, Tn, self.H, self.dh)
+            gate = None
+            if self.rel_pos:
+                gate = k.wavlm_gate(ws["x"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], ws["gate"], B, Tn, self.H, self.dh)
+                if taps is not None and i == 0:
+                    taps["gate0"] = ws["gate"].clone()
+            gate, rb = self._attn_bias(gate)
+            k.xattn_fwd(ws["qkv"], ws["o"], ws["lse"], B, Tn, self.H, self.dh, gate=gate, rb=rb, klen=klen)
             k.gemm_nt(ws["o"], Lw_["wo"], ws["y"], bias=Lw_["bo"], res=ws["x"])
             k.layernorm_fwd(ws["y"], Lw_["ln1_w"], Lw_["ln1_b"], yT=ws["x1b"], y32=ws["x1"])
             k.gemm_nt(ws["x1b"], Lw_["w1"], ws["hm"], bias=Lw_["b1"], act=L.ACT_GELU)
@@ -384,12 +432,29 @@ class WavLMBackbone:
             k.layernorm_fwd(ws["y"], Lw_["ln2_w"], Lw_["ln2_b"], yT=ws["xb"], y32=ws["x"])
             if taps is not None:
                 taps[f"layer{i}"] = ws["x"].view(B, Tn, d).clone()
-
+        if mix_w is not None:
+            k.hidden_mix_axpy(ws["x"], mix_w, nL, ws["feat"], overwrite=(nL == 0))
 
     # ------------------------------------------------------------------ training: forward with saved activations, backward
-    def _fwd_post_train(self, ws, B, sv):
-        W, k = self.W, ops
+    # dropout sites of one step: seed = base + 16 * (layer + 1) + site  (site 0 = encoder input / input features)
+    _D1, _ATT, _D2, _D3 = 1, 2, 3, 4
+
+    def _site(self, sv, layer, site):
+        return sv["drop"]["base"] + 16 * (layer + 1) + site
+
+    def _fwd_post_train(self, ws, B, sv, klen=None, mix_w=None):
+        """Training-mode forward of the encoder (the reference runs the backbone in train() mode in every regime, so the
+        dropouts of lid/wavlm/WavLM.py:615 (encoder input), :745-771 (dropout1 / dropout2 / dropout3 of every layer) and the
+        attention dropout inside multi_head_attention_forward apply even while the encoder's parameters are frozen).  Masks
+        are functions of (seed, step, site, element index): the backward regenerates them, nothing is stored."""
+        W, k, cfg = self.W, ops, self.cfg
         Tn, M, Pp, d = ws["Tn"], ws["M"], ws["Pp"], self.d
+        p_drop, p_att, p_act = (float(cfg.get(n, 0.0)) for n in ("dropout", "attention_dropout", "activation_dropout"))
+        sv["drop"] = dict(p=p_drop, att=p_att, act=p_act, base=(((self.seed * 1000003 + self.step) & 0x7FFFFFFF) << 12))
+        fk = self.forced_keep
+        sv["klen"], sv["mix"] = klen, mix_w is not None
+        if klen is not None:
+            k.zero_padded_rows(ws["x"], klen, B, Tn)
         cg = d // self.gpos
         k.wavlm_posconv_prep(ws["x"], ws["xg"], B, Tn, self.gpos, Pp, self.kpos // 2)
         for g in range(self.gpos):
@@ -402,21 +467,45 @@ class WavLMBackbone:
         drop = float(self.cfg.get("encoder_layerdrop", 0.0))
         active = [i for i in range(self.n_layers) if np.random.random() > drop or drop <= 0.0]
         sv["active"] = active
+        if mix_w is not None and len(active) != self.n_layers:
+            raise LidkError("hidden_states weighted sum with LayerDrop: the number of hidden states changes from step to step "
+                            "(the reference's Featurizer asserts on this too, interfaces.py:228): set encoder_layerdrop to 0")
         first = sv["layers"][active[0]] if active else None
         o32, ob = (first["xin"], first["xinb"]) if first is not None else (ws["x"], ws["xb"])
         k.layernorm_fwd(sv["y0"], W["enc_ln_w"], W["enc_ln_b"], yT=ob, y32=o32, mean=sv["mean0"], rstd=sv["rstd0"])
+        if p_drop > 0:                                                    # F.dropout(x, p=self.dropout) in front of the layers
+            k.dropout(o32, o32, p_drop, seed=self._site(sv, -1, 0), keep_in=fk.get("enc"))
+            k.scale_cast(o32, ob, 1.0)
         for n, i in enumerate(active):
             Lw_, S = W["layers"][i], sv["layers"][i]
             nxt = sv["layers"][active[n + 1]] if n + 1 < len(active) else None
             xo32, xob = (nxt["xin"], nxt["xinb"]) if nxt is not None else (ws["x"], ws["xb"])
             k.gemm_nt(S["xinb"], Lw_["wqkv"], S["qkv"], bias=Lw_["bqkv"])
-            k.wavlm_gate(S["xin"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], S["gate"], B, Tn, self.H, self.dh)
-            k.wavlm_attn_fwd(S["qkv"], S["gate"], W["rb"], S["o"], B, Tn, self.H, self.dh, probs=S["probs"])
-            k.gemm_nt(S["o"], Lw_["wo"], S["y1"], bias=Lw_["bo"], res=S["xin"])
+            gate = None
+            if self.rel_pos and 0 in active:
+                gate = k.wavlm_gate(S["xin"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], S["gate"], B, Tn, self.H, self.dh)
+            gate, rb = self._attn_bias(gate, active)
+            k.xattn_fwd(S["qkv"], S["o"], S["lse"], B, Tn, self.H, self.dh, gate=gate, rb=rb, klen=klen, drop_p=p_att,
+                        seed=self._site(sv, i, self._ATT), keep=fk.get(("att", i)))
+            if p_drop > 0:
+                k.gemm_nt(S["o"], Lw_["wo"], ws["tmp"], bias=Lw_["bo"])
+                k.dropout_add(ws["tmp"], S["xin"], S["y1"], p_drop, seed=self._site(sv, i, self._D1), keep_in=fk.get(("d1", i)))
+            else:
+                k.gemm_nt(S["o"], Lw_["wo"], S["y1"], bias=Lw_["bo"], res=S["xin"])
             k.layernorm_fwd(S["y1"], Lw_["ln1_w"], Lw_["ln1_b"], yT=S["x1b"], y32=S["x1"], mean=S["mean1"], rstd=S["rstd1"])
             k.gemm_nt(S["x1b"], Lw_["w1"], S["hm"], bias=Lw_["b1"], act=L.ACT_GELU, out2=S["pre"])
-            k.gemm_nt(S["hm"], Lw_["w2"], S["y2"], bias=Lw_["b2"], res=S["x1"])
+            if p_act > 0:
+                k.dropout(S["hm"], S["hm"], p_act, seed=self._site(sv, i, self._D2), keep_in=fk.get(("d2", i)))
+            if p_drop > 0:
+                k.gemm_nt(S["hm"], Lw_["w2"], ws["tmp"], bias=Lw_["b2"])
+                k.dropout_add(ws["tmp"], S["x1"], S["y2"], p_drop, seed=self._site(sv, i, self._D3), keep_in=fk.get(("d3", i)))
+            else:
+                k.gemm_nt(S["hm"], Lw_["w2"], S["y2"], bias=Lw_["b2"], res=S["x1"])
             k.layernorm_fwd(S["y2"], Lw_["ln2_w"], Lw_["ln2_b"], yT=xob, y32=xo32, mean=S["mean2"], rstd=S["rstd2"])
+        if mix_w is not None:
+            for n, i in enumerate(active):
+                k.hidden_mix_axpy(sv["layers"][i]["xin"], mix_w, n, ws["feat"], overwrite=(n == 0))
+            k.hidden_mix_axpy(ws["x"], mix_w, len(active), ws["feat"], overwrite=(len(active) == 0))
 
     TRAINABLE_PREFIX = "encoder."
     INPUT_SIDE = ("layer_norm.weight", "layer_norm.bias", "mask_emb")      # never frozen by the reference's freeze_* helpers
@@ -473,56 +562,90 @@ class WavLMBackbone:
     def _wgrad(self, dy, x, gw, gb=None):
         ops.gemm_tn(dy, x, gw, colsum=gb, splitk=self._splitk(gw.shape[0], gw.shape[1]))
 
-    def backward(self, dfeat: torch.Tensor, B: int, Lw: int, wgrads: bool = True):
+    def backward(self, dfeat: torch.Tensor, B: int, Lw: int, wgrads: bool = True, mix_w=None, mix_dw=None,
+                 data_grads: bool = True):
         """Backward of the last ``forward(..., train=True)`` of this (B, L) shape from dfeat = d(loss)/d(features) (B, T, d) f32.
         Accumulates into ``self.grads`` (reference names): always the parameters upstream of the transformer that the reference
         never freezes (``layer_norm.*`` in front of post_extract_proj and, under span masking, ``mask_emb``); with ``wgrads``
-        (un-frozen encoder) also every ``encoder.*`` parameter.  With wgrads False the chain carries data gradients only."""
+        (un-frozen encoder) also every ``encoder.*`` parameter.  With wgrads False the chain carries data gradients only.
+        mix_w / mix_dw: the hidden-state mixing logits of the forward and where their gradient is accumulated; with
+        data_grads False (nothing upstream of the features trains) only that gradient is produced."""
         ws = self._ws[(B, Lw)]
         sv, W, k = ws["save"], self.W, ops
         Tn, M, Pp, d, H = ws["Tn"], ws["M"], ws["Pp"], self.d, self.H
         self._alloc_grads()
         g, bf = self.grads, torch.bfloat16
         G = (lambda n: g[n]) if wgrads else (lambda n: None)
-        self._drb.zero_()
+        dr, fk, klen, active = sv["drop"], self.forced_keep, sv["klen"], sv["active"]
+        p_drop, p_att, p_act = dr["p"], dr["att"], dr["act"]
+        if self.rel_pos:
+            self._drb.zero_()
         dx = sv["dxa"]
-        k.scale_cast(dfeat.reshape(M, d).contiguous(), dx, 1.0)
-        for i in reversed(sv["active"]):
+        dfe = dfeat.reshape(M, d).contiguous()
+        if not data_grads:
+            if sv["mix"] and mix_dw is not None:
+                sv["dots"].zero_()
+                for n, i in enumerate(active):
+                    k.hidden_mix_dot(dfe, sv["layers"][i]["xin"], sv["dots"][n:n + 1])
+                k.hidden_mix_dot(dfe, ws["x"], sv["dots"][len(active):len(active) + 1])
+                k.hidden_mix_wgrad(mix_w, sv["dots"], mix_dw)
+            return
+        if sv["mix"]:
+            if mix_w is None:
+                raise LidkError("backward: the forward mixed hidden states; pass the same mix_w")
+            sv["dots"].zero_()
+            nL = len(active)
+            k.hidden_mix_dot(dfe, ws["x"], sv["dots"][nL:nL + 1])
+            k.hidden_mix_axpy(dfe, mix_w, nL, dx, overwrite=True)
+        else:
+            k.scale_cast(dfe, dx, 1.0)
+        for n, i in reversed(list(enumerate(active))):
             S, Lw_ = sv["layers"][i], W["layers"][i]
             q = f"encoder.layers.{i}."
             a = q + "self_attn."
             other = sv["dxb"] if dx is sv["dxa"] else sv["dxa"]
             k.layernorm_bwd(dx, S["y2"], S["mean2"], S["rstd2"], Lw_["ln2_w"], sv["partial"], dx=sv["da"], dxT=sv["dab"],
                             dgamma=G(q + "final_layer_norm.weight"), dbeta=G(q + "final_layer_norm.bias"), dtype=bf)
+            dy2 = sv["dab"]
+            if p_drop > 0:                                                 # dropout3: only the fc2 branch is masked
+                dy2 = k.dropout(sv["dab"], sv["dm"], p_drop, seed=self._site(sv, i, self._D3), keep_in=fk.get(("d3", i)))
             if wgrads:
-                self._wgrad(sv["dab"], S["hm"], g[q + "fc2.weight"], g[q + "fc2.bias"])
-            k.gemm_nt(sv["dab"], Lw_["w2T"], sv["dpre"], act=L.ACT_GELU_GRAD, aux=S["pre"])
+                self._wgrad(dy2, S["hm"], g[q + "fc2.weight"], g[q + "fc2.bias"])
+            k.gemm_nt(dy2, Lw_["w2T"], sv["dpre"], act=L.ACT_GELU_GRAD, aux=S["pre"])
+            if p_act > 0:
+                k.dropout(sv["dpre"], sv["dpre"], p_act, seed=self._site(sv, i, self._D2), keep_in=fk.get(("d2", i)))
             if wgrads:
                 self._wgrad(sv["dpre"], S["x1b"], g[q + "fc1.weight"], g[q + "fc1.bias"])
             k.gemm_nt(sv["dpre"], Lw_["w1T"], sv["dx1"], res=sv["da"])
             k.layernorm_bwd(sv["dx1"], S["y1"], S["mean1"], S["rstd1"], Lw_["ln1_w"], sv["partial"], dx=sv["db"], dxT=sv["dbb"],
                             dgamma=G(q + "self_attn_layer_norm.weight"), dbeta=G(q + "self_attn_layer_norm.bias"), dtype=bf)
+            dy1 = sv["dbb"]
+            if p_drop > 0:                                                 # dropout1: only the attention branch is masked
+                dy1 = k.dropout(sv["dbb"], sv["dm"], p_drop, seed=self._site(sv, i, self._D1), keep_in=fk.get(("d1", i)))
             if wgrads:
-                self._wgrad(sv["dbb"], S["o"], g[a + "out_proj.weight"], g[a + "out_proj.bias"])
-            k.gemm_nt(sv["dbb"], Lw_["woT"], sv["do"])
-            if self._mfma_attn_bwd(Tn):
-                # dQ/dK/dV by the Conformer's MFMA attention backward with a ZERO relative-position table (the additive bias only
-                # enters through the saved probabilities); it leaves dS (bf16) in the scratch buffer, from which the gate and
-                # bias-table gradients are reduced
-                k.attn_bwd(S["qkv"], W["zero_emb"], S["probs"], sv["do"], sv["dqkv"], None, sv["dsc"], B, Tn, H, self.dh,
-                           rel_emb_T=W["zero_embT"])
-                k.wavlm_attn_bias_grads(sv["dsc"], S["gate"], W["rb"], sv["dgate"], self._drb, B, Tn, H, S["probs"].shape[-1])
-            else:
-                k.wavlm_attn_bwd(S["qkv"], S["probs"], sv["do"], S["gate"], W["rb"], sv["dqkv"], sv["dgate"], self._drb, sv["dsc"],
-                                 B, Tn, H, self.dh)
+                self._wgrad(dy1, S["o"], g[a + "out_proj.weight"], g[a + "out_proj.bias"])
+            k.gemm_nt(dy1, Lw_["woT"], sv["do"])
+            # key-tiled backward: S tiles recomputed from Q, K and the saved log-sum-exp; dgate written, drb accumulated
+            gate, rb = self._attn_bias(S["gate"], active)
+            k.xattn_bwd(S["qkv"], S["o"], sv["do"], S["lse"], sv["dqkv"], sv["delta"], B, Tn, H, self.dh, gate=gate, rb=rb,
+                        klen=klen, drop_p=p_att, seed=self._site(sv, i, self._ATT), keep=fk.get(("att", i)),
+                        dgate=sv["dgate"] if gate is not None else None, drb=self._drb if gate is not None else None)
             if wgrads:
                 gw, gb = self._gqkv[i]
                 self._wgrad(sv["dqkv"], S["xinb"], gw, gb)
             k.gemm_nt(sv["dqkv"], Lw_["wqkvT"], other, res=sv["db"])
-            gp = g if wgrads else self._gate_scratch()
-            k.wavlm_gate_bwd(S["xin"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], sv["dgate"], other, gp[a + "grep_linear.weight"],
-                             gp[a + "grep_linear.bias"], gp[a + "grep_a"].view(-1), B, Tn, H, self.dh)
+            if gate is not None:
+                gp = g if wgrads else self._gate_scratch()
+                k.wavlm_gate_bwd(S["xin"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], sv["dgate"], other, gp[a + "grep_linear.weight"],
+                                 gp[a + "grep_linear.bias"], gp[a + "grep_a"].view(-1), B, Tn, H, self.dh)
+            if sv["mix"]:                                                  # this layer's input is hidden state n
+                k.hidden_mix_dot(dfe, S["xin"], sv["dots"][n:n + 1])
+                k.hidden_mix_axpy(dfe, mix_w, n, other)
             dx = other
+        if sv["mix"] and mix_dw is not None:
+            k.hidden_mix_wgrad(mix_w, sv["dots"], mix_dw)
+        if p_drop > 0:                                                     # the encoder-input dropout
+            k.dropout(dx, dx, p_drop, seed=self._site(sv, -1, 0), keep_in=fk.get("enc"))
         # encoder.layer_norm, then y0 = x + gelu(pos_conv(x))
         k.layernorm_bwd(dx, sv["y0"], sv["mean0"], sv["rstd0"], W["enc_ln_w"], sv["partial"], dx=sv["dy0"],
                         dgamma=G("encoder.layer_norm.weight"), dbeta=G("encoder.layer_norm.bias"), dtype=bf)
@@ -535,14 +658,17 @@ class WavLMBackbone:
                 X = sv["dpc"][:B * Pp, gi * cg:(gi + 1) * cg]
                 ops.gemm_tn(X, A, self._gposw[gi], colsum=g["encoder.pos_conv.0.bias"][gi * cg:(gi + 1) * cg], splitk=16)
             self._posconv_weight_grads()
-            # the bias table's gradient back into the bucket embedding (owned by layer 0): emb[bucket(r)][h] += drb[h][r]
-            g["encoder.layers.0.self_attn.relative_attention_bias.weight"].index_add_(0, W["rb_bucket"], self._drb.t().contiguous())
+            if self.rel_pos:
+                # the bias table's gradient back into the bucket embedding (owned by layer 0): emb[bucket(r)][h] += drb[h][r]
+                g["encoder.layers.0.self_attn.relative_attention_bias.weight"].index_add_(0, W["rb_bucket"], self._drb.t().contiguous())
         # data gradient of the positional convolution (the same strided-view GEMM on the flipped kernel) + the residual path
         for gi in range(self.gpos):
             A = sv["dpg"][gi].as_strided((B * Pp, self.kpos * cg), (cg, 1))
             k.gemm_nt(A, W["pos_wd"][gi], sv["dxp"][:, gi * cg:(gi + 1) * cg])
         k.wavlm_add_rows(sv["dy0"], sv["dxp"], sv["da"], B, Tn, Pp)            # da = d(loss)/d(x after masking)
         dxm = sv["da"]
+        if klen is not None:                                                   # x[padding] = 0 in front of the pos-conv
+            k.zero_padded_rows(dxm, klen, B, Tn)
         if ws.get("masked"):                                                   # WavLM.apply_mask backward (WavLM.py:300-337)
             tm, cm = ws["masked"]
             v3 = dxm.view(B, Tn, d)
@@ -552,21 +678,15 @@ class WavLMBackbone:
                 sel = tm.bool()
                 g["mask_emb"] += (v3 * sel[:, :, None].to(v3.dtype)).sum((0, 1))
                 v3.mul_((~sel)[:, :, None].to(v3.dtype))
+        p_in = float(self.cfg.get("dropout_input", 0.0))
+        if p_in > 0:
+            k.dropout(dxm, dxm, p_in, seed=self._site(sv, -1, 1), keep_in=fk.get("in"))
         # post_extract_proj (frozen: data gradient only), then the LayerNorm on the conv features
         k.scale_cast(dxm, sv["dab"], 1.0)
         k.gemm_nt(sv["dab"], W["proj_wT"], sv["dxc"])
         k.layernorm_bwd(sv["dxc"], ws["xc"], ws["mean_in"], ws["rstd_in"], W["ln0_w"], sv["partial"],
                         dx=sv["db"].view(-1)[:M * self.C].view(M, self.C),      # (unused: the conv extractor below is frozen)
                         dgamma=g["layer_norm.weight"], dbeta=g["layer_norm.bias"], dtype=bf)
-
-    def _mfma_attn_bwd(self, Tn: int) -> bool:
-        ok = getattr(self, "_mfma_ok", None)
-        if ok is None:
-            ok = self._mfma_ok = {}
-        if Tn not in ok:
-            import os
-            ok[Tn] = os.environ.get("LIDK_WAVLM_ATTN_BWD", "mfma") == "mfma" and ops.attn_bwd_relpos_supported(Tn, self.dh, torch.bfloat16)
-        return ok[Tn]
 
     def _gate_scratch(self):
         """Throw-away targets for the gate's parameter gradients while the encoder is frozen (data gradients only)."""
@@ -597,11 +717,14 @@ class WavLMBackbone:
 
     # ------------------------------------------------------------------ forward
     def forward(self, wav: torch.Tensor, taps: Dict[str, torch.Tensor] = None, mask: bool = False,
-                n_samples: List[int] = None, train: bool = False) -> torch.Tensor:
+                n_samples: List[int] = None, train: bool = False, mix_w: torch.Tensor = None) -> torch.Tensor:
         """wav (B, L) f32 on the GPU -> (B, T, d) f32.  ``taps`` (tests): receives copies of the stage outputs.
         mask=True (training, WavLM.apply_mask): spans of the projected features are replaced by ``mask_emb`` / zeroed channels
-        with cfg mask_prob / mask_channel_prob; n_samples (true lengths of a zero-padded batch) only shapes the padding mask
-        those spans avoid - like the reference, the encoder itself never sees a padding mask."""
+        with cfg mask_prob / mask_channel_prob.  n_samples (true lengths of a zero-padded batch): in WavLM it only shapes the
+        padding mask those spans avoid - like the reference, the encoder itself never sees a padding mask; with
+        cfg ``encoder_padding_mask`` (wav2vec2) padded frames are zeroed in front of the positional convolution and masked out
+        as attention keys.  mix_w (L + 1,) f32 on the GPU: return the softmax(mix_w)-weighted sum of the hidden states (the input
+        of every layer and the encoder output: s3prl's ``hidden_states`` feature) instead of the last one."""
         if not wav.is_cuda or wav.dtype != torch.float32:
             raise LidkError("WavLMBackbone.forward needs a float32 GPU tensor (B, L)")
         if not self._prepared:
@@ -613,19 +736,27 @@ class WavLMBackbone:
         ws["wav"].copy_(wav)                                  # static input buffer: captured launches see one address
         masking = mask and (self.cfg.get("mask_prob", 0.0) > 0 or self.cfg.get("mask_channel_prob", 0.0) > 0)
         ws["masked"] = None
-        if train:                                             # un-frozen encoder: keep what backward needs (eager launches)
+        klen = self._key_lengths(ws, B, Tn, Lw, n_samples)
+        if train:                                             # keep what backward needs (eager launches, dropouts on)
+            self.step += 1
             self.graphs.run(("pre", B, Lw), lambda: self._fwd_pre(ws, B, None))
+            sv = self._train_buffers(ws, B)
+            p_in = float(self.cfg.get("dropout_input", 0.0))
+            if p_in > 0:
+                sv["drop"] = dict(base=(((self.seed * 1000003 + self.step) & 0x7FFFFFFF) << 12))
+                ops.dropout(ws["x"], ws["x"], p_in, seed=self._site(sv, -1, 1), keep_in=self.forced_keep.get("in"))
             if masking:
                 self._apply_mask(ws, B, Tn, Lw, n_samples)
-            self._fwd_post_train(ws, B, self._train_buffers(ws, B))
+            self._fwd_post_train(ws, B, sv, klen, mix_w)
         elif taps is not None:                                # tests: eager, with copies of the stage outputs
             self._fwd_pre(ws, B, taps)
             if masking:
                 self._apply_mask(ws, B, Tn, Lw, n_samples)
-            self._fwd_post(ws, B, taps)
+            self._fwd_post(ws, B, taps, klen=klen, mix_w=mix_w)
         else:
             self.graphs.run(("pre", B, Lw), lambda: self._fwd_pre(ws, B, None))
             if masking:
                 self._apply_mask(ws, B, Tn, Lw, n_samples)     # host-drawn spans -> two small H2D copies + one launch
-            self.graphs.run(("post", B, Lw), lambda: self._fwd_post(ws, B, None))
-        return ws["x"].view(B, Tn, d)
+            self.graphs.run(("post", B, Lw, klen is not None, None if mix_w is None else mix_w.data_ptr()),
+                            lambda: self._fwd_post(ws, B, None, klen=klen, mix_w=mix_w))
+        return (ws["feat"] if mix_w is not None else ws["x"]).view(B, Tn, d)

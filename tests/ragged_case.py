@@ -67,3 +67,14 @@ def wavlm_batch():
     wav_pct = torch.FloatTensor([w.shape[0] / longest for w in wavs])
     txt_pct = torch.FloatTensor([t.shape[-1] / (tx.shape[1] + 1e-9) for t in texts])
     return wavs, tx, wav_pct, txt_pct
+
+
+def wavlm_long_batch():
+    """(2, 208000) f32: two 13 s waveforms (T = 649 frames after the conv stack: the reference WavLM confs' max_duration)."""
+    g = torch.Generator().manual_seed(4711)
+    n = 13 * 16000
+    t = torch.arange(n) / 16000.0
+    x = 0.3 * torch.randn(2, n, generator=g)
+    for b in range(2):
+        x[b] += 0.5 * torch.sin(2 * math.pi * (150.0 * (b + 1)) * t) * (0.5 + 0.5 * torch.sin(2 * math.pi * 0.7 * t))
+    return x

@@ -248,3 +248,23 @@ def test_wavlm_gradient_accumulation_without_masking_keeps_every_micro_batch():
     for n in names:
         rel = float((params[n].grad - 2 * one[n]).abs().max() / (2 * one[n]).abs().max())
         assert rel <= 2e-3, (n, rel)
+
+
+def test_wavlm_backbone_13_s_utterances_against_the_reference():
+    """the reference WavLM confs train with max_duration 13 s (T = 649 frames); the backbone's first attention
+    kernels stopped at 256 frames.  Key-tiled attention: the reference backbone's features on two 13 s utterances."""
+    from lidk.wavlm import WavLMBackbone
+    g = load_npz("wavlm_long.npz")
+    bb = WavLMBackbone(wc.CFG)
+    bb.load_state_dict(wc.backbone_weights())
+    bb.to(DEV)
+    taps = {}
+    out = bb.forward(rc.wavlm_long_batch().to(DEV), taps)
+    torch.cuda.synchronize()
+    assert out.shape[1] == int(g["frames"]) == 649
+    for key, got in (("layer0_8", taps["layer0"][:, ::8]), ("features_8", out[:, ::8])):
+        ref = torch.from_numpy(g[key])
+        err, scale = float((got.float().cpu() - ref).abs().max()), float(ref.abs().max())
+        rel = float((got.float().cpu() - ref).norm() / ref.norm())
+        print(f"[wavlm 13 s {key}] max_abs_err={err:.3e} (max |ref| {scale:.2f}) rel_l2={rel:.3e}")
+        assert err <= 2e-2 * scale and rel <= 1.5e-2

@@ -60,8 +60,40 @@ def test_wavlm_model_state_dict_names_and_module_surface():
     assert [n for n, p in mod.model.named_parameters() if p.requires_grad] == trainable
     with pytest.raises(NotImplementedError):
         mod.model.unfreeze_feature_extractor()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                                 # a wav2vec2 model needs a checkpoint or a config
         LidModule(lang2vocab=wc.L2V, lang2index_dict=wc.L2I, tokenizer_dict=toks, use_wav2vec=True, conformer_linear=True)
+
+
+def test_wav2vec2_model_state_dict_names_and_module_surface():
+    """LidModule(use_wav2vec=True) builds the wav2vec2-backbone model (lid/Wav2vecMutiLangModel.py): fairseq parameter names under
+    model.featurizer.upstream.model.*, the s3prl Featurizer's mixing weights, no relative-position parameters; the freeze_*
+    helpers leave layer_norm + mask_emb (+ the mixing weights and heads) trainable, like the reference's."""
+    from lid.LidModule_ASR import LidModule
+    from lid.tokenizer import CTCTokenizer
+    from lidk.wavlm import WavLMBackbone
+    toks = {k: CTCTokenizer([chr(0x4E00 + i) for i in range(v)]) for k, v in wc.L2V.items()}
+    mod = LidModule(optimizer_name="adam", optimizer_param={"lr": 1e-4}, scheduler="none", use_wav2vec=True, conformer_linear=True,
+                    sr=16000, dropout=0.0, linear_dim=768, mask=True, hidden_dim=32, feature_selection="hidden_states", dim_head=32,
+                    num_head=8, lang2vocab=wc.L2V, lang2index_dict=wc.L2I, tokenizer_dict=toks, wav2vec_cfg=wc.W2V_CFG)
+    m = mod.model
+    pre = "model.featurizer.upstream.model."
+    shapes = WavLMBackbone.param_shapes(wc.W2V_CFG)
+    assert not any("grep" in k or "relative_attention_bias" in k for k in shapes)
+    want = {pre + k for k in shapes} | set(wc.head_weights()) | {"model.featurizer.weights"}
+    assert set(m.state_dict()) == want
+    assert m.state_dict()["model.featurizer.weights"].shape == (wc.W2V_CFG["encoder_layers"] + 1,)
+    assert m.backbone.pad_mask and not m.backbone.rel_pos and m.backbone.cfg["mask_prob"] == 0.65
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad and n.startswith("model.featurizer.")}
+    assert trainable == {pre + "layer_norm.weight", pre + "layer_norm.bias", pre + "mask_emb", "model.featurizer.weights"}
+    m.unfreeze_tranformer_encoder()
+    now = {n for n, p in m.named_parameters() if p.requires_grad and n.startswith(pre)}
+    assert {pre + k for k in shapes if k.startswith("encoder.")} <= now
+    m.froze_wav2vec_model()
+    assert not any(p.requires_grad for p in m.model.parameters()) and all(p.requires_grad for p in m.lang_discriminator.parameters())
+    m.unfroze_wav2vec_model()
+    last = LidModule(use_wav2vec=True, conformer_linear=True, feature_selection="last_hidden_state", lang2vocab=wc.L2V,
+                     lang2index_dict=wc.L2I, tokenizer_dict=toks, wav2vec_cfg=wc.W2V_CFG, linear_dim=768)
+    assert "model.featurizer.weights" not in last.model.state_dict()
 
 
 def test_padding_frames_closed_form_equals_forward_padding_mask():

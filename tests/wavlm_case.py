@@ -14,6 +14,12 @@ CFG = dict(encoder_layers=2, encoder_embed_dim=768, encoder_ffn_embed_dim=3072, 
 # fine-tuning fixtures: the same model with every dropout and LayerDrop switched off, so a training-mode step is deterministic
 CFG_TRAIN = dict(CFG, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0, dropout_features=0.0,
                  encoder_layerdrop=0.0)
+# wav2vec2 Base architecture (fairseq Wav2Vec2Config names; lid/s3prl_updream/wav2vec/wav2vec2.py) at reduced depth: no relative
+# position embedding, the encoder receives the padding mask; dropouts off for deterministic training-mode fixtures
+W2V_CFG = dict(encoder_layers=2, encoder_embed_dim=768, encoder_ffn_embed_dim=3072, encoder_attention_heads=12,
+               conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2", conv_pos=128, conv_pos_groups=16,
+               layer_norm_first=False, extractor_mode="default", conv_bias=False, dropout=0.0, attention_dropout=0.0,
+               activation_dropout=0.0, dropout_input=0.0, dropout_features=0.0, encoder_layerdrop=0.0)
 MASK_PROB, MASK_CHANNEL_PROB, MASK_SEED = 0.3, 0.2, 5           # the span-masked frozen-regime fixture (numpy seed before the step)
 L2V = {"a": 30, "b": 40, "c": 50}
 L2I = {"a": 0, "b": 1, "c": 2}
@@ -25,7 +31,7 @@ def _seed(name: str) -> int:
     return (sum((i + 1) * ord(c) for i, c in enumerate(name)) * 2654435761) % (2 ** 31)
 
 
-def backbone_shapes(layers: int):
+def backbone_shapes(layers: int, rel_pos: bool = True):
     s = {"mask_emb": (768,), "feature_extractor.conv_layers.0.0.weight": (512, 1, 10),
          "feature_extractor.conv_layers.0.2.weight": (512,), "feature_extractor.conv_layers.0.2.bias": (512,)}
     for i in range(1, 7):
@@ -34,12 +40,14 @@ def backbone_shapes(layers: int):
               "encoder.pos_conv.0.weight_g": (1, 1, 128), "encoder.pos_conv.0.weight_v": (768, 48, 128)})
     for i in range(layers):
         p = f"encoder.layers.{i}."
-        s[p + "self_attn.grep_a"] = (1, 12, 1, 1)
-        if i == 0:
+        if rel_pos:
+            s[p + "self_attn.grep_a"] = (1, 12, 1, 1)
+        if i == 0 and rel_pos:
             s[p + "self_attn.relative_attention_bias.weight"] = (320, 12)
         for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
             s[p + f"self_attn.{n}.weight"], s[p + f"self_attn.{n}.bias"] = (768, 768), (768,)
-        s[p + "self_attn.grep_linear.weight"], s[p + "self_attn.grep_linear.bias"] = (8, 64), (8,)
+        if rel_pos:
+            s[p + "self_attn.grep_linear.weight"], s[p + "self_attn.grep_linear.bias"] = (8, 64), (8,)
         s[p + "self_attn_layer_norm.weight"], s[p + "self_attn_layer_norm.bias"] = (768,), (768,)
         s[p + "fc1.weight"], s[p + "fc1.bias"], s[p + "fc2.weight"], s[p + "fc2.bias"] = (3072, 768), (3072,), (768, 3072), (768,)
         s[p + "final_layer_norm.weight"], s[p + "final_layer_norm.bias"] = (768,), (768,)
@@ -48,11 +56,11 @@ def backbone_shapes(layers: int):
     return s
 
 
-def backbone_weights(layers: int = CFG["encoder_layers"]):
+def backbone_weights(layers: int = CFG["encoder_layers"], rel_pos: bool = True):
     """name -> CPU f32 tensor for lid/wavlm/WavLM.py's state_dict: every tensor drawn from its own seeded generator, scaled so
     that activations stay O(1) through the stack (fan-in scaling; norm scales near 1, biases small but non-zero)."""
     out = {}
-    for name, shape in backbone_shapes(layers).items():
+    for name, shape in backbone_shapes(layers, rel_pos).items():
         g = torch.Generator().manual_seed(_seed(name))
         if name.endswith(("norm.weight", "conv_layers.0.2.weight")):
             t = 1.0 + 0.1 * torch.randn(shape, generator=g)
