@@ -68,16 +68,22 @@ def build(args, rank, world, device):
           "module.interval=1000000", "trainer.log_interval=1000000", f"model.n_blocks={args.blocks}",
           f"module.optimizer_param.lr={args.lr}"]
     global N_LANGS
-    if args.model == "wavlm":
+    if args.model in ("wavlm", "w2v2"):
+        key = "wavlm_cfg" if args.model == "wavlm" else "wav2vec_cfg"
         ov = [o for o in ov if not o.startswith(("model.n_blocks", "trainer.total_epoch", "module.optimizer_param.lr"))] + ["trainer.total_epoch=1000",
-              f"model.wavlm_cfg.encoder_layers={args.blocks}", "data.synthetic.seconds=3.0",
+              f"model.{key}.encoder_layers={args.blocks}",
               f"+module.train_input_norm={'false' if args.wavlm_regime == 'heads' else 'true'}"]
+        if not args.ragged:
+            ov += ["data.synthetic.seconds=3.0", "data.synthetic.min_seconds=null", "data.synthetic.bucket_seconds=null"] \
+                if args.model == "w2v2" else ["data.synthetic.seconds=3.0"]
+    if args.ragged and args.model != "w2v2":       # SURVEY 8d's cfg5 recipe: U[1, 10] s in 1 s bins, batches of similar length
+        ov += ["data.synthetic.seconds=10.0", "+data.synthetic.min_seconds=1.0", "+data.synthetic.bucket_seconds=1.0"]
     cfg = hydra_lite.load_config(os.path.join(ROOT, "speech-lid_amd", "lid", "conf"),
-                                 "synthetic_cfg2" if args.model == "conformer" else "synthetic_wavlm", ov)
+                                 {"conformer": "synthetic_cfg2", "wavlm": "synthetic_wavlm", "w2v2": "synthetic_w2v2"}[args.model], ov)
     N_LANGS = len(cfg["data"]["langs"])
     module, sets, params = launcher.build(cfg, rank, world)
     module.model.use_stochastic_depth = bool(args.stochastic_depth)
-    if args.model == "wavlm" and args.wavlm_regime == "finetune":
+    if args.model in ("wavlm", "w2v2") and args.wavlm_regime == "finetune":
         module.model.unfreeze_tranformer_encoder()
     trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
     trainer.ccml_module = module
@@ -112,16 +118,22 @@ class CachedDataset(torch.utils.data.Dataset):
         return self.ds.collate_fn(batch)
 
 
-def resident_batches(ds, rank, world, device, batch, resident):
+def resident_batches(ds, rank, world, device, batch, resident, ragged=False):
     """``resident`` batches per language, built once and moved to HBM (each rank gets different utterances of the language).
-    Order: round-robin over languages, so consecutive steps train different heads."""
+    Order: round-robin over languages, so consecutive steps train different heads.  ragged: a language's utterances are sorted by
+    length and cut into batches (bucketed padding, what MutiBatchSampler(bucket_window) yields); each batch carries the seconds
+    of TRUE audio it holds (``_audio_s``), which is what the throughput counts - padding is not audio."""
     per_lang = len(ds) // N_LANGS
     out = []
     for r in range(resident):
         for k in range(N_LANGS):
             base = k * per_lang
-            idx = [base + ((r * world + rank) * batch + j) % per_lang for j in range(batch)]
+            order = list(range(per_lang))
+            if ragged:
+                order.sort(key=lambda i: ds.n_samples_of(base + i))
+            idx = [base + order[((r * world + rank) * batch + j) % per_lang] for j in range(batch)]
             b = list(ds.collate_fn([ds[i] for i in idx]))
+            b.append(sum(ds.n_samples_of(i) for i in idx) / 16000.0 if ragged else batch * SECONDS)
             b[0] = [w.to(device) for w in b[0]] if isinstance(b[0], list) else b[0].to(device)
             for j in (1, 2, 3, 5):
                 b[j] = b[j].to(device)
@@ -591,8 +603,12 @@ def fit_throughput(args, cfg, module, sets, params, device):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", choices=["conformer", "wavlm"], default="conformer",
-                    help="conformer = BASELINE configs[1] (the headline); wavlm = configs[3]: WavLM-base backbone (frozen) + heads")
+    ap.add_argument("--model", choices=["conformer", "wavlm", "w2v2"], default="conformer",
+                    help="conformer = BASELINE configs[1] (the headline); wavlm = configs[3]: WavLM-base backbone + heads; "
+                         "w2v2 = configs[4]: wav2vec2-base backbone (key padding mask, hidden-state mix) + heads")
+    ap.add_argument("--ragged", action="store_true",
+                    help="variable-length utterances U[1, 10] s in 1 s bins with bucketed padding (BASELINE configs[4]'s data shape); "
+                         "audio-seconds count TRUE audio")
     ap.add_argument("--wavlm-regime", choices=["heads", "frozen", "finetune"], default="frozen",
                     help="heads = gradient stops at the features (train_input_norm=false: backbone = 2 graphs); frozen = the "
                          "reference's first-epoch regime (encoder frozen, layer_norm + mask_emb train: data gradients through the "
@@ -618,7 +634,7 @@ def main():
     ap.add_argument("--fit-epochs", type=int, default=4, help="epochs of the Trainer.fit measurement (0 = skip)")
     ap.add_argument("--fit-workers", type=int, default=4)
     args = ap.parse_args()
-    if args.model == "wavlm":                    # secondary line: no Cavg phase (random frozen backbone), no fit leg
+    if args.model in ("wavlm", "w2v2") or args.ragged:        # secondary lines: no Cavg phase, no fit leg
         args.cavg_steps, args.fit_epochs = 0, 0
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -638,7 +654,8 @@ def main():
     cfg, module, trainer, sets = build(args, rank, world, device)
     ds = sets["train"]
     log("model built; materialising resident batches")
-    batches = resident_batches(ds, rank, world, device, args.batch, args.resident)
+    batches = resident_batches(ds, rank, world, device, args.batch, args.resident, ragged=args.ragged)
+    batch_audio = [b.pop() for b in batches]
     log(f"{len(batches)} resident batches in HBM; set-up + warm-up")
     nb = len(batches)
     n_total = 10 ** 9
@@ -673,8 +690,10 @@ def main():
     marks[0].record()
     burst = min(8, args.steps)                     # host cost per step: the first steps after a sync, while the device queue is
     host_issue = 0.0                               # still short (later the host is throttled by the queue depth, not by its work)
+    audio_s_rank = 0.0
     for i in range(args.steps):
         _, loss, _ = step_fn(it, batches[it % nb], batches[(it + 1) % nb])
+        audio_s_rank += batch_audio[it % nb]
         it += 1
         losses.append(loss)
         if i + 1 == burst:
@@ -706,36 +725,46 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_model, usable = host_info()
         log(f"cpu baseline on {usable} cores ({cpu_model})")
-        if args.model == "wavlm":
+        if args.model == "w2v2" or args.ragged:
+            cpu = None                                   # the bounded CPU sample belongs to the two fixed-length headline workloads
+        elif args.model == "wavlm":
             cpu = cpu_baseline_wavlm(module, ds, max(args.cpu_steps // 2, 3), 1, min(args.cpu_batch, 8), usable, cpu_model)
         else:
             cpu = cpu_baseline(module, ds, args.cpu_steps, 2, args.cpu_batch, usable, cpu_model)
     if rank == 0:
-        audio_s = world * args.batch * SECONDS * args.steps
+        audio_s = world * audio_s_rank                    # ragged: true audio of this rank's batches x ranks (same length mix)
         med = sorted(chunk_ms)[len(chunk_ms) // 2]
-        if args.model == "wavlm":
+        if args.model in ("wavlm", "w2v2"):
             regime = {"heads": "backbone forward only (gradient stops at the features)",
                       "frozen": "encoder frozen as in the reference's first epochs: data gradients through the transformer to "
                                 "layer_norm + mask_emb",
                       "finetune": "transformer encoder un-frozen: full encoder backward + Adam on it"}[args.wavlm_regime]
-            metric = f"audio-seconds/sec LID training, WavLM-base backbone ({args.wavlm_regime}) + Conformer heads"
-            workload = (f"WavLMMutiLangModel: WavLM-base width backbone ({args.blocks} transformer layers, conv extractor on raw "
-                        f"3 s@16 kHz waveforms, span masking on; {regime}) + {N_LANGS} Conformer CTC heads d768 "
-                        f"(forward + backward), Adam, batch={args.batch}/GPU")
+            dur = "1-10 s (1 s bins, bucketed padding; true audio counted)" if args.ragged else "3 s"
+            if args.model == "wavlm":
+                metric = f"audio-seconds/sec LID training, WavLM-base backbone ({args.wavlm_regime}) + Conformer heads"
+                workload = (f"WavLMMutiLangModel: WavLM-base width backbone ({args.blocks} transformer layers, conv extractor on raw "
+                            f"{dur}@16 kHz waveforms, span masking + dropouts on; {regime}) + {N_LANGS} Conformer CTC heads d768 "
+                            f"(forward + backward), Adam, batch={args.batch}/GPU")
+            else:
+                metric = f"audio-seconds/sec joint CTC+LID training, wav2vec2-base backbone ({args.wavlm_regime}) + Conformer heads"
+                workload = (f"LidModule on Wav2vecMutiLangModel: wav2vec2-base backbone ({args.blocks} transformer layers, key padding "
+                            f"mask, hidden-state mix, span masking + dropouts on; {regime}), {dur}@16 kHz waveforms, {N_LANGS} Conformer "
+                            f"CTC heads d768 (forward + backward), Adam, batch={args.batch}/GPU")
         else:
             metric = "audio-seconds/sec LID training, Conformer d256"
-            workload = (f"ConformerLangModel {args.blocks}-layer d256, 14-lang CTC heads, log-mel 80-bin, 3 s@16 kHz, "
+            dur = "1-10 s (1 s bins, bucketed padding; true audio counted)" if args.ragged else "3 s"
+            workload = (f"ConformerLangModel {args.blocks}-layer d256, 14-lang CTC heads, log-mel 80-bin, {dur}@16 kHz, "
                         f"batch={args.batch}/GPU, Novograd+clip, features on GPU")
         line = {"metric": metric, "value": round(audio_s / elapsed, 1),
                 "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": workload,
-                           "global_batch": world * args.batch, "utterance_seconds": SECONDS,
+                           "global_batch": world * args.batch, "utterance_seconds": "1-10" if args.ragged else SECONDS,
                            "parallelism": f"dp{world}", "stochastic_depth": bool(args.stochastic_depth),
                            "grad_payload": trainer.grad_compress if world > 1 else None},
                 "chunks_ms_per_step": [round(c, 3) for c in chunk_ms], "median_ms_per_step": round(med, 3),
-                "value_at_median": round(world * args.batch * SECONDS / (med * 1e-3), 1),
+                "value_at_median": round(audio_s / args.steps / (med * 1e-3), 1),
                 "loss_first_last": [round(float(loss_vals[0]), 4), round(float(loss_vals[-1]), 4)], "loss_finite": finite,
                 "host_issue_ms_per_step": round(host_issue * 1e3, 3), "phases_ms": phases, "roofline": roof,
                 # whole step against the MFMA roof: SURVEY 8d's algorithmic FLOPs (21.67 GFLOP per 3 s utterance: one head,

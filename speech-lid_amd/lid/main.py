@@ -61,8 +61,10 @@ def build(cfg, rank=0, world=1):
     sets = {s: dataset(s, s == "train") for s in ("train", "val", "test")}
     sc = data["sampler_common"]
     params = dict(data["dataloader_params"])
+    window = int(sc.get("bucket_window", 0))                              # > 0: batches of similar length (bucketed padding)
+    lengths = getattr(sets["train"], "n_samples_of", None) if window > 0 else None
     params["train_batch_sampler"] = MutiBatchSampler(sets["train"].samplers, sc["train_batch_size"], True, rank, world,
-                                                     seed=0 if world > 1 else None)
+                                                     seed=0 if world > 1 else None, lengths=lengths, bucket_window=window)
     params["val_batch_sampler"] = MutiBatchSampler(sets["val"].samplers, sc["val_batch_size"], False, rank, world, seed=1)
     params["test_batch_sampler"] = MutiBatchSampler(sets["test"].samplers, sc["test_batch_size"], False, 0, 1, seed=2)
     return module, sets, params

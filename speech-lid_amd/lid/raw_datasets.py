@@ -123,10 +123,14 @@ class MutiBatchSampler(Sampler[List[int]]):
     the same head on disjoint utterances.  ``set_epoch`` reseeds the draw."""
 
     def __init__(self, samplers: List[Sampler[int]], batch_size: int, drop_last: bool, rank: int = 0, world_size: int = 1,
-                 seed: Optional[int] = None) -> None:
+                 seed: Optional[int] = None, lengths=None, bucket_window: int = 0) -> None:
+        """lengths (index -> samples) + bucket_window > 0: bucketed padding (BASELINE config 5).  Each language's permutation is
+        cut into windows of ``bucket_window`` global batches, a window is sorted by length and cut into batches (so a batch
+        pads to a similar length), and the window's batches are then drawn in random order.  0 = the reference's behaviour."""
         self.samplers, self.batch_size, self.drop_last = samplers, batch_size, drop_last
         self.rank, self.world_size, self.seed, self.epoch = rank, world_size, seed, 0
         self.weight = [len(s) for s in samplers]
+        self.lengths, self.bucket_window = lengths, int(bucket_window)
 
     def set_epoch(self, epoch: int):
         self.epoch = epoch
@@ -138,6 +142,8 @@ class MutiBatchSampler(Sampler[List[int]]):
             for k, s in enumerate(self.samplers):                           # identical permutations on every rank
                 s.generator = torch.Generator().manual_seed(((self.seed or 0) * 1000003 + self.epoch * 1009 + k) % (2 ** 31))
         iters = [iter(s) for s in self.samplers]
+        if self.lengths is not None and self.bucket_window > 0:
+            iters = [iter(self._bucketed(list(it), gb, rng)) for it in iters]
         remain = [len(s) for s in self.samplers]
         while sum(remain) > 0:
             area = rng.randint(0, sum(remain) - 1)
@@ -154,6 +160,17 @@ class MutiBatchSampler(Sampler[List[int]]):
                 per = math.ceil(take / self.world_size)
                 mine = batch[self.rank * per:(self.rank + 1) * per]
                 yield mine if mine else batch[:1]
+
+    def _bucketed(self, order: List[int], gb: int, rng) -> List[int]:
+        """One language's permutation re-ordered so that consecutive runs of ``gb`` indices have similar lengths."""
+        out, win = [], self.bucket_window * gb
+        for w0 in range(0, len(order), win):
+            chunk = sorted(order[w0:w0 + win], key=lambda i: self.lengths(i))
+            batches = [chunk[b0:b0 + gb] for b0 in range(0, len(chunk), gb)]
+            full = [b for b in batches if len(b) == gb]
+            rng.shuffle(full)
+            out += [i for b in full for i in b] + [i for b in batches if len(b) != gb for i in b]
+        return out
 
     def __len__(self) -> int:
         gb = self.batch_size * self.world_size
@@ -268,12 +285,15 @@ class SyntheticMergedDataset(_CollateMixin, Dataset):
 
     def __init__(self, train: bool, langs: Dict[str, int], lang2vocab: Dict[str, int], items_per_lang: int = 64,
                  seconds: float = 3.0, text_len: int = 20, seed: int = 1234, lang2tokenizer: Dict = None,
-                 min_seconds: Optional[float] = None, transcript: str = "random", cache: bool = True, **feature):
-        """min_seconds: if given, item i lasts U[min_seconds, seconds] (a pure function of (seed, i)): ragged batches."""
+                 min_seconds: Optional[float] = None, transcript: str = "random", cache: bool = True,
+                 bucket_seconds: Optional[float] = None, **feature):
+        """min_seconds: if given, item i lasts U[min_seconds, seconds] (a pure function of (seed, i)): ragged batches;
+        bucket_seconds: those durations are rounded UP to a multiple of it (SURVEY 8d's cfg5 recipe: U[1, 10] s in 1 s bins)."""
         if transcript not in ("random", "tones"):
             raise ValueError(f"transcript must be 'random' or 'tones', got {transcript!r}")
         self.train, self.lang2index_dict, self.lang2vocab = train, dict(langs), dict(lang2vocab)
         self.min_samples = None if min_seconds is None else int(min_seconds * feature.get("sr", 16000))
+        self.bucket_samples = None if not bucket_seconds else int(bucket_seconds * feature.get("sr", 16000))
         self.feat = _FeatureCfg(**{"speed_shift": False, "pitch_shift": False, "reverb": False, **feature})
         self.type = self.feat.type
         self.n_samples, self.text_len, self.seed = int(seconds * self.feat.sr), text_len, seed
@@ -302,7 +322,15 @@ class SyntheticMergedDataset(_CollateMixin, Dataset):
     def _length(self, index: int, g: torch.Generator) -> int:
         if self.min_samples is None:
             return self.n_samples
-        return self.min_samples + int(torch.randint(0, max(self.n_samples - self.min_samples, 0) + 1, (1,), generator=g))
+        n = self.min_samples + int(torch.randint(0, max(self.n_samples - self.min_samples, 0) + 1, (1,), generator=g))
+        if self.bucket_samples:
+            n = min(-(-n // self.bucket_samples) * self.bucket_samples, max(self.n_samples, self.bucket_samples))
+        return n
+
+    def n_samples_of(self, index: int) -> int:
+        """Length of item ``index`` without synthesising it (what a manifest's duration column gives a real corpus)."""
+        g = torch.Generator().manual_seed((self.seed * 7919 + index) % (2 ** 31))
+        return self._length(index, g)
 
     def text(self, index: int) -> torch.Tensor:
         item = self.datasets[index]

@@ -130,3 +130,48 @@ def test_reference_schema_yaml_trains_from_disk(tmp_path, monkeypatch):
     assert os.path.exists("ckpt/last.pt") and trainer.current_step == 2 * 3     # 6 batches / accumulate_grad 2, 2 epochs
     state = torch.load("ckpt/last.pt", weights_only=False)
     assert {"model", "hyper_parameters", "epoch", "optimizer", "scalar", "logger"} <= set(state)
+
+
+def test_trainer_fit_wav2vec2_variable_length_bucketed(tmp_path, monkeypatch):
+    """BASELINE config 5 in miniature through the launcher: LidModule(use_wav2vec) on a 2-layer wav2vec2-width backbone, 1 - 4 s
+    utterances in 1 s bins with bucketed padding, epoch 0 with the transformer frozen, epoch 1 fine-tuning it: finite losses, the
+    Featurizer's mixing weights and (from epoch 1) the encoder move, the conv feature extractor stays bit-identical."""
+    monkeypatch.chdir(tmp_path)
+    from ccml import seed_everything
+    from ccml.trainer import Trainer
+    from lid import hydra_lite
+    import lid.main as launcher
+    seed_everything(0)
+    cfg = hydra_lite.load_config(os.path.join(PKG, "lid", "conf"), "synthetic_w2v2",
+                                 ["model.wav2vec_cfg.encoder_layers=2", "model.wav2vec_cfg.mask_prob=0.3", "trainer.total_epoch=2",
+                                  "trainer.gpu_id=0", "data.synthetic.items_per_lang=16", "data.synthetic.seconds=4.0",
+                                  "data.sampler_common.train_batch_size=8", "module.freeze_tranformer_epoch=0", "module.interval=1000",
+                                  "trainer.log_interval=1000", "module.scheduler=none"])
+    module, sets, params = launcher.build(cfg)
+    m = module.model
+    assert type(m).__name__ == "Wav2vecMutiLangModel" and params["train_batch_sampler"].bucket_window == 4
+    lens = sorted({sets["train"].n_samples_of(i) for i in range(len(sets["train"]))})
+    assert len(lens) > 1 and all(n % 16000 == 0 for n in lens)
+    pre = m.BB_PREFIX
+    before = {k: v.detach().clone() for k, v in m.state_dict().items() if k.startswith(pre) or k == "model.featurizer.weights"}
+    snaps, losses = {}, []
+    orig = module.train_loop_end
+
+    def spy(outputs):
+        losses.append(float(torch.stack([o["loss"].float() for o in outputs]).mean()))
+        snaps[len(losses)] = m.state_dict()[pre + "encoder.layers.1.fc1.weight"].detach().clone()
+        return orig(outputs)
+
+    module.train_loop_end = spy
+    trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
+    trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=params)
+    print("w2v2 epoch losses", losses, "val", module.last_val)
+    assert len(losses) == 2 and all(np.isfinite(losses)) and np.isfinite(module.last_val["val_loss"])
+    after = m.state_dict()
+    key = pre + "encoder.layers.1.fc1.weight"
+    assert torch.equal(snaps[1].cpu(), before[key].cpu())                       # epoch 0: transformer frozen
+    assert not torch.equal(snaps[2].cpu(), before[key].cpu())                   # epoch 1: fine-tuned
+    assert float(after["model.featurizer.weights"].abs().max()) > 0             # the hidden-state mix trains from step one
+    for k in before:
+        if ".feature_extractor." in k or ".post_extract_proj." in k:
+            assert torch.equal(after[k].cpu(), before[k].cpu()), k
