@@ -56,21 +56,24 @@ int lidk_speed_perturb(const float* x, int B, int Lin, const int32_t* n_in, floa
 /* lid/audio_processor.py:72-105 _internal_wav2mel (torchaudio MelSpectrogram + AmplitudeToDB(top_db=80)) fused with
  * lid/audio_processor.py:225-227 spectrogram_augment masks and lid/raw_datasets.py:345-365 collate layout.
  * wav [B][L] -> out [B][F][n_mels] f32 dB, F = 1 + (L + 2*pad)/hop.  window [512] (hann(win) centred), twiddle [256][2]
- * (cos,sin of 2*pi*k/512), melfb [257][n_mels].  utt_max [B] scratch (per-utterance dB max, used for the top_db floor).
+ * (cos,sin of 2*pi*k/512), melfb [257][n_mels].  utt_max: scratch of 2*B floats (per-utterance dB max for the top_db floor +
+ * one int ticket per utterance: the workgroup that finishes an utterance last applies the floor and the masks).
  * spans [B][mask_times][4] int32 = (t0,t1,f0,f1) filled with 0.0 dB, or NULL/mask_times=0 for none.
+ * mel_rng [2][128] int32 + mel_coef [128][32] f32 (both may be NULL): the filterbank in compact form - first / last non-zero FFT
+ * bin of every filter and its taps from the first one on (zero padded) - so a workgroup copies 17 KB instead of scanning melfb.
  * n_samples (may be NULL): ragged batch - utterance b has n_samples[b] samples, hence F_b = 1 + (n_samples[b] + 2*pad)/hop
  * frames computed as if it were alone (reflection at its own end, its own top_db maximum); rows F_b..F-1 are exactly 0.0,
  * the zero padding the reference's collate gives the mel. */
 int lidk_logmel(const float* wav, const float* window, const float* twiddle, const float* melfb, float* out,
                 float* utt_max, int B, int L, int pad, int hop, int n_mels, const int32_t* spans, int mask_times,
-                float top_db, const int32_t* n_samples, void* stream);
+                float top_db, const int32_t* n_samples, const int32_t* mel_rng, const float* mel_coef, void* stream);
 /* The same from the RAW waveform: normalize_wav, dither and pre-emphasis (lid/audio_processor.py:108-134) are applied in the
- * STFT's frame load from per-utterance partial sums, so the prepared waveforms never exist in memory: three launches
- * (statistics, STFT/mel/dB, floor + masks).  stats: scratch of B * 16 doubles.  noise [B][L] (may be NULL): explicit dither
+ * STFT's frame load from per-utterance partial sums, so the prepared waveforms never exist in memory: two launches
+ * (statistics; STFT/mel/dB with the floor + masks applied by each utterance's last workgroup).  stats: scratch of B * 16 doubles.  noise [B][L] (may be NULL): explicit dither
  * values instead of the counter-based generator (what lidk_dither_preemph takes). */
 int lidk_wav2mel(const float* wav, const float* window, const float* twiddle, const float* melfb, float* out, float* utt_max,
                  double* stats, int B, int L, int pad, int hop, int n_mels, const int32_t* spans, int mask_times, float top_db,
-                 const int32_t* n_samples, float coef, float dither, uint64_t seed, const float* noise, void* stream);
+                 const int32_t* n_samples, float coef, float dither, uint64_t seed, const float* noise, const int32_t* mel_rng, const float* mel_coef, void* stream);
 
 /* ------------------------------------------------------------------ generic element-wise helpers */
 /* y = scale * x with dtype conversion (x_dtype/y_dtype in {LIDK_F32, LIDK_BF16}). */

@@ -39,8 +39,8 @@ SIGNATURES = {
     "lidk_normalize_wav": (_I, [_P, _P, _I, _I, _P, _P]),
     "lidk_dither_preemph": (_I, [_P, _P, _P, _I, _I, _F, _F, _U64, _P]),
     "lidk_speed_perturb": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
-    "lidk_logmel": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P, _P]),
-    "lidk_wav2mel": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P, _F, _F, _U64, _P, _P]),
+    "lidk_logmel": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P, _P, _P, _P]),
+    "lidk_wav2mel": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P, _F, _F, _U64, _P, _P, _P, _P]),
     "lidk_scale_cast": (_I, [_P, _I, _P, _I, _L, _F, _P]),
     "lidk_scale_cast_2d": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _F, _P]),
     "lidk_dropout": (_I, [_P, _I, _P, _I, _P, _P, _L, _F, _U64, _P]),

@@ -57,7 +57,23 @@ def fft_tables(device, win_length=400, n_mels=80):
         win[left:left + win_length] = torch.hann_window(win_length)
         k = torch.arange(256, dtype=torch.float64) * (2.0 * math.pi / 512.0)
         tw = torch.stack([torch.cos(k), torch.sin(k)], dim=1).float()
-        _TABLES[key] = (win.to(device), tw.contiguous().to(device), melscale_fbanks(n_mels).contiguous().to(device))
+        fb = melscale_fbanks(n_mels).contiguous()
+        # compact form of the (triangular, hence banded) filterbank: first / last non-zero bin of every filter and its taps
+        rng, coef = torch.zeros(2, 128, dtype=torch.int32), torch.zeros(128, 32)
+        rng[0].fill_(257)
+        rng[1].fill_(-1)
+        compact = n_mels <= 128
+        for m in range(min(n_mels, 128)):
+            nz = torch.nonzero(fb[:, m]).flatten()
+            if nz.numel():
+                lo, hi = int(nz[0]), int(nz[-1])
+                rng[0, m], rng[1, m] = lo, hi
+                if hi - lo < 32:
+                    coef[m, :hi - lo + 1] = fb[lo:hi + 1, m]
+                else:
+                    compact = False
+        _TABLES[key] = (win.to(device), tw.contiguous().to(device), fb.to(device),
+                        rng.contiguous().to(device) if compact else None, coef.contiguous().to(device) if compact else None)
     return _TABLES[key]
 
 
@@ -149,12 +165,12 @@ def logmel(wav, pad=0, hop=160, win_length=400, n_mels=80, spans=None, top_db=80
     (int32 (B, mask_times, 4)).  n_samples: optional int32 (B,) true lengths; rows behind an utterance's own frames are 0."""
     B, Lw = wav.shape
     F_ = 1 + (Lw + 2 * pad) // hop
-    win, tw, fb = fft_tables(wav.device, win_length, n_mels)
+    win, tw, fb, mrng, mcoef = fft_tables(wav.device, win_length, n_mels)
     out = torch.empty(B, F_, n_mels, device=wav.device, dtype=torch.float32) if out is None else out
-    umax = torch.empty(B, device=wav.device, dtype=torch.float32)
+    umax = torch.empty(2 * B, device=wav.device, dtype=torch.float32)      # dB maxima + one int ticket per utterance
     mt = 0 if spans is None else spans.shape[1]
     check(lib().lidk_logmel(_p(wav), _p(win), _p(tw), _p(fb), _p(out), _p(umax), B, Lw, pad, hop, n_mels, _p(spans), mt,
-                            top_db, _p(n_samples), _stream()), "logmel")
+                            top_db, _p(n_samples), _p(mrng), _p(mcoef), _stream()), "logmel")
     return out
 
 
@@ -164,13 +180,13 @@ def wav2mel(wav, pad=0, hop=160, win_length=400, n_mels=80, spans=None, top_db=8
     waveform preparation happens in the STFT's frame load)."""
     B, Lw = wav.shape
     F_ = 1 + (Lw + 2 * pad) // hop
-    win, tw, fb = fft_tables(wav.device, win_length, n_mels)
+    win, tw, fb, mrng, mcoef = fft_tables(wav.device, win_length, n_mels)
     out = torch.empty(B, F_, n_mels, device=wav.device, dtype=torch.float32) if out is None else out
-    umax = torch.empty(B, device=wav.device, dtype=torch.float32)
+    umax = torch.empty(2 * B, device=wav.device, dtype=torch.float32)      # dB maxima + one int ticket per utterance
     stats = torch.empty(B * 16, device=wav.device, dtype=torch.float64)
     mt = 0 if spans is None else spans.shape[1]
     check(lib().lidk_wav2mel(_p(wav), _p(win), _p(tw), _p(fb), _p(out), _p(umax), _p(stats), B, Lw, pad, hop, n_mels, _p(spans), mt,
-                             top_db, _p(n_samples), coef, dither, seed, _p(noise), _stream()), "wav2mel")
+                             top_db, _p(n_samples), coef, dither, seed, _p(noise), _p(mrng), _p(mcoef), _stream()), "wav2mel")
     return out
 
 
