@@ -169,6 +169,14 @@ int lidk_ln_gemm_nt(const lidk_gemm_args* args, const float* x, int ldx, const f
  * float atomics.  This is the autograd of every nn.Linear / 1x1 Conv1d weight on the path (dW = dY^T . X). */
 int lidk_gemm_tn(const void* X, int ldx, const void* Y, int ldy, float* C, int ldc, float* colsum, int M, int N1, int N2,
                  float alpha, int splitk, int dtype, void* stream);
+/* The same for SEVERAL weight gradients in ONE launch (bf16 operands): descs = n_desc device records of
+ * lidk_gemm_tn_desc_bytes() bytes each: { const void* X; const void* Y; float* C; float* colsum; int ldx, ldy, ldc, M, N1, N2,
+ * mchunk (rows per item, a multiple of 64), item0 (first item of the record), nsplit (= ceil(M / mchunk)), pad; float alpha;
+ * int pad }.  Item i of a record = (row chunk, tile row, tile column) of its 64x64-tile decomposition; total_items = the sum
+ * of tiles * nsplit; full != 0: every record has M, N1, N2 multiples of 64.  A ConformerBlock's eight Linear / 1x1-conv weight
+ * gradients are one such launch (ccml/trainer.py:531 loss.backward() is where the reference forms them). */
+int lidk_gemm_tn_desc_bytes(void);
+int lidk_gemm_tn_grouped(const void* descs, int n_desc, int total_items, int full, void* stream);
 
 /* ------------------------------------------------------------------ Attention core with Shaw relative positions (lid/conformer.py:117-148)
  * qkv [B*T][3*heads*dh] (T): q | k | v column blocks, head h at columns h*dh.. within each.  rel_emb [2*max_pos+1][dh] f32.
@@ -344,6 +352,20 @@ int lidk_wavlm_attn_fwd_probs(const void* qkv, const float* gate, const float* r
  * lid/wavlm/modules.py:505-560 on the MFMA path. */
 int lidk_wavlm_attn_bias_grads(const void* ds, const float* gate, const float* rb, float* dgate, float* drb, int B, int T, int H,
                                int RB, int ldp, void* stream);
+
+/* ------------------------------------------------------------------ backward of the conv feature extractor
+ * (lid/wavlm/WavLM.py:409-531, un-frozen by lid/WavLMMutiLangModel.py:86-94).  Layers 1-6 are the forward's strided-view GEMMs
+ * run backwards (lidk_gemm_tn / lidk_gemm_nt) plus these layout kernels; layer 0 is recomputed from the waveform.
+ *   conv_dlast : dpre [B*P][C] bf16 = dsrc [B*T][C] f32 * gelu'(pre) for t < T, zero in the pitch padding rows
+ *   conv_col2im: dprev [B*2P][C] bf16, row (b, t < Tprev) = (window terms of dcol [B*P][kW*C] bf16 that touch input row t:
+ *                k2 s2 one term, k3 s2 two on even rows) * gelu'(pre [B*2P][C]) (pre NULL: no factor), zero for t >= Tprev
+ *   conv0_bwd  : dy0 [B*P0][C] bf16 at layer 0's output, stats [B][C][2] (mean, rstd) from lidk_wavlm_conv0's workspace
+ *                (offset B*ceil(T0/128)*C*2 floats); dw [C][10], dgamma [C], dbeta [C] ACCUMULATED; sums: scratch B*C*2 floats. */
+int lidk_wavlm_conv_dlast(const float* dsrc, const void* pre, void* dpre, int B, int T, int P, int C, void* stream);
+int lidk_wavlm_conv_col2im(const void* dcol, const void* pre, void* dprev, int B, int P, int T, int Tprev, int kW, int C,
+                           void* stream);
+int lidk_wavlm_conv0_bwd(const float* wav, int B, int L, const float* w, const float* gamma, const float* beta, const float* stats,
+                         const void* dy0, float* sums, float* dw, float* dgamma, float* dbeta, int T0, int P0, int C, void* stream);
 
 /* ------------------------------------------------------------------ wav2vec2 pieces
  * lidk_zero_padded_rows: x [B][T][C] f32, rows t >= klen[b] become zero - TransformerEncoder.extract_features zeroes padded frames

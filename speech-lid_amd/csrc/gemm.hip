@@ -782,10 +782,12 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
 // =====================================================================================================================
 #define BKM 64
 
+// One output tile over one row chunk: tile = (bz, by, bx) of a (t1 x t2 tiles) x (row chunks of mchunk) decomposition.
+// ATOMIC: partial tiles of several row chunks meet in C through float atomics; otherwise the tile is the only writer (C += ...).
 template <int BN1, int BN2, bool FULL>    // FULL: N1 % BN1 == 0, N2 % BN2 == 0, every row tile complete -> unpredicated loads
-__global__ void __launch_bounds__(256)
-gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict__ Y, int ldy, float* __restrict__ C, int ldc,
-                    float* __restrict__ colsum, int M, int N1, int N2, int mchunk, float alpha) {
+__device__ __forceinline__ void
+gemm_tn_tile(const bf16* __restrict__ X, int ldx, const bf16* __restrict__ Y, int ldy, float* __restrict__ C, int ldc,
+             float* __restrict__ colsum, int M, int N1, int N2, int mchunk, float alpha, int tile, bool atomic) {
   constexpr int LDX = BN1 + 8, LDY = BN2 + 8, TM = BN1 / 32, TN = BN2 / 32, WM = BN1 / 2, WN = BN2 / 2, CST = WN + 4;
   constexpr int CX = BKM * BN1 / 8 / 256, CY = BKM * BN2 / 8 / 256, PX = BN1 / 8, PY = BN2 / 8;
   constexpr int AB_BYTES = BKM * (LDX + LDY) * 2, C_BYTES = 4 * WM * CST * 4, R_BYTES = 256 * 8 * 4;
@@ -794,9 +796,7 @@ gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict_
   bf16* Xs = reinterpret_cast<bf16*>(smem);
   bf16* Ys = Xs + BKM * LDX;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1, fr = lane & 15, fq = lane >> 4;
-  // 1-D launch, XCD-aware: all tiles of one row chunk (they share its X and Y rows) run on the same XCD back to back
   const int t1 = (N1 + BN1 - 1) / BN1, t2 = (N2 + BN2 - 1) / BN2;
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int bz = tile / (t1 * t2), by = (tile / t2) % t1, bx = tile % t2;
   const int n1_0 = by * BN1, n2_0 = bx * BN2;
   const int mbeg = bz * mchunk, mend = min(M, mbeg + mchunk);
@@ -896,7 +896,10 @@ gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict_
       const int c8 = tid >> 3, q = tid & 7;
       float t = 0.f;
       for (int u = c8; u < 256; u += PX) t += red[u * 8 + q];
-      if (n1_0 + tid < N1) atomicAdd(&colsum[n1_0 + tid], t * alpha);
+      if (n1_0 + tid < N1) {
+        if (atomic) atomicAdd(&colsum[n1_0 + tid], t * alpha);
+        else colsum[n1_0 + tid] += t * alpha;
+      }
     }
     __syncthreads();
   }
@@ -911,8 +914,53 @@ gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict_
   constexpr int RPA = 64 / WN;
   for (int row = lane / WN; row < WM; row += RPA) {
     const int col = lane % WN, n1 = n1_0 + wm * WM + row, n2 = n2_0 + wn * WN + col;
-    if (n1 < N1 && n2 < N2) atomicAdd(&C[(size_t)n1 * ldc + n2], Cw[row * CST + col] * alpha);
+    if (n1 < N1 && n2 < N2) {
+      if (atomic) atomicAdd(&C[(size_t)n1 * ldc + n2], Cw[row * CST + col] * alpha);
+      else C[(size_t)n1 * ldc + n2] += Cw[row * CST + col] * alpha;
+    }
   }
+}
+
+template <int BN1, int BN2, bool FULL>
+__global__ void __launch_bounds__(256)
+gemm_tn_bf16_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict__ Y, int ldy, float* __restrict__ C, int ldc,
+                    float* __restrict__ colsum, int M, int N1, int N2, int mchunk, float alpha) {
+  // 1-D launch, XCD-aware: all tiles of one row chunk (they share its X and Y rows) run on the same XCD back to back
+  gemm_tn_tile<BN1, BN2, FULL>(X, ldx, Y, ldy, C, ldc, colsum, M, N1, N2, mchunk, alpha, xcd_tile(blockIdx.x, gridDim.x), true);
+}
+
+// Grouped form: ONE launch for the weight gradients of a whole ConformerBlock (ff1 x 2, ff2 x 2, conv pw1 / pw2, attention out,
+// fused qkv).  Ten separate launches of ~512 short workgroups (19 row tiles each, 8-16 partial tiles meeting in atomics) kept
+// the second stream busy for ~210 us per block at a fifth of the L2 rate; here every item runs a long row chunk (M / split
+// rows, split = 4 by default), the launch holds ~1 700 items - the chip stays full from first to last wave - and a 4-way
+// atomic fan-in replaces the 8-16-way one.  descs: device array, item0 ascending.
+struct TnDesc {
+  const bf16* X; const bf16* Y; float* C; float* colsum;
+  int ldx, ldy, ldc, M, N1, N2, mchunk, item0, nsplit, pad0;
+  float alpha; int pad1;
+};
+template <bool FULL>
+__global__ void __launch_bounds__(256)
+gemm_tn_grouped_kernel(const TnDesc* __restrict__ descs, int n_desc) {
+  const int item = xcd_tile(blockIdx.x, gridDim.x);
+  int g = 0;
+  while (g + 1 < n_desc && item >= descs[g + 1].item0) ++g;
+  const TnDesc d = descs[g];
+  gemm_tn_tile<64, 64, FULL>(d.X, d.ldx, d.Y, d.ldy, d.C, d.ldc, d.colsum, d.M, d.N1, d.N2, d.mchunk, d.alpha, item - d.item0,
+                             d.nsplit > 1);
+}
+
+extern "C" int lidk_gemm_tn_desc_bytes(void) { return (int)sizeof(TnDesc); }
+
+// descs: n_desc TnDesc records on the DEVICE (layout: lidk_gemm_tn_desc_bytes(), built by the host binding); total_items =
+// sum over records of tiles(N1, 64) * tiles(N2, 64) * nsplit; full != 0 asserts that every record has N1 % 64 == N2 % 64 ==
+// M % 64 == 0 (unpredicated loads).
+extern "C" int lidk_gemm_tn_grouped(const void* descs, int n_desc, int total_items, int full, void* stream) {
+  if (!descs || n_desc <= 0 || total_items <= 0) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  if (full) gemm_tn_grouped_kernel<true><<<total_items, 256, 0, s>>>((const TnDesc*)descs, n_desc);
+  else gemm_tn_grouped_kernel<false><<<total_items, 256, 0, s>>>((const TnDesc*)descs, n_desc);
+  return launch_status();
 }
 
 // f32 (parity mode): 64x64 tile, 16 rows of m per step, 4x4 outputs per thread; tiles are used as stored.

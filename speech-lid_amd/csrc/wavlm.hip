@@ -776,3 +776,180 @@ extern "C" int lidk_hidden_mix_wgrad(const float* w, const float* dots, float* d
   hidden_mix_wgrad_kernel<<<1, HM_MAX, 0, as_stream(stream)>>>(w, dots, dw, n_states);
   return launch_status();
 }
+
+// =====================================================================================================================
+// Backward of the convolutional feature extractor (lid/wavlm/WavLM.py:409-531; un-frozen by
+// lid/WavLMMutiLangModel.py:86-94 after freeze_encoder_epoch).  Layers 1-6 mirror the forward's strided-view GEMMs:
+//   dpre_l = dY_l * gelu'(pre_l)            (pre_l kept by the forward's GELU epilogue, bf16)
+//   dW_l  += dpre_l^T . A_l                 TN GEMM on the SAME strided view of layer l-1's output (lidk_gemm_tn, ldy < N2)
+//   dcol_l = dpre_l . W_l                   NT GEMM: [rows][kW*C], the gradient of every window position
+//   dY_{l-1}[2u + kk] = sum over windows    col2im below (k2 s2: windows do not overlap, k3 s2: rows 2u get two terms)
+// and layer 0 (k10 s5 on the raw waveform + per-channel GroupNorm over time + GELU) is recomputed from the waveform as in the
+// forward: one pass for the GroupNorm backward sums, one for dW0.
+// =====================================================================================================================
+// dprev [B*Pprev][C] bf16, Pprev = 2 * P: row (b, t) = (sum of the window terms of dcol that touch input row t) * gelu'(pre[b][t])
+// for t < Tprev, zero behind (pitch padding rows must carry no gradient).  pre == NULL: no activation factor (layer 0's output:
+// its GELU is handled with the GroupNorm in lidk_wavlm_conv0_bwd).  dcol [B*P][kW*C] bf16.
+__global__ void wavlm_conv_col2im_kernel(const bf16* __restrict__ dcol, const bf16* __restrict__ pre, bf16* __restrict__ dprev,
+                                         int B, int P, int T_, int Tprev, int kW, int C) {
+  const int Pprev = 2 * P;
+  const long n8 = (long)B * Pprev * C / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 8;
+    const int c = (int)(e % C);
+    const long row = e / C;
+    const int b = (int)(row / Pprev), t = (int)(row % Pprev);
+    f32x8_t v;
+    v.lo = make_float4(0.f, 0.f, 0.f, 0.f); v.hi = v.lo;
+    if (t < Tprev) {
+      const int u = t >> 1, kk = t & 1;
+      if (u < T_) v = load8(dcol + ((size_t)b * P + u) * kW * C + (size_t)kk * C + c);
+      if (kW == 3 && kk == 0 && u >= 1 && u - 1 < T_) {
+        const f32x8_t w = load8(dcol + ((size_t)b * P + u - 1) * kW * C + (size_t)2 * C + c);
+        v.lo.x += w.lo.x; v.lo.y += w.lo.y; v.lo.z += w.lo.z; v.lo.w += w.lo.w;
+        v.hi.x += w.hi.x; v.hi.y += w.hi.y; v.hi.z += w.hi.z; v.hi.w += w.hi.w;
+      }
+      if (pre) {
+        const f32x8_t p = load8(pre + (size_t)row * C + c);
+        v.lo.x *= gelu_grad_(p.lo.x); v.lo.y *= gelu_grad_(p.lo.y); v.lo.z *= gelu_grad_(p.lo.z); v.lo.w *= gelu_grad_(p.lo.w);
+        v.hi.x *= gelu_grad_(p.hi.x); v.hi.y *= gelu_grad_(p.hi.y); v.hi.z *= gelu_grad_(p.hi.z); v.hi.w *= gelu_grad_(p.hi.w);
+      }
+    }
+    store8(dprev + e, v);
+  }
+}
+extern "C" int lidk_wavlm_conv_col2im(const void* dcol, const void* pre, void* dprev, int B, int P, int T_, int Tprev, int kW,
+                                      int C, void* stream) {
+  if (!dcol || !dprev || B <= 0 || P <= 0 || T_ <= 0 || T_ > P || Tprev <= 0 || Tprev > 2 * P || (kW != 2 && kW != 3) || C <= 0 || (C & 7))
+    return LIDK_ERR_ARG;
+  const long n8 = (long)B * 2 * P * C / 8;
+  int blocks = (int)((n8 + 255) / 256); if (blocks > 16384) blocks = 16384;
+  wavlm_conv_col2im_kernel<<<blocks, 256, 0, as_stream(stream)>>>((const bf16*)dcol, (const bf16*)pre, (bf16*)dprev, B, P, T_, Tprev, kW, C);
+  return launch_status();
+}
+
+// dsrc [B*T][C] f32 (gradient at the extractor's output, channel-last without pitch) -> dpre [B*P][C] bf16 =
+// dsrc * gelu'(pre) for t < T, zero in the pitch padding rows: the last conv layer's operand.
+__global__ void wavlm_conv_dlast_kernel(const float* __restrict__ dsrc, const bf16* __restrict__ pre, bf16* __restrict__ dpre, int B,
+                                        int T_, int P, int C) {
+  const long n = (long)B * P * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long row = i / C;
+    const int b = (int)(row / P), t = (int)(row % P);
+    float v = 0.f;
+    if (t < T_) v = dsrc[((size_t)b * T_ + t) * C + c] * gelu_grad_((float)pre[i]);
+    dpre[i] = (bf16)v;
+  }
+}
+extern "C" int lidk_wavlm_conv_dlast(const float* dsrc, const void* pre, void* dpre, int B, int T_, int P, int C, void* stream) {
+  if (!dsrc || !pre || !dpre || B <= 0 || T_ <= 0 || P < T_ || C <= 0) return LIDK_ERR_ARG;
+  const long n = (long)B * P * C;
+  int blocks = (int)((n + 255) / 256); if (blocks > 16384) blocks = 16384;
+  wavlm_conv_dlast_kernel<<<blocks, 256, 0, as_stream(stream)>>>(dsrc, (const bf16*)pre, (bf16*)dpre, B, T_, P, C);
+  return launch_status();
+}
+
+// Layer 0 backward.  dy0 [B*P0][C] bf16 = gradient at the layer's (post-GELU) output.  stats [B][C][2] = (mean, rstd) of the
+// forward (lidk_wavlm_conv0's workspace tail).  Pass 1: per (utterance, channel) S1 = sum_t dz, S2 = sum_t dz * yhat with
+// z = yhat * gamma + beta, dz = dy0 * gelu'(z); pass 2: dy = rstd * gamma * (dz - S1/T - yhat * S2/T) and
+// dW0[c][k] += sum_t dy * wav[5 t + k]; dgamma[c] += S2, dbeta[c] += S1.  (lid/wavlm/WavLM.py:433-470: conv, GroupNorm, GELU.)
+#define W0B_T 1024       // time steps per workgroup in the backward passes
+__global__ void __launch_bounds__(256)
+wavlm_conv0_bwd_sums_kernel(const float* __restrict__ wav, int L, const float* __restrict__ w, const float* __restrict__ stats,
+                            const float* __restrict__ gamma, const float* __restrict__ beta, const bf16* __restrict__ dy0,
+                            float* __restrict__ sums, int T0, int P0, int C) {
+  __shared__ float xs[W0_TC * W0_S + W0_K];
+  const int b = blockIdx.y, tb = blockIdx.x * W0B_T;
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  float wk[2][W0_K];
+  for (int q = 0; q < 2; ++q) {
+    const int c = threadIdx.x + 256 * q;
+    for (int k = 0; k < W0_K; ++k) wk[q][k] = c < C ? w[c * W0_K + k] : 0.f;
+  }
+  for (int t0 = tb; t0 < min(T0, tb + W0B_T); t0 += W0_TC) {
+    const int nt = min(W0_TC, T0 - t0);
+    __syncthreads();
+    const float* x = wav + (size_t)b * L + (size_t)t0 * W0_S;
+    for (int i = threadIdx.x; i < nt * W0_S + W0_K - W0_S; i += 256) xs[i] = x[i];
+    __syncthreads();
+    for (int q = 0; q < 2; ++q) {
+      const int c = threadIdx.x + 256 * q;
+      if (c >= C) continue;
+      const float mu = stats[((size_t)b * C + c) * 2], rs = stats[((size_t)b * C + c) * 2 + 1], g = gamma[c], be = beta[c];
+      for (int t = 0; t < nt; ++t) {
+        float y = 0.f;
+#pragma unroll
+        for (int k = 0; k < W0_K; ++k) y = fmaf(wk[q][k], xs[t * W0_S + k], y);
+        const float yh = (y - mu) * rs;
+        const float dz = (float)dy0[((size_t)b * P0 + t0 + t) * C + c] * gelu_grad_(yh * g + be);
+        s1[q] += dz; s2[q] = fmaf(dz, yh, s2[q]);
+      }
+    }
+  }
+  for (int q = 0; q < 2; ++q) {
+    const int c = threadIdx.x + 256 * q;
+    if (c < C) { atomicAdd(&sums[((size_t)b * C + c) * 2], s1[q]); atomicAdd(&sums[((size_t)b * C + c) * 2 + 1], s2[q]); }
+  }
+}
+__global__ void __launch_bounds__(256)
+wavlm_conv0_bwd_apply_kernel(const float* __restrict__ wav, int L, const float* __restrict__ w, const float* __restrict__ stats,
+                             const float* __restrict__ gamma, const float* __restrict__ beta, const bf16* __restrict__ dy0,
+                             const float* __restrict__ sums, float* __restrict__ dw, float* __restrict__ dgamma,
+                             float* __restrict__ dbeta, int T0, int P0, int C) {
+  __shared__ float xs[W0_TC * W0_S + W0_K];
+  const int b = blockIdx.y, tb = blockIdx.x * W0B_T;
+  float acc[2][W0_K], wk[2][W0_K];
+  for (int q = 0; q < 2; ++q) {
+    const int c = threadIdx.x + 256 * q;
+    for (int k = 0; k < W0_K; ++k) { wk[q][k] = c < C ? w[c * W0_K + k] : 0.f; acc[q][k] = 0.f; }
+  }
+  const float invT = 1.0f / (float)T0;
+  for (int t0 = tb; t0 < min(T0, tb + W0B_T); t0 += W0_TC) {
+    const int nt = min(W0_TC, T0 - t0);
+    __syncthreads();
+    const float* x = wav + (size_t)b * L + (size_t)t0 * W0_S;
+    for (int i = threadIdx.x; i < nt * W0_S + W0_K - W0_S; i += 256) xs[i] = x[i];
+    __syncthreads();
+    for (int q = 0; q < 2; ++q) {
+      const int c = threadIdx.x + 256 * q;
+      if (c >= C) continue;
+      const float mu = stats[((size_t)b * C + c) * 2], rs = stats[((size_t)b * C + c) * 2 + 1], g = gamma[c], be = beta[c];
+      const float m1 = sums[((size_t)b * C + c) * 2] * invT, m2 = sums[((size_t)b * C + c) * 2 + 1] * invT;
+      for (int t = 0; t < nt; ++t) {
+        float y = 0.f;
+#pragma unroll
+        for (int k = 0; k < W0_K; ++k) y = fmaf(wk[q][k], xs[t * W0_S + k], y);
+        const float yh = (y - mu) * rs;
+        const float dz = (float)dy0[((size_t)b * P0 + t0 + t) * C + c] * gelu_grad_(yh * g + be);
+        const float dy = rs * g * (dz - m1 - yh * m2);
+#pragma unroll
+        for (int k = 0; k < W0_K; ++k) acc[q][k] = fmaf(dy, xs[t * W0_S + k], acc[q][k]);
+      }
+    }
+  }
+  for (int q = 0; q < 2; ++q) {
+    const int c = threadIdx.x + 256 * q;
+    if (c >= C) continue;
+    for (int k = 0; k < W0_K; ++k) atomicAdd(&dw[c * W0_K + k], acc[q][k]);
+    if (blockIdx.x == 0) {                               // one workgroup per utterance adds the affine parameters' share
+      atomicAdd(&dgamma[c], sums[((size_t)b * C + c) * 2 + 1]);
+      atomicAdd(&dbeta[c], sums[((size_t)b * C + c) * 2]);
+    }
+  }
+}
+// sums: scratch [B][C][2] f32 (zeroed here).  dw [C][10], dgamma [C], dbeta [C] are ACCUMULATED.  C <= 512.
+extern "C" int lidk_wavlm_conv0_bwd(const float* wav, int B, int L, const float* w, const float* gamma, const float* beta,
+                                    const float* stats, const void* dy0, float* sums, float* dw, float* dgamma, float* dbeta,
+                                    int T0, int P0, int C, void* stream) {
+  if (!wav || !w || !gamma || !beta || !stats || !dy0 || !sums || !dw || !dgamma || !dbeta || B <= 0 || C <= 0 || C > 512 || T0 <= 0 ||
+      P0 < T0)
+    return LIDK_ERR_ARG;
+  if ((long)(T0 - 1) * W0_S + W0_K > L) return LIDK_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  if (hipMemsetAsync(sums, 0, (size_t)B * C * 2 * sizeof(float), s) != hipSuccess) return LIDK_ERR_LAUNCH;
+  const dim3 grid(cdiv(T0, W0B_T), B);
+  wavlm_conv0_bwd_sums_kernel<<<grid, 256, 0, s>>>(wav, L, w, stats, gamma, beta, (const bf16*)dy0, sums, T0, P0, C);
+  wavlm_conv0_bwd_apply_kernel<<<grid, 256, 0, s>>>(wav, L, w, stats, gamma, beta, (const bf16*)dy0, sums, dw, dgamma, dbeta, T0, P0, C);
+  return launch_status();
+}

@@ -14,9 +14,9 @@ What runs: the backbone on hand-written HIP (lidk/wavlm.py) without autograd, th
 lid/LidModule_ASR.py:243-258) and in inference the backbone forward is two captured graphs.  After
 ``unfreeze_tranformer_encoder()`` the transformer encoder (pos-conv, encoder LayerNorm, every layer, the relative-position
 bucket embedding) trains too: the forward keeps each layer's activations, the Engine hands back d(loss)/d(features) and
-``WavLMBackbone.backward`` produces the encoder gradients, published as the ``.grad`` of the reference-named Parameters.  The
-convolutional feature extractor + post_extract_proj stay frozen (``unfreeze_feature_extractor`` raises): the reference's
-default schedule never reaches it (freeze_encoder_epoch = 100 >= total_epoch, lid/LidModule_ASR.py:26).
+``WavLMBackbone.backward`` produces the encoder gradients, published as the ``.grad`` of the reference-named Parameters.
+``unfreeze_feature_extractor()`` (the reference reaches it after ``freeze_encoder_epoch`` = 100, lid/LidModule_ASR.py:26) adds
+the convolutional feature extractor and post_extract_proj: the conv stack's backward mirrors its strided-view GEMMs.
 """
 import logging
 from typing import Dict, List, Optional
@@ -152,7 +152,7 @@ class WavLMMutiLangModel(_EngineBoundModel):
         with torch.no_grad():
             feats = self.backbone.forward(wav.contiguous(), mask=self.training, n_samples=n_samples, mix_w=mix_w,
                                           train=grad_path and (self.train_input_norm or not self._backbone_frozen["encoder"]
-                                                               or mix_w is not None))
+                                                               or not self._backbone_frozen["extractor"] or mix_w is not None))
         eng = self.lidk_engine
         if grad_path:
             if self._anchor is None or self._anchor.device != feats.device:
@@ -175,6 +175,9 @@ class WavLMMutiLangModel(_EngineBoundModel):
     # ------------------------------------------------------------------ reference helper surface
     def freeze_feature_extractor(self):
         self._backbone_frozen["extractor"] = True
+        self.backbone.train_extractor = False
+        for p in self._extractor_parameters().values():
+            p.requires_grad = False
 
     def _encoder_parameters(self):
         params = dict(self.named_parameters())
@@ -185,10 +188,18 @@ class WavLMMutiLangModel(_EngineBoundModel):
         for p in self._encoder_parameters().values():
             p.requires_grad = False
 
+    def _extractor_parameters(self):
+        params = dict(self.named_parameters())
+        return {n: params[self.BB_PREFIX + n] for n in self._bb_names if n.startswith(WavLMBackbone.EXTRACTOR_PREFIXES)
+                and n in WavLMBackbone.param_shapes(self.backbone.cfg)}
+
     def unfreeze_feature_extractor(self):
-        raise NotImplementedError(
-            "un-freezing the WavLM convolutional feature extractor needs its backward pass, which is not built (SURVEY 8f N1): "
-            "keep freeze_encoder_epoch at or above trainer.total_epoch (the reference's default, 100)")
+        """lid/WavLMMutiLangModel.py:86-94: the conv feature extractor and post_extract_proj take gradients from now on (the
+        reference reaches this after ``freeze_encoder_epoch``); the forward then keeps the conv stack's pre-activations."""
+        self._backbone_frozen["extractor"] = False
+        self.backbone.train_extractor = True
+        for p in self._extractor_parameters().values():
+            p.requires_grad = True
 
     def unfreeze_tranformer_encoder(self):
         """lid/WavLMMutiLangModel.py:106-112: the transformer encoder's parameters take gradients from now on."""
@@ -200,7 +211,7 @@ class WavLMMutiLangModel(_EngineBoundModel):
         """Called by the autograd node after the heads' backward: encoder gradients from d(loss)/d(features)."""
         frozen = self._backbone_frozen["encoder"]
         mix_w = self._mix_w()
-        if frozen and not self.train_input_norm and mix_w is None:
+        if frozen and not self.train_input_norm and mix_w is None and self._backbone_frozen["extractor"]:
             return
         bb = self.backbone
         params = dict(self.named_parameters())
@@ -222,7 +233,8 @@ class WavLMMutiLangModel(_EngineBoundModel):
                 self._mix_grad.zero_()
             mix_dw = self._mix_grad if mp.requires_grad else None
         bb.backward(dfeat, *self._bb_shape, wgrads=not frozen, mix_w=mix_w, mix_dw=mix_dw,
-                    data_grads=not (frozen and not self.train_input_norm))
+                    data_grads=not (frozen and not self.train_input_norm) or not self._backbone_frozen["extractor"],
+                    extractor=not self._backbone_frozen["extractor"])
         if mix_dw is not None:
             params[self.MIX_NAME].grad = self._mix_grad
         for n, p in live.items():

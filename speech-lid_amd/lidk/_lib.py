@@ -58,6 +58,8 @@ SIGNATURES = {
     "lidk_ln_gemm_supported": (_I, [_I, _I, _I, _I]),
     "lidk_ln_gemm_nt": (_I, [_P, _P, _I, _P, _P, _F, _P, _P, _P, _I, _P]),
     "lidk_gemm_tn": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _I, _I, _P]),
+    "lidk_gemm_tn_desc_bytes": (_I, []),
+    "lidk_gemm_tn_grouped": (_I, [_P, _I, _I, _I, _P]),
     "lidk_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_attn_bwd_relpos_supported": (_I, [_I, _I, _I]),
     "lidk_attn_bwd_relpos": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -101,6 +103,9 @@ SIGNATURES = {
     "lidk_wavlm_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lidk_wavlm_attn_fwd_probs": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "lidk_wavlm_attn_bias_grads": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lidk_wavlm_conv_dlast": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "lidk_wavlm_conv_col2im": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lidk_wavlm_conv0_bwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_zero_padded_rows": (_I, [_P, _P, _I, _I, _I, _P]),
     "lidk_hidden_mix_axpy": (_I, [_P, _P, _I, _I, _P, _L, _I, _P]),
     "lidk_hidden_mix_dot": (_I, [_P, _P, _P, _L, _P]),

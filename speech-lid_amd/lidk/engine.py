@@ -238,6 +238,7 @@ class _Work:
 
 
 _WGRAD_WGS = int(__import__("os").environ.get("LIDK_WGRAD_WGS", "512"))      # workgroups a weight-gradient launch aims for (tuning knob)
+_WGRAD_SPLIT = int(__import__("os").environ.get("LIDK_WGRAD_SPLIT", "4"))     # row chunks per weight gradient in the grouped launch
 
 
 class Engine:
@@ -818,20 +819,37 @@ class Engine:
         ci, K = C["dw"].shape[0], C["dw"].shape[2]
         inner = bp.heads * bp.dh
         t0, t1, t2, t3 = S.dyTs
+        dy1 = S.dy1.view(-1)[:M * 2 * ci].view(M, 2 * ci)
+        dqkv = S.dqkv.view(-1)[:M * 3 * inner].view(M, 3 * inner)
+        sites = []                                   # (dY, activation, dW, db, n, k): dW [n, k] += dY^T @ activation
         for P, dyT, da_buf, h, u in ((bp.ff2, t0, S.da[0], bb.h4, bb.u4), (bp.ff1, t3, S.da[1], bb.h1, bb.u1)):
             ff = u.shape[1]
             da = da_buf if da_buf.shape[1] == ff else da_buf.view(-1)[:M * ff].view(M, ff)
-            self._wgrad(w, dyT, u, P["dw2"], d, ff, P["db2"])
-            self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
-        self._wgrad(w, t1, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
+            sites += [(dyT, u, P["dw2"], P["db2"], d, ff), (da, h, P["dw1"], P["db1"], ff, d)]
+        sites += [(t1, bb.s, C["dw2"].view(d, ci), C["db2"], d, ci), (dy1, bb.h3, C["dw1"].view(2 * ci, d), C["db1"], 2 * ci, d),
+                  (t2, bb.o, A["dwo"], A["dbo"], d, inner), (dqkv, bb.h2, A["dwqkv"], None, 3 * inner, d)]
+        if self._grouped_wgrads():
+            # ONE launch for the block's eight Linear / 1x1-conv weight gradients (csrc/gemm.hip gemm_tn_grouped_kernel); the
+            # descriptor table holds raw pointers into this workspace and the arenas, so it lives and dies with the workspace
+            cache = w.__dict__.setdefault("_tn_groups", {})
+            key = (id(bp), id(bb), id(S))
+            grp = cache.get(key)
+            if grp is None:
+                grp = cache[key] = self.k.build_tn_group([(dy, x, dW, db, M, n, k) for dy, x, dW, db, n, k in sites],
+                                                         split=_WGRAD_SPLIT)
+            self.k.gemm_tn_grouped(grp)
+        else:
+            for dy, x, dW, db, n, k in sites:
+                self._wgrad(w, dy, x, dW, n, k, db)
         self._conv_wgrad(w, bp, bb, S)
-        dy1 = S.dy1.view(-1)[:M * 2 * ci].view(M, 2 * ci)
-        self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
-        self._wgrad(w, t2, bb.o, A["dwo"], d, inner, A["dbo"])
-        dqkv = S.dqkv.view(-1)[:M * 3 * inner].view(M, 3 * inner)
-        self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
         if self._relpos_split(T, bp.dh):
             self.k.attn_bwd_relpos(bb.qkv, S.dsc, bb.probs.shape[-1], A["demb"], B, T, bp.heads, bp.dh)
+
+    def _grouped_wgrads(self) -> bool:
+        """The block's weight-gradient GEMMs as one grouped launch (bf16 operands, HIP backend; LIDK_WGRAD_GROUPED=0 restores the
+        eight separate launches)."""
+        return bool(self._hip and self.act_dtype == torch.bfloat16 and hasattr(self.k, "gemm_tn_grouped")
+                    and _os_env("LIDK_WGRAD_GROUPED", "1") == "1")
 
     def _relpos_split(self, T: int, dh: int) -> bool:
         key = (T, dh)

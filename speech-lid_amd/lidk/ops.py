@@ -335,6 +335,42 @@ def gemm_tn(X, Y, C, colsum=None, alpha=1.0, splitk=1, M=None, N1=None, N2=None)
 
 
 # ----------------------------------------------------------------------------------------------- attention
+class _TnDesc(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("Y", C.c_void_p), ("C", C.c_void_p), ("colsum", C.c_void_p),
+                ("ldx", C.c_int), ("ldy", C.c_int), ("ldc", C.c_int), ("M", C.c_int), ("N1", C.c_int), ("N2", C.c_int),
+                ("mchunk", C.c_int), ("item0", C.c_int), ("nsplit", C.c_int), ("pad0", C.c_int), ("alpha", C.c_float), ("pad1", C.c_int)]
+
+
+def build_tn_group(entries, split=4):
+    """Descriptor table of a grouped weight-gradient launch.  entries: list of (X (M, N1) bf16, Y (M, N2) bf16, C (N1, N2) f32,
+    colsum (N1,) f32 or None, M, N1, N2): C += X[:M, :N1]^T @ Y[:M, :N2].  -> (device uint8 tensor, n, total_items, full); the
+    table holds raw pointers: rebuild it when any buffer is reallocated."""
+    if lib().lidk_gemm_tn_desc_bytes() != C.sizeof(_TnDesc):
+        raise LidkError("TnDesc layout mismatch between ops.py and liblidk.so")
+    arr, item, full, dev = (_TnDesc * len(entries))(), 0, True, None
+    for i, (X, Y, Cm, cs, M, N1, N2) in enumerate(entries):
+        if X.dtype != torch.bfloat16 or Y.dtype != torch.bfloat16 or Cm.dtype != torch.float32:
+            raise LidkError("build_tn_group: bf16 operands, f32 output")
+        if X.stride(-1) != 1 or Y.stride(-1) != 1 or Cm.stride(-1) != 1 or (X.stride(0) & 7) or (Y.stride(0) & 7):
+            raise LidkError("build_tn_group: unit inner strides and row pitches that are multiples of 8")
+        mchunk = -(-(-(-M // split)) // 64) * 64
+        nsplit = -(-M // mchunk)
+        d = arr[i]
+        d.X, d.Y, d.C, d.colsum = X.data_ptr(), Y.data_ptr(), Cm.data_ptr(), (cs.data_ptr() if cs is not None else None)
+        d.ldx, d.ldy, d.ldc, d.M, d.N1, d.N2 = X.stride(0), Y.stride(0), Cm.stride(0), M, N1, N2
+        d.mchunk, d.item0, d.nsplit, d.alpha = mchunk, item, nsplit, 1.0
+        item += (-(-N1 // 64)) * (-(-N2 // 64)) * nsplit
+        full = full and not (M % 64 or N1 % 64 or N2 % 64)
+        dev = X.device
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(dev), len(entries), item, full
+
+
+def gemm_tn_grouped(group):
+    table, n, items, full = group
+    check(lib().lidk_gemm_tn_grouped(_p(table), n, items, int(full), _stream()), "gemm_tn_grouped")
+
+
 def attn_ldp(T, dh, dtype):
     """Row stride of the probs buffer for this (T, dh, dtype): padded to 32 when the MFMA kernels apply."""
     return lib().lidk_attn_ldp(T, dh, dtype_code(dtype))
@@ -597,6 +633,27 @@ def wavlm_attn_bwd(qkv, probs, dout, gate, rb, dqkv, dgate, drb, dscores, B, T, 
     RB = (rb.shape[1] + 1) // 2
     check(lib().lidk_wavlm_attn_bwd(_p(qkv), _p(probs), _p(dout), _p(gate), _p(rb), _p(dqkv), _p(dgate), _p(drb), _p(dscores),
                                     B, T, H, dh, RB, _stream()), "wavlm_attn_bwd")
+
+
+def wavlm_conv_dlast(dsrc, pre, dpre, B, T, P):
+    check(lib().lidk_wavlm_conv_dlast(_p(dsrc), _p(pre), _p(dpre), B, T, P, dsrc.shape[-1], _stream()), "wavlm_conv_dlast")
+    return dpre
+
+
+def wavlm_conv_col2im(dcol, pre, dprev, B, P, T, Tprev, kW, C):
+    check(lib().lidk_wavlm_conv_col2im(_p(dcol), _p(pre), _p(dprev), B, P, T, Tprev, kW, C, _stream()), "wavlm_conv_col2im")
+    return dprev
+
+
+def wavlm_conv0_stats_offset(B, T0, C):
+    """Float offset of the (mean, rstd) block inside lidk_wavlm_conv0's workspace."""
+    return B * (-(-T0 // 128)) * C * 2
+
+
+def wavlm_conv0_bwd(wav, w, gamma, beta, stats, dy0, sums, dw, dgamma, dbeta, T0, P0):
+    B, Lw = wav.shape
+    check(lib().lidk_wavlm_conv0_bwd(_p(wav), B, Lw, _p(w), _p(gamma), _p(beta), _p(stats), _p(dy0), _p(sums), _p(dw), _p(dgamma),
+                                     _p(dbeta), T0, P0, w.shape[0], _stream()), "wavlm_conv0_bwd")
 
 
 def zero_padded_rows(x, klen, B, T):

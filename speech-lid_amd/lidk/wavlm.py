@@ -123,6 +123,7 @@ class WavLMBackbone:
                                       "(wav2vec2)")
         self.rel_pos = bool(cfg.get("relative_position_embedding", False))
         self.pad_mask = bool(cfg.get("encoder_padding_mask", False))
+        self.train_extractor = False              # un-frozen conv feature extractor: the forward keeps its pre-activations
         self.seed, self.step = 0, 0               # dropout decisions are functions of (seed, step, site, element index)
         self.forced_keep: Dict = {}               # tests: site -> uint8 keep mask (reference-captured dropout masks)
         self.d = cfg.get("encoder_embed_dim", 768)
@@ -199,6 +200,7 @@ class WavLMBackbone:
         for i in range(1, len(self.layers_spec)):
             w = g(f"{fe}{i}.0.weight")                                        # [Co][Ci][kW] -> [Co][kW*Ci], k-major
             W["conv"].append(w.permute(0, 2, 1).reshape(w.shape[0], -1).to(bf).contiguous())
+        W["convT"] = [w_.t().contiguous() for w_ in W["conv"]]                   # [kW*Ci][Co]: data gradient of the conv stack
         W["ln0_w"], W["ln0_b"] = g("layer_norm.weight"), g("layer_norm.bias")
         W["proj_w"], W["proj_b"] = g("post_extract_proj.weight").to(bf), g("post_extract_proj.bias")
         wv, wg = g("encoder.pos_conv.0.weight_v"), g("encoder.pos_conv.0.weight_g")
@@ -365,15 +367,32 @@ class WavLMBackbone:
         st["events"][i] = ev
         return dst
 
-    def _fwd_pre(self, ws, B, taps):
-        """Feature extractor, LayerNorm, post_extract_proj -> ws["x"] (B*T, d) f32."""
+    def _extractor_buffers(self, ws, B):
+        """Pre-activations of conv layers 1.. (kept by the forward while the extractor trains) and the backward's scratch."""
+        ex = ws.get("ex")
+        if ex is None:
+            dev, bf, C, P, n = self.device, torch.bfloat16, self.C, ws["P"], len(ws["P"])
+            kmax = max(kw for _, kw, _ in self.layers_spec[1:])
+            ex = ws["ex"] = dict(
+                pre=[None] + [torch.zeros(B * P[l] + 8, C, device=dev, dtype=bf) for l in range(1, n)],
+                d=[torch.zeros(B * P[l] + 8, C, device=dev, dtype=bf) for l in range(n)],
+                dcol=torch.empty(B * P[1], kmax * C, device=dev, dtype=bf),
+                sums=torch.empty(B * C * 2, device=dev),
+                gconv=[None] + [torch.zeros(C, self.layers_spec[l][1] * C, device=dev) for l in range(1, n)],
+                gconv0=torch.zeros(C, self.layers_spec[0][1], device=dev))
+        return ex
+
+    def _fwd_pre(self, ws, B, taps, keep_pre=False):
+        """Feature extractor, LayerNorm, post_extract_proj -> ws["x"] (B*T, d) f32.  keep_pre: the GELU epilogues also write
+        the pre-activations (the extractor's backward needs gelu')."""
         W, k, wav = self.W, ops, ws["wav"]
         T, P, bufs, C, d = ws["T"], ws["P"], ws["bufs"], self.C, self.d
+        ex = self._extractor_buffers(ws, B) if keep_pre else None
         k.wavlm_conv0(wav, W["conv0_w"], W["gn_w"], W["gn_b"], bufs[0], T[0], P[0], workspace=ws["c0ws"])
         for l in range(1, len(T)):
             _, kw, st = self.layers_spec[l]
             A = bufs[l - 1].as_strided((B * P[l], kw * C), (st * C, 1))          # strided view: the convolution is this GEMM
-            k.gemm_nt(A, W["conv"][l - 1], bufs[l][:B * P[l]], act=L.ACT_GELU)
+            k.gemm_nt(A, W["conv"][l - 1], bufs[l][:B * P[l]], act=L.ACT_GELU, out2=ex["pre"][l][:B * P[l]] if ex else None)
         Tn, M, Pp = ws["Tn"], ws["M"], ws["Pp"]
         last = bufs[-1][:B * P[-1]]
         k.scale_cast_2d(last.view(B, P[-1] * C), ws["xc"].view(B, Tn * C), B, Tn * C)       # drop the pitch padding rows
@@ -509,6 +528,7 @@ class WavLMBackbone:
 
     TRAINABLE_PREFIX = "encoder."
     INPUT_SIDE = ("layer_norm.weight", "layer_norm.bias", "mask_emb")      # never frozen by the reference's freeze_* helpers
+    EXTRACTOR_PREFIXES = ("feature_extractor.", "post_extract_proj.")      # what (un)freeze_feature_extractor toggles
 
     def zero_grads(self):
         if getattr(self, "grads", None):
@@ -533,7 +553,8 @@ class WavLMBackbone:
 
         fused = (".q_proj.", ".k_proj.", ".v_proj.")
         for name, t in self.params.items():
-            if (name.startswith(self.TRAINABLE_PREFIX) or name in self.INPUT_SIDE) and not any(f in name for f in fused):
+            if (name.startswith((self.TRAINABLE_PREFIX,) + self.EXTRACTOR_PREFIXES) or name in self.INPUT_SIDE) \
+                    and not any(f in name for f in fused) and name in self.param_shapes(self.cfg):
                 take(name, t.shape)
         for i in range(self.n_layers):
             take(f"qkv_w.{i}", (3 * d, d))
@@ -563,7 +584,7 @@ class WavLMBackbone:
         ops.gemm_tn(dy, x, gw, colsum=gb, splitk=self._splitk(gw.shape[0], gw.shape[1]))
 
     def backward(self, dfeat: torch.Tensor, B: int, Lw: int, wgrads: bool = True, mix_w=None, mix_dw=None,
-                 data_grads: bool = True):
+                 data_grads: bool = True, extractor: bool = False):
         """Backward of the last ``forward(..., train=True)`` of this (B, L) shape from dfeat = d(loss)/d(features) (B, T, d) f32.
         Accumulates into ``self.grads`` (reference names): always the parameters upstream of the transformer that the reference
         never freezes (``layer_norm.*`` in front of post_extract_proj and, under span masking, ``mask_emb``); with ``wgrads``
@@ -684,9 +705,47 @@ class WavLMBackbone:
         # post_extract_proj (frozen: data gradient only), then the LayerNorm on the conv features
         k.scale_cast(dxm, sv["dab"], 1.0)
         k.gemm_nt(sv["dab"], W["proj_wT"], sv["dxc"])
-        k.layernorm_bwd(sv["dxc"], ws["xc"], ws["mean_in"], ws["rstd_in"], W["ln0_w"], sv["partial"],
-                        dx=sv["db"].view(-1)[:M * self.C].view(M, self.C),      # (unused: the conv extractor below is frozen)
+        dconv = sv["db"].view(-1)[:M * self.C].view(M, self.C)                  # gradient at the conv stack's output
+        k.layernorm_bwd(sv["dxc"], ws["xc"], ws["mean_in"], ws["rstd_in"], W["ln0_w"], sv["partial"], dx=dconv,
                         dgamma=g["layer_norm.weight"], dbeta=g["layer_norm.bias"], dtype=bf)
+        if extractor:
+            self._wgrad(sv["dab"], ws["h0"], g["post_extract_proj.weight"], g["post_extract_proj.bias"])
+            self._backward_extractor(ws, B, dconv)
+
+    def _backward_extractor(self, ws, B, dconv):
+        """Conv feature extractor backward (lid/wavlm/WavLM.py:409-531): layers 6..1 are the forward's strided-view GEMMs run
+        backwards (weight gradient = TN GEMM on the same view, data gradient = NT GEMM to window space + col2im), layer 0 is
+        recomputed from the waveform.  Needs a forward that kept the pre-activations (``train_extractor``)."""
+        ex, W, k, g = ws.get("ex"), self.W, ops, self.grads
+        if ex is None or not ws.get("ex_valid"):
+            raise LidkError("extractor backward without a forward that kept the pre-activations (set train_extractor first)")
+        T, P, bufs, C = ws["T"], ws["P"], ws["bufs"], self.C
+        n = len(T)
+        fe = "feature_extractor.conv_layers."
+        fgm = float(self.cfg.get("feature_grad_mult", 1.0))       # WavLM.py:362-368: GradMultiply on the extractor's output
+        if fgm <= 0:
+            return                                                # the reference runs the extractor under no_grad then
+        if fgm != 1.0:
+            k.scale_cast(dconv, dconv, fgm)
+        k.wavlm_conv_dlast(dconv, ex["pre"][n - 1][:B * P[n - 1]], ex["d"][n - 1][:B * P[n - 1]], B, T[n - 1], P[n - 1])
+        for l in range(n - 1, 0, -1):
+            _, kw, st = self.layers_spec[l]
+            rows = B * P[l]
+            dpre = ex["d"][l][:rows]
+            A = bufs[l - 1].as_strided((rows, kw * C), (st * C, 1))
+            gw = ex["gconv"][l]
+            gw.zero_()
+            k.gemm_tn(dpre, A, gw, splitk=16)
+            g[f"{fe}{l}.0.weight"] += gw.view(C, kw, C).permute(0, 2, 1)                  # [Co][kW*Ci] -> [Co][Ci][kW]: layout glue
+            dcol = ex["dcol"].view(-1)[:rows * kw * C].view(rows, kw * C)
+            k.gemm_nt(dpre, W["convT"][l - 1], dcol)
+            k.wavlm_conv_col2im(dcol, ex["pre"][l - 1][:B * P[l - 1]] if l > 1 else None, ex["d"][l - 1][:B * P[l - 1]], B, P[l],
+                                T[l], T[l - 1], kw, C)
+        off = k.wavlm_conv0_stats_offset(B, T[0], C)
+        ex["gconv0"].zero_()
+        k.wavlm_conv0_bwd(ws["wav"], W["conv0_w"], W["gn_w"], W["gn_b"], ws["c0ws"][off:off + B * C * 2], ex["d"][0][:B * P[0]],
+                          ex["sums"], ex["gconv0"], g[fe + "0.2.weight"], g[fe + "0.2.bias"], T[0], P[0])
+        g[fe + "0.0.weight"] += ex["gconv0"].view(C, 1, -1)
 
     def _gate_scratch(self):
         """Throw-away targets for the gate's parameter gradients while the encoder is frozen (data gradients only)."""
@@ -739,7 +798,9 @@ class WavLMBackbone:
         klen = self._key_lengths(ws, B, Tn, Lw, n_samples)
         if train:                                             # keep what backward needs (eager launches, dropouts on)
             self.step += 1
-            self.graphs.run(("pre", B, Lw), lambda: self._fwd_pre(ws, B, None))
+            keep_pre = bool(self.train_extractor)
+            self.graphs.run(("pre", B, Lw, keep_pre), lambda: self._fwd_pre(ws, B, None, keep_pre))
+            ws["ex_valid"] = keep_pre
             sv = self._train_buffers(ws, B)
             p_in = float(self.cfg.get("dropout_input", 0.0))
             if p_in > 0:
@@ -754,7 +815,8 @@ class WavLMBackbone:
                 self._apply_mask(ws, B, Tn, Lw, n_samples)
             self._fwd_post(ws, B, taps, klen=klen, mix_w=mix_w)
         else:
-            self.graphs.run(("pre", B, Lw), lambda: self._fwd_pre(ws, B, None))
+            self.graphs.run(("pre", B, Lw, False), lambda: self._fwd_pre(ws, B, None))
+            ws["ex_valid"] = False
             if masking:
                 self._apply_mask(ws, B, Tn, Lw, n_samples)     # host-drawn spans -> two small H2D copies + one launch
             self.graphs.run(("post", B, Lw, klen is not None, None if mix_w is None else mix_w.data_ptr()),

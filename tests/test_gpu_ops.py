@@ -938,3 +938,30 @@ def test_speed_perturb_matches_the_float64_restatement():
     out2, _, lens2 = ops.speed_perturb(wav[:2].to(DEV), [(11, 10)] * 2)
     assert lens2 == [ops.speed_out_len(L, 11, 10)] * 2
     np.testing.assert_allclose(out2[0].cpu().numpy(), of.speed_perturb_np(wav[0].numpy(), 11, 10), atol=2e-5)
+
+
+@pytest.mark.parametrize("M", [9664, 1000])
+def test_grouped_weight_gradients_equal_the_separate_launches(M):
+    """lidk_gemm_tn_grouped (one launch for a block's weight gradients) against lidk_gemm_tn per site and against torch:
+    full-tile shapes (M = 9664 = 151 * 64) and a ragged M with a narrow, non-multiple-of-64 site."""
+    torch.manual_seed(M)
+    shapes = [(256, 1024), (1024, 256), (256, 512), (768, 256), (256, 256)] + ([(48, 256)] if M % 64 else [])
+    ents, refs, seps = [], [], []
+    for n1, n2 in shapes:
+        X = (0.5 * torch.randn(M, n1)).bfloat16().to(DEV)
+        Y = (0.5 * torch.randn(M, n2)).bfloat16().to(DEV)
+        C0 = torch.randn(n1, n2).to(DEV)
+        cs0 = torch.randn(n1).to(DEV)
+        Cg, csg, Cs, css = C0.clone(), cs0.clone(), C0.clone(), cs0.clone()
+        ents.append((X, Y, Cg, csg, M, n1, n2))
+        ops.gemm_tn(X, Y, Cs, colsum=css, splitk=8)
+        seps.append((Cs, css))
+        refs.append((C0 + X.float().t() @ Y.float(), cs0 + X.float().sum(0)))
+    grp = ops.build_tn_group(ents, split=4)
+    assert grp[3] == (M % 64 == 0)
+    ops.gemm_tn_grouped(grp)
+    torch.cuda.synchronize()
+    for (X, Y, Cg, csg, *_), (Cs, css), (Cr, csr) in zip(ents, seps, refs):
+        scale = float(Cr.abs().max())
+        assert float((Cg - Cr).abs().max()) <= 2e-3 * scale and float((Cg - Cs).abs().max()) <= 2e-3 * scale
+        assert float((csg - csr).abs().max()) <= 2e-3 * float(csr.abs().max())

@@ -201,8 +201,11 @@ def test_head_training_step_on_frozen_backbone_against_the_reference(dt):
     assert not bad, bad[:8]
 
 
-def _cmp_grads(g, grad_of, tag, cos_min=0.99, nrel_max=0.08, skip=()):
-    """Norm + sampled direction of every gradient tensor against the reference's autograd.
+def _cmp_grads(g, grad_of, tag, cos_min=0.997, nrel_max=0.05, skip=()):
+    """Norm + sampled direction of every gradient tensor against the reference's autograd (bf16 operands here, f32 there):
+    sampled cosine >= 0.997, norm within 5 %.  Measured worst cases, all on the GRU gate's path (grep_a 3.1 % in norm, grep_linear
+    cosine 0.998 under dropout): the gate's gradient is a row sum of dS against the bias table, and dS carries delta_i = dO_i . O_i
+    formed from the bf16 attention output; every projection / FFN / LayerNorm / conv tensor sits at cosine >= 0.9995, norm <= 1 %.
 
     ``grep_linear.bias`` (the GRU gate's bias) is held to an ABSOLUTE bound instead: its two distinct values are sums of the
     same signed per-(row, head) terms whose |.|-weighted sums make up ``grep_linear.weight``'s gradient, and they cancel almost
@@ -439,3 +442,41 @@ def test_finetune_step_with_backbone_dropout_against_the_reference():
         e1, _ = m([wav[i] for i in range(wav.shape[0])], 16000, "b")
         e2, _ = m([wav[i] for i in range(wav.shape[0])], 16000, "b")
     assert torch.equal(e1["b"], e2["b"])
+
+
+def test_full_finetune_step_with_unfrozen_feature_extractor_against_the_reference():
+    """Everything un-frozen (the reference's regime after freeze_encoder_epoch, lid/LidModule_ASR.py:288-293): on top of the
+    transformer, the conv feature extractor (7 conv layers, the GroupNorm of layer 0) and post_extract_proj take gradients - the
+    conv stack's backward mirrors its strided-view GEMMs.  Every gradient against the reference's autograd
+    (tests/golden/wavlm_full.npz)."""
+    from lid.ConformerLangModel import CtcLossFn
+    g = load_npz("wavlm_full.npz")
+    m = _model(cfg=wc.CFG_TRAIN)
+    m.train()
+    m.unfreeze_feature_extractor()
+    m.unfreeze_tranformer_encoder()
+    wav, texts = wc.waveforms().to(DEV), wc.texts().to(DEV)
+    m.zero_grad()
+    logits, _ = m([wav[i] for i in range(wav.shape[0])], 16000, "b")
+    z = logits["b"]
+    B, T, _ = z.shape
+    per = CtcLossFn.apply(z, texts, torch.full((B,), T, device=DEV, dtype=torch.long),
+                          torch.full((B,), texts.shape[1], device=DEV, dtype=torch.long), 40, m.lidk_engine.k)
+    per.mean().backward()
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(g["train_logits_b"])
+    lerr, loss, ref_loss = float((z.detach().cpu() - ref).abs().max()), float(per.mean().detach()), float(g["train_loss"])
+    print(f"[wavlm full step] logits err {lerr:.3e}; loss {loss:.4f} vs {ref_loss:.4f}")
+    assert lerr <= 4e-2 * max(1.0, float(ref.abs().max())) and abs(loss - ref_loss) <= 2e-2 * ref_loss
+    params = dict(m.named_parameters())
+    n = _cmp_grads(g, lambda name: params[name].grad, "wavlm full step")
+    assert n >= 86 and params["model.featurizer.model.feature_extractor.conv_layers.0.0.weight"].grad is not None
+    # freezing it again stops those gradients (and the forward stops keeping pre-activations)
+    m.freeze_feature_extractor()
+    m.zero_grad()
+    logits, _ = m([wav[i] for i in range(wav.shape[0])], 16000, "b")
+    per = CtcLossFn.apply(logits["b"], texts, torch.full((B,), T, device=DEV, dtype=torch.long),
+                          torch.full((B,), texts.shape[1], device=DEV, dtype=torch.long), 40, m.lidk_engine.k)
+    per.mean().backward()
+    params = dict(m.named_parameters())
+    assert all(p.grad is None for k, p in params.items() if ".feature_extractor." in k or ".post_extract_proj." in k)
