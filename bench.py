@@ -62,7 +62,8 @@ def build(args, rank, world, device):
     seed_everything(0)
     per_lang = args.batch * world * args.resident
     ov = [f"trainer.gpu_id={device.index}", "trainer.use_amp=true", f"trainer.ddp={'true' if world > 1 else 'false'}",
-          f"trainer.world_size={world}", f"trainer.local_rank={rank}", "trainer.backend=nccl", "trainer.total_epoch=1000",
+          f"trainer.world_size={world}", f"trainer.local_rank={rank}",
+          f"trainer.backend={'gloo' if os.environ.get('LIDK_BENCH_ONE_GPU', '0') == '1' else 'nccl'}", "trainer.total_epoch=1000",
           f"data.sampler_common.train_batch_size={args.batch}", f"data.synthetic.items_per_lang={per_lang}",
           f"data.synthetic.val_items_per_lang={args.val_items}", "data.synthetic.test_items_per_lang=2",
           "module.interval=1000000", "trainer.log_interval=1000000", f"model.n_blocks={args.blocks}",
@@ -643,11 +644,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the lidk path has no CPU fallback")
-    device = torch.device(f"cuda:{local}")
+    # Rehearsal switches for a ONE-GPU box (tests only; the driver's N > 1 runs use neither): every rank on cuda:0 and gloo
+    # instead of RCCL, which refuses two ranks on one device
+    one_gpu = os.environ.get("LIDK_BENCH_ONE_GPU", "0") == "1"
+    device = torch.device("cuda:0" if one_gpu else f"cuda:{local}")
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         args.cavg_steps = 0                      # the Cavg / fit / CPU legs belong to the N = 1 run (see the docstring)
         args.fit_epochs = 0
 
@@ -711,6 +718,36 @@ def main():
     finite = bool(torch.isfinite(loss_vals).all())
     chunk_ms = [marks[c].elapsed_time(marks[c + 1]) / max(bounds[c + 1] - bounds[c], 1) for c in range(chunks)]
 
+    # Exposed communication (N > 1): the same steps again with every data-path collective stubbed out (gradient exchange skipped,
+    # SyncBatchNorm all-reduce a no-op: the ranks then train on local statistics - timing only, after the timed region).
+    comm = None
+    if world > 1:
+        eng = trainer.engine
+        keep_sync, keep_stat = trainer._sync_grads, eng.stat_allreduce
+        n_probe = max(10, args.steps // 4)
+
+        def probe(stub):
+            nonlocal it
+            if stub:
+                eng.stat_allreduce = (lambda t: None) if keep_stat is not None else None
+                trainer.ddp_comm_stub = True
+            sync()
+            t_ = time.perf_counter()
+            for _ in range(n_probe):
+                step_fn(it, batches[it % nb], batches[(it + 1) % nb])
+                it += 1
+            sync()
+            dt = (time.perf_counter() - t_) / n_probe * 1e3
+            eng.stat_allreduce, trainer.ddp_comm_stub = keep_stat, False
+            return dt
+        with_comm = probe(False)
+        without = probe(True)
+        t = torch.tensor([with_comm, without], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm = {"ms_per_step_with_comm": round(float(t[0]), 3), "ms_per_step_comm_stubbed": round(float(t[1]), 3),
+                "comm_exposed_ms": round(float(t[0] - t[1]), 3), "steps": n_probe,
+                "stage_group": int(os.environ.get("LIDK_DP_STAGE_GROUP", "3")),
+                "note": "stubbed = gradient exchange skipped and SyncBatchNorm all-reduce replaced by a no-op (timing only)"}
     phases = phase_times(trainer, batches, step_fn)      # every rank runs these extra steps (they contain collectives)
     roof = roofline(trainer, batches, step_fn)
     it += 2
@@ -766,7 +803,7 @@ def main():
                 "chunks_ms_per_step": [round(c, 3) for c in chunk_ms], "median_ms_per_step": round(med, 3),
                 "value_at_median": round(audio_s / args.steps / (med * 1e-3), 1),
                 "loss_first_last": [round(float(loss_vals[0]), 4), round(float(loss_vals[-1]), 4)], "loss_finite": finite,
-                "host_issue_ms_per_step": round(host_issue * 1e3, 3), "phases_ms": phases, "roofline": roof,
+                "host_issue_ms_per_step": round(host_issue * 1e3, 3), "comm": comm, "phases_ms": phases, "roofline": roof,
                 # whole step against the MFMA roof: SURVEY 8d's algorithmic FLOPs (21.67 GFLOP per 3 s utterance: one head,
                 # every block) over the timed wall clock - only meaningful for the headline Conformer workload
                 "whole_step_tflops": (round(world * args.batch * FLOP_PER_UTT_TRAIN * args.steps / elapsed / 1e12, 1)

@@ -80,3 +80,25 @@ def test_single_rank_rccl_process_group_with_graph_capture(tmp_path):
     for k in a:
         if a[k].is_floating_point() and not k.endswith(("conv.net.4.conv.bias", "conv.net.5.running_mean")):
             np.testing.assert_allclose(b[k].numpy(), a[k].numpy(), rtol=5e-3, atol=5e-5, err_msg=k)
+
+
+def test_bench_two_ranks_rehearsal_at_cfg2_shape():
+    """the data-parallel path at the BENCHMARKED shape (12 x d256, 14 languages, B = 32 per rank, 3 s) through
+    bench.py itself, two ranks sharing this box's one GPU over gloo (LIDK_BENCH_ONE_GPU: RCCL refuses two ranks per device):
+    per-block graphs cut at the SyncBatchNorm all-reduces, coalesced gradient stages, the exposed-communication probe, finite
+    losses, and the contract line."""
+    import json
+    import subprocess
+    env = dict(os.environ, LIDK_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--batch", "32",
+           "--resident", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["loss_finite"] is True
+    assert line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
+    comm = line["comm"]
+    print("[bench dp2 rehearsal]", line["ms_per_step"], comm)
+    assert comm["ms_per_step_with_comm"] > 0 and comm["ms_per_step_comm_stubbed"] > 0 and "comm_exposed_ms" in comm
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
