@@ -196,6 +196,11 @@ int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, 
 /* Split form: lidk_attn_bwd with drel_emb == NULL leaves the relative-position embedding gradient out (allowed when
  * lidk_attn_bwd_relpos_supported: bf16, dh 32/64, T within the MFMA kernels' LDS budget) and lidk_attn_bwd_relpos adds it
  * later from the dS rows that call stored in `dscores`:  drel_emb[clamp(r)+max_pos][:] += scale * sum_i dS[i][i-r] q[i][:]. */
+/* Shapes for which `probs` may be NULL in lidk_attn_fwd and lidk_attn_bwd (bf16, dh 32 / 64, T <= 256): the forward then stores
+ * nothing T x T and the backward RECOMPUTES the probabilities from q, k and the relative embeddings (row kernel: softmax rows, dS,
+ * dq, each row's log-sum-exp and delta; key-block kernel: dk, dv from recomputed tiles).  dscores keeps its size: the bf16 dS rows
+ * fill its first half, the row statistics sit behind them. */
+int lidk_attn_recompute_supported(int T, int dh, int dtype);
 int lidk_attn_bwd_relpos_supported(int T, int dh, int dtype);
 int lidk_attn_bwd_relpos(const void* qkv, const float* dscores, int ldp, float* drel_emb, int B, int T, int heads, int dh,
                          int max_pos, int dtype, void* stream);

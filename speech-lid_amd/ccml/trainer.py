@@ -268,6 +268,13 @@ class Trainer:
             dist.broadcast(b, src=0)
         engine.refresh_weights()
 
+    def _background_batches(self) -> bool:
+        """Pull batches on a helper thread?  Only when DataLoader WORKER PROCESSES build them: with num_workers = 0 the collate
+        (speed / SpecAugment / dither-seed draws from the global random / torch generators) would run on that thread
+        concurrently with the launch thread's own draws (LayerDrop, span masks, dither seeds) and a seeded run would no longer
+        be reproducible."""
+        return self.device.type == "cuda" and int(getattr(self.train_dataloader, "num_workers", 0) or 0) > 0
+
     def _wait_comm(self):
         flush = getattr(self, "_dp_flush", None)
         if flush is not None:
@@ -469,7 +476,7 @@ class Trainer:
             value = {"avg_accumulate_loss": 0.0, "moving_avg_loss": 0.0}
             self.exec_callbacks("before_train_epoch", {})
             self.before_train_loop({})
-            with tqdm(enumerate(_lookahead(self.train_dataloader, background=self.device.type == "cuda")), total=n, desc="train", disable=self.local_rank > 0) as tbar:
+            with tqdm(enumerate(_lookahead(self.train_dataloader, background=self._background_batches())), total=n, desc="train", disable=self.local_rank > 0) as tbar:
                 self.tbar = tbar
                 last = time.time()
                 for i, (batch, upcoming) in tbar:

@@ -322,11 +322,13 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT
       }
     }
     __builtin_amdgcn_wave_barrier();
-    // P rows -> global, 16 bytes per lane
-    bf16* pg = probs + ((size_t)(b * g.H + h) * T_ + i0) * ldp;
-    for (int c = lane; c < 16 * (Tp / 8); c += 64) {
-      int row = c / (Tp / 8), col = (c % (Tp / 8)) * 8;
-      if (i0 + row < T_) *reinterpret_cast<uint4*>(pg + (size_t)row * ldp + col) = *reinterpret_cast<const uint4*>(&Pw[row * LDV + col]);
+    // P rows -> global, 16 bytes per lane (probs == NULL: the backward recomputes them, nothing T x T is stored)
+    if (probs) {
+      bf16* pg = probs + ((size_t)(b * g.H + h) * T_ + i0) * ldp;
+      for (int c = lane; c < 16 * (Tp / 8); c += 64) {
+        int row = c / (Tp / 8), col = (c % (Tp / 8)) * 8;
+        if (i0 + row < T_) *reinterpret_cast<uint4*>(pg + (size_t)row * ldp + col) = *reinterpret_cast<const uint4*>(&Pw[row * LDV + col]);
+      }
     }
     // O = P.V
     f32x4 ao[DH / 16];
@@ -363,6 +365,7 @@ static int att_pick_nw(int T_, size_t (*lds)(int, int, int), int dh) {
   return nw < 4 ? 4 : nw;
 }
 
+extern "C" int lidk_attn_recompute_supported(int T_, int dh, int dtype);
 extern "C" int lidk_attn_ldp(int T_, int dh, int dtype) {
   // row stride of the probs buffer: padded to a multiple of 32 for the MFMA kernels, plain T otherwise
   bool mfma = dtype == LIDK_BF16 && (dh == 32 || dh == 64) && T_ <= 16 * AF_NJ_MAX && att_mfma_lds(T_, dh) <= 160 * 1024;
@@ -382,7 +385,7 @@ template <int DH>
 __global__ void __launch_bounds__(640)
 attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT, const bf16* __restrict__ probs,
                           const bf16* __restrict__ dout, bf16* __restrict__ dqkv, bf16* __restrict__ dsT, AttGeom g,
-                          int ldp, float scale) {
+                          int ldp, float scale, float* __restrict__ row_stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int KS = DH / 32, LDK = DH + 8, CH = DH / 8;
   const int T_ = g.T, Tp = (T_ + 31) / 32 * 32, NJ = Tp / 16, LDV = Tp + 8, NE = 2 * Tp + 8;
@@ -417,12 +420,81 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
   const size_t bh = (size_t)(b * g.H + h) * T_;
   for (int rb = wave; rb < nrb; rb += NW) {          // wave-uniform
     const int i0 = rb * 16;
-    // P rows of this block -> LDS (16-byte chunks); rows >= T are zero
-    for (int c = lane; c < 16 * (Tp / 8); c += 64) {
-      int row = c / (Tp / 8), col = (c % (Tp / 8)) * 8;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (i0 + row < T_) v = *reinterpret_cast<const uint4*>(probs + (bh + i0 + row) * ldp + col);
-      *reinterpret_cast<uint4*>(&Pw[row * LDV + col]) = v;
+    if (probs) {
+      // P rows of this block -> LDS (16-byte chunks); rows >= T are zero
+      for (int c = lane; c < 16 * (Tp / 8); c += 64) {
+        int row = c / (Tp / 8), col = (c % (Tp / 8)) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i0 + row < T_) v = *reinterpret_cast<const uint4*>(probs + (bh + i0 + row) * ldp + col);
+        *reinterpret_cast<uint4*>(&Pw[row * LDV + col]) = v;
+      }
+    } else {
+      // recompute P = softmax(scale * (Q.K^T + skew(Q.E^T))) exactly as attn_fwd_mfma_kernel does (same tiles, same order), and
+      // leave each row's log-sum-exp for the key-block kernel; nothing T x T is read from HBM
+      bf16x8 qf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i0 + fr < T_) v = *reinterpret_cast<const uint4*>(base + (size_t)(i0 + fr) * g.ld + ks * 32 + fq * 8);
+        qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+      }
+      float sc[AF_NJ_MAX][4];
+      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+        if (jt < NJ) {
+          const int j0 = jt * 16;
+          f32x4 as = {0.f, 0.f, 0.f, 0.f}, r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
+          const int eb = i0 - j0 - 15 + Tp;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(j0 + fr) * LDK + ks * 32 + fq * 8]);
+            bf16x8 e0 = *reinterpret_cast<const bf16x8*>(&Es[(eb + fr) * LDK + ks * 32 + fq * 8]);
+            bf16x8 e1 = *reinterpret_cast<const bf16x8*>(&Es[(eb + 16 + fr) * LDK + ks * 32 + fq * 8]);
+            as = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, as, 0, 0, 0);
+            r0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], e0, r0, 0, 0, 0);
+            r1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], e1, r1, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int a = fq * 4 + r, cp = a - fr + 15;
+            const int src = (lane & 48) | (cp & 15);
+            const float v0 = __shfl(r0[r], src, 64), v1 = __shfl(r1[r], src, 64);
+            float v = scale * (as[r] + (cp < 16 ? v0 : v1));
+            if (j0 + fr >= T_) v = -INFINITY;
+            sc[jt][r] = v;
+            mx[r] = fmaxf(mx[r], v);
+          }
+        }
+      }
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+      }
+#pragma unroll
+      for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+        if (jt < NJ) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { float p = __expf(sc[jt][r] - mx[r]); sc[jt][r] = p; sum[r] += p; }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sum[r] += __shfl_xor(sum[r], o, 64);
+        if (fr == 0 && i0 + fq * 4 + r < T_) row_stats[bh + i0 + fq * 4 + r] = mx[r] + __logf(sum[r]);
+        sum[r] = __builtin_amdgcn_rcpf(sum[r]);
+      }
+#pragma unroll
+      for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+        if (jt < NJ) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Pw[(fq * 4 + r) * LDV + jt * 16 + fr] = (i0 + fq * 4 + r < T_) ? (bf16)(sc[jt][r] * sum[r]) : (bf16)0.f;
+        }
+      }
     }
     bf16x8 dof[KS];
 #pragma unroll
@@ -454,6 +526,7 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) delta[r] += __shfl_xor(delta[r], o, 64);
+      if (!probs && fr == 0 && i0 + fq * 4 + r < T_) row_stats[(size_t)g.B * g.H * T_ + bh + i0 + fq * 4 + r] = delta[r];
     }
 #pragma unroll
     for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
@@ -616,6 +689,124 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
   }
 }
 
+// Key-block kernel of the recompute path (probs == NULL): a wave owns 16 keys and walks the query rows 32 at a time; the S tiles
+// are recomputed from Q, K and the relative embeddings (same MFMAs and the same skew as the forward), P = exp(S - lse), dS =
+// P (dP - delta) with lse / delta left by attn_bwd_rows_mfma_kernel.  The accumulator tiles of P and dS, packed to bf16, ARE the
+// A operands of dV += P^T.dO and dK += dS^T.Q (slot-permuted MFMA, common.h tr_frag_split): no probabilities, no dS and nothing
+// transposed is read from HBM or staged through LDS.  (dE, the embedding table's gradient, stays with the PART-2 launch of
+// attn_bwd_cols_mfma_kernel on the weight-gradient stream, fed by the dS rows the row kernel writes.)
+template <int DH>
+__global__ void __launch_bounds__(1024)
+attn_bwd_kv_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT, const bf16* __restrict__ dout,
+                        const float* __restrict__ row_stats, bf16* __restrict__ dqkv, AttGeom g, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int KS = DH / 32, LDK = DH + 8, CH = DH / 8, NT = DH / 16;
+  const int T_ = g.T, Tp = (T_ + 31) / 32 * 32, NJ = Tp / 16, NE = 2 * Tp + 8;
+  bf16* Qs = reinterpret_cast<bf16*>(smem);             // [Tp][LDK]
+  bf16* Ds = Qs + Tp * LDK;                             // dO
+  bf16* Es = Ds + Tp * LDK;                             // [NE][LDK], row e <-> offset e - Tp
+  float* lse_s = reinterpret_cast<float*>(Es + NE * LDK);
+  float* del_s = lse_s + Tp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4, nthr = blockDim.x, NW = nthr >> 6;
+  const int b = blockIdx.x / g.H, h = blockIdx.x % g.H;
+  const size_t bh = (size_t)(b * g.H + h) * T_;
+  const bf16* base = qkv + (size_t)b * T_ * g.ld + h * DH;
+  const bf16* dbase = dout + (size_t)b * T_ * g.inner + h * DH;
+  for (int c = tid; c < Tp * CH; c += nthr) {
+    const int i = c / CH, dc = (c % CH) * 8;
+    uint4 qv = make_uint4(0, 0, 0, 0), dv4 = make_uint4(0, 0, 0, 0);
+    if (i < T_) {
+      qv = *reinterpret_cast<const uint4*>(base + (size_t)i * g.ld + dc);
+      dv4 = *reinterpret_cast<const uint4*>(dbase + (size_t)i * g.inner + dc);
+    }
+    *reinterpret_cast<uint4*>(&Qs[i * LDK + dc]) = qv;
+    *reinterpret_cast<uint4*>(&Ds[i * LDK + dc]) = dv4;
+  }
+  for (int c = tid; c < NE * CH; c += nthr) {
+    const int e = c / CH, dc = (c % CH) * 8;
+    const int r = max(-g.max_pos, min(g.max_pos, e - Tp)) + g.max_pos;
+    *reinterpret_cast<uint4*>(&Es[e * LDK + dc]) = *reinterpret_cast<const uint4*>(embT + (size_t)r * DH + dc);
+  }
+  for (int i = tid; i < Tp; i += nthr) {
+    lse_s[i] = i < T_ ? row_stats[bh + i] : 0.f;
+    del_s[i] = i < T_ ? row_stats[(size_t)g.B * g.H * T_ + bh + i] : 0.f;
+  }
+  __syncthreads();
+  for (int jt = wave; jt < NJ; jt += NW) {                // wave-uniform
+    const int j0 = jt * 16, j = j0 + fr;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (j < T_) {
+        kv = *reinterpret_cast<const uint4*>(base + (size_t)j * g.ld + g.inner + ks * 32 + fq * 8);
+        vv = *reinterpret_cast<const uint4*>(base + (size_t)j * g.ld + 2 * g.inner + ks * 32 + fq * 8);
+      }
+      kf[ks] = *reinterpret_cast<bf16x8*>(&kv);
+      vf[ks] = *reinterpret_cast<bf16x8*>(&vv);
+    }
+    f32x4 dk[NT], dv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { dk[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int i0 = 0; i0 < Tp; i0 += 32) {
+      float pd[2][4], ds[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ib = i0 + 16 * t, eb = ib - j0 - 15 + Tp;
+        f32x4 as = {0.f, 0.f, 0.f, 0.f}, r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&Qs[(ib + fr) * LDK + ks * 32 + fq * 8]);
+          const bf16x8 da = *reinterpret_cast<const bf16x8*>(&Ds[(ib + fr) * LDK + ks * 32 + fq * 8]);
+          const bf16x8 e0 = *reinterpret_cast<const bf16x8*>(&Es[(eb + fr) * LDK + ks * 32 + fq * 8]);
+          const bf16x8 e1 = *reinterpret_cast<const bf16x8*>(&Es[(eb + 16 + fr) * LDK + ks * 32 + fq * 8]);
+          as = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], as, 0, 0, 0);
+          r0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, e0, r0, 0, 0, 0);
+          r1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, e1, r1, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = fq * 4 + r, cp = a - fr + 15, i = ib + a;
+          const int src = (lane & 48) | (cp & 15);
+          const float v0 = __shfl(r0[r], src, 64), v1 = __shfl(r1[r], src, 64);
+          const float sv = scale * (as[r] + (cp < 16 ? v0 : v1));
+          const float p = (i < T_ && j < T_) ? __expf(sv - lse_s[i]) : 0.f;
+          pd[t][r] = p;
+          ds[t][r] = p * (dp[r] - del_s[i]);
+        }
+      }
+      union { bf16 e[8]; bf16x8 v; } pf, sf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pf.e[r] = (bf16)pd[0][r]; pf.e[4 + r] = (bf16)pd[1][r];
+        sf.e[r] = (bf16)ds[0][r]; sf.e[4 + r] = (bf16)ds[1][r];
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        dv[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf.v, tr_frag_split(Ds, LDK, i0, nt * 16, fq, fr), dv[nt], 0, 0, 0);
+        dk[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf.v, tr_frag_split(Qs, LDK, i0, nt * 16, fq, fr), dk[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jo = j0 + fq * 4 + r;
+      if (jo < T_) {
+        bf16* row = dqkv + (size_t)(b * T_ + jo) * g.ld + h * DH;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          row[g.inner + nt * 16 + fr] = (bf16)(dk[nt][r] * scale);
+          row[2 * g.inner + nt * 16 + fr] = (bf16)dv[nt][r];
+        }
+      }
+    }
+  }
+}
+static size_t att_bwd_kv_mfma_lds(int T_, int dh) {
+  const int Tp = (T_ + 31) / 32 * 32;
+  return (size_t)2 * ((size_t)2 * Tp * (dh + 8) + (size_t)(2 * Tp + 8) * (dh + 8)) + (size_t)2 * Tp * 4;
+}
+
 static size_t att_bwd_rows_mfma_lds(int T_, int dh, int nw = 4) {
   int Tp = (T_ + 31) / 32 * 32;
   return (size_t)2 * ((size_t)2 * Tp * (dh + 8) + (size_t)(2 * Tp + 8) * (dh + 8) + (size_t)nw * 16 * (Tp + 8));
@@ -631,10 +822,27 @@ static void att_bwd_mfma_launch(const void* qkv, const void* embT, const void* p
   const float scale = 1.0f / sqrtf((float)DH);
   const int nw = att_pick_nw(g.T, att_bwd_rows_mfma_lds, DH);
   size_t l1 = att_bwd_rows_mfma_lds(g.T, DH, nw), l2 = att_bwd_cols_mfma_lds(g.T, DH);
+  // row statistics (log-sum-exp, delta) of the recompute path live behind the bf16 dS rows in the caller's f32 scratch
+  float* row_stats = reinterpret_cast<float*>(dsT) + (size_t)g.B * g.H * g.T * ldp / 2;
   (void)hipFuncSetAttribute((const void*)attn_bwd_rows_mfma_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
   attn_bwd_rows_mfma_kernel<DH><<<g.B * g.H, 64 * nw, l1, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)probs,
-                                                           (const bf16*)dout, (bf16*)dqkv, (bf16*)dsT, g, ldp, scale);
+                                                           (const bf16*)dout, (bf16*)dqkv, (bf16*)dsT, g, ldp, scale, row_stats);
   const int Tp = (g.T + 31) / 32 * 32;
+  if (!probs) {                                      // recompute path: dK / dV from recomputed tiles, then (optionally) dE
+    const size_t l3 = att_bwd_kv_mfma_lds(g.T, DH);
+    const int nwk = min(16, max(4, Tp / 16));
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_mfma_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3);
+    attn_bwd_kv_mfma_kernel<DH><<<g.B * g.H, 64 * nwk, l3, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)dout, row_stats,
+                                                            (bf16*)dqkv, g, scale);
+    if (demb) {
+      const void* np = nullptr; const void* nd = nullptr; void* nq = nullptr;
+      const int nwc = min(16, max(4, 2 * Tp / 16 / 2));
+      (void)hipFuncSetAttribute((const void*)attn_bwd_cols_mfma_kernel<DH, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+      attn_bwd_cols_mfma_kernel<DH, false, 2><<<g.B * g.H, 64 * nwc, l2, s>>>((const bf16*)qkv, (const bf16*)np, (const bf16*)nd,
+                                                                          (const bf16*)dsT, (bf16*)nq, demb, g, ldp, scale);
+    }
+    return;
+  }
   const bool dual = att_bwd_cols_mfma_lds(g.T, DH, true) <= 160 * 1024;
   if (dual) l2 = att_bwd_cols_mfma_lds(g.T, DH, true);
 #define LIDK_COLS_LAUNCH(DUAL_, PART_, NW_)                                                                                    \
@@ -685,8 +893,9 @@ static bool att_dh_ok(int dh) { return dh == 8 || dh == 16 || dh == 32 || dh == 
 
 extern "C" int lidk_attn_fwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, void* out, void* probs, int ldp,
                              int B, int T_, int heads, int dh, int max_pos, int dtype, void* stream) {
-  if (!qkv || !rel_emb || !out || !probs || B <= 0 || T_ <= 0 || heads <= 0 || ldp < T_) return LIDK_ERR_ARG;
+  if (!qkv || !rel_emb || !out || B <= 0 || T_ <= 0 || heads <= 0 || ldp < T_) return LIDK_ERR_ARG;
   if (!att_dh_ok(dh)) return LIDK_ERR_UNSUPPORTED;
+  if (!probs && !lidk_attn_recompute_supported(T_, dh, dtype)) return LIDK_ERR_ARG;       // only the MFMA path can do without
   AttGeom g{B, T_, heads, dh, max_pos, heads * dh, 3 * heads * dh};
   const float scale = 1.0f / sqrtf((float)dh);
   hipStream_t s = as_stream(stream);
@@ -749,6 +958,13 @@ static int att_bwd_launch(const void* qkv, const float* rel_emb, const void* pro
   return launch_status();
 }
 
+// probs may be NULL in lidk_attn_fwd / lidk_attn_bwd (the backward recomputes the probabilities from Q, K, E) for these shapes
+extern "C" int lidk_attn_recompute_supported(int T_, int dh, int dtype) {
+  static const bool off = getenv("LIDK_ATTN_RECOMPUTE") && atoi(getenv("LIDK_ATTN_RECOMPUTE")) == 0;
+  return !off && dtype == LIDK_BF16 && (dh == 32 || dh == 64) && T_ <= 16 * AF_NJ_MAX && att_bwd_rows_mfma_lds(T_, dh) <= 160 * 1024 &&
+         att_bwd_cols_mfma_lds(T_, dh) <= 160 * 1024 && att_bwd_kv_mfma_lds(T_, dh) <= 160 * 1024 && att_mfma_lds(T_, dh) <= 160 * 1024;
+}
+
 extern "C" int lidk_attn_bwd_relpos_supported(int T_, int dh, int dtype) {
   return dtype == LIDK_BF16 && (dh == 32 || dh == 64) && T_ <= 16 * AF_NJ_MAX && att_bwd_rows_mfma_lds(T_, dh) <= 160 * 1024 &&
          att_bwd_cols_mfma_lds(T_, dh) <= 160 * 1024;
@@ -767,9 +983,10 @@ extern "C" int lidk_attn_bwd_relpos(const void* qkv, const float* dscores, int l
 extern "C" int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, const void* probs, int ldp,
                              const void* dout, void* dqkv, float* drel_emb, float* dscores, int B, int T_, int heads, int dh,
                              int max_pos, int dtype, void* stream) {
-  if (!qkv || !rel_emb || !probs || !dout || !dqkv || !dscores || B <= 0 || T_ <= 0 || heads <= 0 || ldp < T_)
+  if (!qkv || !rel_emb || !dout || !dqkv || !dscores || B <= 0 || T_ <= 0 || heads <= 0 || ldp < T_)
     return LIDK_ERR_ARG;
   if (!att_dh_ok(dh)) return LIDK_ERR_UNSUPPORTED;
+  if (!probs && !(lidk_attn_recompute_supported(T_, dh, dtype) && rel_emb_T && ldp == (T_ + 31) / 32 * 32)) return LIDK_ERR_ARG;
   if (!drel_emb && !lidk_attn_bwd_relpos_supported(T_, dh, dtype)) return LIDK_ERR_ARG;      // split form: MFMA path only
   AttGeom g{B, T_, heads, dh, max_pos, heads * dh, 3 * heads * dh};
   hipStream_t s = as_stream(stream);

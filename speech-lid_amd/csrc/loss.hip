@@ -325,7 +325,7 @@ lid_score_kernel(const float* __restrict__ logits, float* __restrict__ scores, i
   const float* lg = logits + (size_t)b * T_ * V1;
   float sum = 0.f, cnt = 0.f;
   for (int t = wave; t < T_; t += 4) {
-    float mx = NEG_INF; int arg = 0x7fffffff;
+    float mx = NEG_INF; int arg = blank;             // an all-NaN / all -inf row decodes as blank, never as an out-of-range id
     for (int c = lane; c < V1; c += 64) {
       float v = lg[(size_t)t * V1 + c];
       if (v > mx) { mx = v; arg = c; }
@@ -397,7 +397,7 @@ ctc_greedy_kernel(const float* __restrict__ logits, const int64_t* __restrict__ 
   const int n = in_len ? (int)min((int64_t)T_, max((int64_t)0, in_len[b])) : T_;
   const float* lg = logits + (size_t)b * T_ * V1;
   for (int t = wave; t < n; t += 4) {
-    float mx = NEG_INF; int arg = 0x7fffffff;
+    float mx = NEG_INF; int arg = blank;             // an all-NaN / all -inf row decodes as blank, never as an out-of-range id
     for (int c = lane; c < V1; c += 64) {
       float v = lg[(size_t)t * V1 + c];
       if (v > mx) { mx = v; arg = c; }
@@ -430,6 +430,8 @@ extern "C" int lidk_ctc_greedy(const float* logits, const int64_t* in_len, int* 
                                int blank, void* stream) {
   if (!logits || !ids || !out_len || B <= 0 || T_ <= 0 || V1 <= 1 || blank < 0 || blank >= V1) return LIDK_ERR_ARG;
   if ((size_t)T_ * 4 > 150 * 1024) return LIDK_ERR_UNSUPPORTED;      // frame symbols live in LDS
+  if ((size_t)T_ * 4 > 48 * 1024)                                     // beyond the default dynamic-LDS limit: ask for it
+    (void)hipFuncSetAttribute((const void*)ctc_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)T_ * 4));
   ctc_greedy_kernel<<<B, 256, (size_t)T_ * 4, as_stream(stream)>>>(logits, in_len, ids, out_len, T_, V1, blank);
   return launch_status();
 }

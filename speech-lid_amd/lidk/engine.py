@@ -524,7 +524,8 @@ class Engine:
             self._ff_fwd(x, bp.ff1, bb.h1, bb.a1, bb.u1, bb.x1, bb.mean[0], bb.rstd[0], ln_done=ff1_ln_done)
             A = bp.attn
             self._ln_gemm(bb.x1, A, A["wqkv"][0], bb.qkv, bb.h2, bb.mean[1], bb.rstd[1])
-            self.k.attn_fwd(bb.qkv, A["emb"], bb.o, bb.probs, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
+            self.k.attn_fwd(bb.qkv, A["emb"], bb.o, None if self._attn_recompute(T, bp.dh) else bb.probs, B, T, bp.heads, bp.dh,
+                            rel_emb_T=A["embT"])
             self.k.gemm_nt(bb.o, A["wo"][0], bb.x2, bias=A["bo"], res=bb.x1)
             self._ln_gemm(bb.x2, C, C["w1"][0], bb.y, bb.h3, bb.mean[2], bb.rstd[2], bias=C["b1"])
             dw2d = C["dw"].view(ci, K)
@@ -778,8 +779,8 @@ class Engine:
             # deferred mode: the relative-position embedding's gradient (a weight gradient, a third of this step's work)
             # is left to _block_wgrads, which computes it from the dS rows kept in the scratch set
             split = (not wg) and self._relpos_split(T, bp.dh)
-            self.k.attn_bwd(bb.qkv, A["emb"], bb.probs, do, dqkv, None if split else A["demb"], S.dsc, B, T, bp.heads, bp.dh,
-                            rel_emb_T=A["embT"])
+            self.k.attn_bwd(bb.qkv, A["emb"], None if self._attn_recompute(T, bp.dh) else bb.probs, do, dqkv,
+                            None if split else A["demb"], S.dsc, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
             if wg:
                 self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
             self.k.gemm_nt(dqkv, A["wqkv"][1], w.dh, N=d, K=3 * inner)
@@ -844,6 +845,14 @@ class Engine:
         self._conv_wgrad(w, bp, bb, S)
         if self._relpos_split(T, bp.dh):
             self.k.attn_bwd_relpos(bb.qkv, S.dsc, bb.probs.shape[-1], A["demb"], B, T, bp.heads, bp.dh)
+
+    def _attn_recompute(self, T: int, dh: int) -> bool:
+        """No probabilities in HBM: the attention backward recomputes them (bf16 MFMA shapes; LIDK_ATTN_RECOMPUTE=0 turns it off)."""
+        key = ("rc", T, dh)
+        if key not in self._split_ok:
+            self._split_ok[key] = bool(self._hip and hasattr(self.k, "attn_recompute_supported")
+                                       and self.k.attn_recompute_supported(T, dh, self.act_dtype))
+        return self._split_ok[key]
 
     def _grouped_wgrads(self) -> bool:
         """The block's weight-gradient GEMMs as one grouped launch (bf16 operands, HIP backend; LIDK_WGRAD_GROUPED=0 restores the

@@ -381,15 +381,24 @@ def attn_max_frames(dh, dtype):
     return lib().lidk_attn_max_frames(dh, dtype_code(dtype))
 
 
+def attn_recompute_supported(T, dh, dtype):
+    """True when attn_fwd / attn_bwd accept probs=None for this shape: the backward recomputes the probabilities."""
+    return bool(lib().lidk_attn_recompute_supported(T, dh, dtype_code(dtype)))
+
+
 def attn_fwd(qkv, rel_emb, out, probs, B, T, heads, dh, rel_emb_T=None):
+    """probs (B, heads, T, ldp) receives the softmax rows; None (attn_recompute_supported shapes): nothing T x T is stored."""
     max_pos = (rel_emb.shape[0] - 1) // 2
-    check(lib().lidk_attn_fwd(_p(qkv), _p(rel_emb), _p(rel_emb_T), _p(out), _p(probs), probs.shape[-1], B, T, heads, dh,
+    ldp = probs.shape[-1] if probs is not None else attn_ldp(T, dh, qkv.dtype)
+    check(lib().lidk_attn_fwd(_p(qkv), _p(rel_emb), _p(rel_emb_T), _p(out), _p(probs), ldp, B, T, heads, dh,
                               max_pos, _code(qkv), _stream()), "attn_fwd")
 
 
 def attn_bwd(qkv, rel_emb, probs, dout, dqkv, drel_emb, dscores, B, T, heads, dh, rel_emb_T=None):
+    """probs None: recompute path (the forward was run with probs=None); dscores then also carries the row statistics."""
     max_pos = (rel_emb.shape[0] - 1) // 2
-    check(lib().lidk_attn_bwd(_p(qkv), _p(rel_emb), _p(rel_emb_T), _p(probs), probs.shape[-1], _p(dout), _p(dqkv),
+    ldp = probs.shape[-1] if probs is not None else attn_ldp(T, dh, qkv.dtype)
+    check(lib().lidk_attn_bwd(_p(qkv), _p(rel_emb), _p(rel_emb_T), _p(probs), ldp, _p(dout), _p(dqkv),
                               _p(drel_emb), _p(dscores), B, T, heads, dh, max_pos, _code(qkv), _stream()), "attn_bwd")
 
 

@@ -293,6 +293,19 @@ def test_attention_fwd_bwd(dt, B, T, H, dh, maxpos, path):
         assert float(demb2.abs().max()) == 0.0 and torch.equal(dqkv2, dqkv)
         ops.attn_bwd_relpos(qd, dsc, probs.shape[-1], demb2, B, T, H, dh)
         check("attn_demb_split", demb2, demb, 1e-4 * max(1.0, float(demb.abs().max())))      # float atomics: order only
+    if path == "mfma" and ops.attn_recompute_supported(T, dh, dt):
+        # recompute path: the forward stores no probabilities, the backward rebuilds them from q, k and the embeddings
+        out3 = torch.empty_like(out)
+        ops.attn_fwd(qd, ed, out3, None, B, T, H, dh, rel_emb_T=embT)
+        assert torch.equal(out3, out)
+        for split in (False, True):
+            dqkv3 = torch.full_like(dqkv, 9.0)
+            demb3 = torch.zeros_like(ed)
+            ops.attn_bwd(qd, ed, None, dev(dout, dt), dqkv3, None if split else demb3, dsc, B, T, H, dh, rel_emb_T=embT)
+            if split:
+                ops.attn_bwd_relpos(qd, dsc, ldp, demb3, B, T, H, dh)
+            check(f"attn_dqkv[recompute split={split}]", dqkv3, qkv_r.grad, 3e-2 * max(1, gs))
+            check(f"attn_demb[recompute split={split}]", demb3, emb_r.grad, 6e-2 * max(1.0, float(emb_r.grad.abs().max())))
 
 
 @pytest.mark.parametrize("dt", DT)
