@@ -58,8 +58,12 @@ def test_wavlm_model_state_dict_names_and_module_surface():
     assert now == {"model.featurizer.model." + k for k in WavLMBackbone.param_shapes(wc.CFG) if k.startswith("encoder.")}
     mod.model.freeze_tranformer_encoder()
     assert [n for n, p in mod.model.named_parameters() if p.requires_grad] == trainable
-    with pytest.raises(NotImplementedError):
-        mod.model.unfreeze_feature_extractor()
+    mod.model.unfreeze_feature_extractor()                          # lid/WavLMMutiLangModel.py:86-94: extractor + post_extract_proj
+    now = {n for n, p in mod.model.named_parameters() if p.requires_grad} - set(trainable)
+    assert now and all(n.startswith(("model.featurizer.model.feature_extractor.", "model.featurizer.model.post_extract_proj."))
+                       for n in now)
+    mod.model.freeze_feature_extractor()
+    assert [n for n, p in mod.model.named_parameters() if p.requires_grad] == trainable
     with pytest.raises(ValueError):                                 # a wav2vec2 model needs a checkpoint or a config
         LidModule(lang2vocab=wc.L2V, lang2index_dict=wc.L2I, tokenizer_dict=toks, use_wav2vec=True, conformer_linear=True)
 
