@@ -115,6 +115,8 @@ int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
                        const float* gamma, const float* dres, float* dx, void* dxT, float dxT_scale, float* dgamma,
                        float* dbeta, float* partial, int M, int C, int dtype, void* stream);
 int lidk_layernorm_param_grads(const float* partial, int M, int C, float* dgamma, float* dbeta, void* stream);
+/* Same finaliser for `rows` partial rows of (dgamma | dbeta) [2*C] written by a kernel with its own grid (lidk_ffn_bwd). */
+int lidk_layernorm_param_grads_rows(const float* partial, int rows, int C, float* dgamma, float* dbeta, void* stream);
 /* Two LayerNorms in a row (C <= 256): post_norm of ConformerBlock i followed by the first FeedForward PreNorm of block i + 1
  * (lid/conformer.py:252-259, 153-171).  y1 = LN1(x) f32, y2 = LN2(y1) in T, statistics of both; one pass over x. */
 int lidk_layernorm2_fwd(const float* x, const float* g1, const float* b1, float* y1, float* mean1, float* rstd1, const float* g2,
@@ -162,6 +164,35 @@ int lidk_gemm_nt(const lidk_gemm_args* args, int dtype, void* stream);
 int lidk_ln_gemm_supported(int M, int N, int K, int dtype);
 int lidk_ln_gemm_nt(const lidk_gemm_args* args, const float* x, int ldx, const float* gamma, const float* beta, float eps,
                     void* h, float* mean, float* rstd, int dtype, void* stream);
+
+/* Whole FeedForward module in ONE launch (lid/conformer.py:153-171 FeedForward, its PreNorm :81-89, Scale(0.5) :247-248 and the
+ * residual add of ConformerBlock.forward :252-259) for the model width d == 256, bf16:
+ *     xo[M][256] (f32) = x + alpha * ( swish( LN(x) . W1[ff][256]^T + b1 ) . W2[256][ff]^T + b2 )
+ * x [M][256] f32 residual stream; gamma/beta/eps: the PreNorm LayerNorm.  h_in (T, optional): LN(x) already produced by
+ * lidk_layernorm2_fwd - then gamma/beta/mean/rstd are ignored and h is not rewritten.  Saved for the backward pass exactly as the
+ * three-launch sequence (lidk_layernorm_fwd + 2 x lidk_gemm_nt) saves them: h [M][256] (T), mean/rstd [M], a [M][ff] (T, the
+ * pre-activation), u [M][ff] (T, swish(a)); a, u, h may be NULL (inference).  A workgroup owns 64 complete rows, the hidden
+ * activation of a row never leaves registers between the two projections, the weights stream through LDS by global_load_lds.
+ * Returns LIDK_ERR_UNSUPPORTED when lidk_ffn_fwd_supported == 0 (callers then issue the three launches). */
+int lidk_ffn_fwd_supported(int M, int d, int ff, int dtype);
+int lidk_ffn_fwd(const float* x, const void* h_in, const float* gamma, const float* beta, float eps, const void* W1, const float* b1,
+                 const void* W2, const float* b2, void* h, float* mean, float* rstd, void* a, void* u, float* xo, float alpha, int M,
+                 int d, int ff, int dtype, void* stream);
+
+/* Data path of the FeedForward backward in ONE launch (autograd of lid/conformer.py:153-171 + PreNorm :81-89), d == 256, bf16:
+ *     da [M][ff] (T, stored)  = (dyT . W2) * swish'(a)        dyT [M][256] (T) = alpha * d(loss)/d(xo), a = saved pre-activation
+ *     dh [M][256]             = da . W1
+ *     dx (f32, optional) = dres (f32, optional) + LN'(dh; x, mean, rstd, gamma);  dxT (T, optional) = dxT_scale * dx
+ * W2T [ff][256] / W1T [256][ff]: the transposed operand copies (row n of W2T = W2[:, n]; row j of W1T = W1[:, j]); ldw2t == 256,
+ * ldw1t == ff.  partial: lidk_ffn_bwd_partial_rows(M) rows of (dgamma | dbeta) [2*256] f32, one per workgroup - finish them with
+ * lidk_layernorm_param_grads_rows.  With dh != NULL the kernel stops after the second product and writes dh (T) instead of running
+ * the LayerNorm backward (x .. partial are ignored): the site whose PreNorm backward is fused with the neighbouring block's
+ * post_norm (lidk_layernorm2_bwd).  da feeds the weight gradients (lidk_gemm_tn: dW1 = da^T h, db1 = colsum da; dW2 = dyT^T u).
+ * Replaces 2 x lidk_gemm_nt + lidk_layernorm_bwd; returns LIDK_ERR_UNSUPPORTED as lidk_ffn_fwd does. */
+int lidk_ffn_bwd_partial_rows(int M);
+int lidk_ffn_bwd(const void* dyT, const void* a, const void* W2T, int ldw2t, const void* W1T, int ldw1t, void* da, const float* x,
+                 const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx, void* dxT, float dxT_scale,
+                 float* partial, void* dh, int M, int d, int ff, int dtype, void* stream);
 
 /* Weight-gradient GEMM ("TN"): C[N1][N2] (f32) += alpha * sum_{m<M} X[m][n1] * Y[m][n2]; colsum[n1] (f32, optional) += alpha *
  * sum_m X[m][n1] (the bias gradient).  X [M][ldx], Y [M][ldy] are the activations as stored (T, row-major); rows are readable

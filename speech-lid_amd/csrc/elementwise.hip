@@ -623,3 +623,9 @@ extern "C" int lidk_layernorm_param_grads(const float* partial, int M, int C, fl
   colreduce_kernel<float, float, true><<<cdiv(2 * C, 16), 1024, 0, as_stream(stream)>>>(partial, G, 2 * C, dgamma, dbeta, C, 1.0f);
   return launch_status();
 }
+
+extern "C" int lidk_layernorm_param_grads_rows(const float* partial, int rows, int C, float* dgamma, float* dbeta, void* stream) {
+  if (!partial || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAX_VEC || (!dgamma && !dbeta)) return LIDK_ERR_ARG;
+  colreduce_kernel<float, float, true><<<cdiv(2 * C, 16), 1024, 0, as_stream(stream)>>>(partial, rows, 2 * C, dgamma, dbeta, C, 1.0f);
+  return launch_status();
+}

@@ -1,0 +1,454 @@
+// Fused FeedForward module (lid/conformer.py:153-171 with its PreNorm :81-89 and Scale(0.5) + residual :247-248,252-259) for the
+// model width d = 256, bf16 operands:
+//     xo = x + alpha * ( swish( LN(x) . W1^T + b1 ) . W2^T + b2 )
+// One workgroup (4 waves) owns 64 complete rows; a wave owns 16 of them for the whole kernel:
+//   * prologue: the wave normalises its rows straight into MFMA operand registers (lane (fr, fq) holds row fr, columns
+//     32*ks + 8*fq .. +7 of every 32-wide K step: 8 x bf16x8 = the A fragments of the up-projection), writes h / mean / rstd for
+//     the backward pass;
+//   * the hidden dimension is walked in chunks of 64 columns.  The chunk's W1 rows [64][256] and W2 columns [256][64] (32 KB each)
+//     arrive in LDS by global_load_lds (16 B per lane, no staging registers), one chunk ahead of the MFMAs, in two buffers;
+//   * up-projection of the chunk (32 MFMAs per wave), bias + Swish in registers, pre-activation and activation stored for the
+//     backward pass; issued "transposed" and with the W1 rows permuted in LDS, a lane's accumulators of two adjacent 16-column
+//     tiles are 8 CONSECUTIVE hidden columns of its row - i.e. packed to bf16 they ARE the A fragment of the down-projection:
+//     the [M][ff] activation never goes through LDS or HBM on its way to the second GEMM;
+//   * down-projection accumulates the chunk into 16 output tiles (64 f32 registers per lane); epilogue adds b2, scales, adds x.
+// LDS images are lane-linear per wave instruction (what global_load_lds writes); bank conflicts are avoided by permuting the
+// 16-byte chunks of a row on the SOURCE address and applying the same XOR on the fragment reads (cdna_hip_programming.md rule 21).
+// HBM traffic per row: x read twice (second time from L2), h + a + u + xo written once; the weights (1 MB) stream from L2 once
+// per workgroup.  Replaces lidk_layernorm_fwd + 2 x lidk_gemm_nt (three launches, u re-read, h re-read).
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+#define FFN_D 256
+#define FFN_BM 64
+#define FFN_CH 64
+#define FFN_BUF (2 * FFN_CH * FFN_D * 2)      // bytes of one chunk buffer: W1 rows + W2 columns
+
+struct FfnFwd {
+  const float* x; const bf16* h_in; const float* gamma; const float* beta; float eps;
+  const bf16* W1; const float* b1; const bf16* W2; const float* b2;
+  bf16* h; float* mean; float* rstd; bf16* a; bf16* u; float* xo;
+  float alpha; int M; int FF;
+};
+
+// LDS-DMA by inline asm: hipcc tracks a builtin global_load_lds as a pending LDS write and drains it (vmcnt(0)) in front of the
+// first LDS read it cannot prove disjoint - in the middle of the chunk the copy is meant to overlap.  Issued this way the compiler
+// does not see the copies; the kernel waits for them itself (vmcnt(0) + barrier at the top of a chunk).  lds_off: wave-uniform
+// byte offset of the wave instruction's 1 KB destination (M0), lane l lands at lds_off + 16 l.
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_off) : "memory");
+}
+
+__device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
+  bf16x8 r;
+  r[0] = (bf16)a.x; r[1] = (bf16)a.y; r[2] = (bf16)a.z; r[3] = (bf16)a.w;
+  r[4] = (bf16)b.x; r[5] = (bf16)b.y; r[6] = (bf16)b.z; r[7] = (bf16)b.w;
+  return r;
+}
+
+// chunk c of W1 / W2 -> LDS buffer at byte offset `buf` (this wave's 8 of the 64 wave instructions; wid is an SGPR value)
+__device__ __forceinline__ void ffn_stage(const bf16* __restrict__ W1, const bf16* __restrict__ W2, int FF, int c, unsigned buf,
+                                          int wid, int lane) {
+  // W1 rows: LDS row rho (512 B) holds global row n(rho) with its 16-byte chunks XOR-permuted by (rho & 15); rho -> n undoes the
+  // "pair" permutation that makes two adjacent accumulator tiles 8 consecutive columns
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rho = 8 * wid + 2 * i + (lane >> 5), p = lane & 31, cc = p ^ (rho & 15);
+    const int n = (rho & 32) + 8 * ((rho >> 2) & 3) + 4 * ((rho >> 4) & 1) + (rho & 3);
+    glds16(W1 + (size_t)(c * FFN_CH + n) * FFN_D + cc * 8, buf + (8 * wid + 2 * i) * 512);
+  }
+  // W2 columns: LDS row = output column (128 B), chunks XOR-permuted by ((row >> 1) & 7)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 32 * wid + 8 * i + (lane >> 3), p = lane & 7, cc = p ^ ((row >> 1) & 7);
+    glds16(W2 + (size_t)row * FF + c * FFN_CH + cc * 8, buf + FFN_CH * FFN_D * 2 + (32 * wid + 8 * i) * 128);
+  }
+}
+
+// 8 waves: wave (half = wid >> 2, rw = wid & 3) owns rows 16 rw .. + 15 of the workgroup's 64 and HALF of every chunk's hidden
+// columns (32 half .. + 31): its up-projection is 2 column tiles x 8 K steps, its down-projection the K = 32 slice of all 16 output
+// tiles that those hidden columns feed.  The two partial outputs of a row group meet once, after the last chunk, through LDS.
+// Two waves per SIMD, so one wave's LDS latency and barrier waits hide behind the other's MFMAs.
+template <bool LN_IN>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+ffn_fwd_kernel(FfnFwd p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];
+  float* lb1 = reinterpret_cast<float*>(ffn_smem + 2 * FFN_BUF);
+  float* lb2 = lb1 + p.FF;
+  const unsigned smem0 = (unsigned)(size_t)(lds_void_t*)ffn_smem;
+  const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), half = wid >> 2, rw = wid & 3;
+  const int m_raw = blockIdx.x * FFN_BM + 16 * rw + fr;
+  const bool m_ok = m_raw < p.M;
+  const int m = m_ok ? m_raw : p.M - 1;
+  const int NC = p.FF / FFN_CH;
+
+  for (int i = tid; i < p.FF / 4; i += 512) reinterpret_cast<float4*>(lb1)[i] = load4(p.b1 + 4 * i);
+  if (tid < FFN_D / 4) reinterpret_cast<float4*>(lb2)[tid] = load4(p.b2 + 4 * tid);
+  ffn_stage(p.W1, p.W2, p.FF, 0, smem0, wid, lane);
+
+  // ---- A fragments of the up-projection: LayerNorm of this lane's 64 row elements, or the ready-made h
+  bf16x8 hA[8];
+  if (LN_IN) {
+    float4 xv[16];
+    const float* xr = p.x + (size_t)m * FFN_D + 8 * fq;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { xv[2 * ks] = load4(xr + 32 * ks); xv[2 * ks + 1] = load4(xr + 32 * ks + 4); }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+    const float mu = s * (1.0f / FFN_D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float a = xv[i].x - mu, b = xv[i].y - mu, c = xv[i].z - mu, d = xv[i].w - mu;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+    const float rs = rsqrtf(q * (1.0f / FFN_D) + p.eps);
+    const bool writer = m_ok && half == 0;
+    if (fq == 0 && writer) { p.mean[m] = mu; p.rstd[m] = rs; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int col = 32 * ks + 8 * fq;
+      const float4 g0 = load4(p.gamma + col), g1 = load4(p.gamma + col + 4), b0 = load4(p.beta + col), b1 = load4(p.beta + col + 4);
+      float4 v0 = xv[2 * ks], v1 = xv[2 * ks + 1];
+      v0.x = (v0.x - mu) * rs * g0.x + b0.x; v0.y = (v0.y - mu) * rs * g0.y + b0.y;
+      v0.z = (v0.z - mu) * rs * g0.z + b0.z; v0.w = (v0.w - mu) * rs * g0.w + b0.w;
+      v1.x = (v1.x - mu) * rs * g1.x + b1.x; v1.y = (v1.y - mu) * rs * g1.y + b1.y;
+      v1.z = (v1.z - mu) * rs * g1.z + b1.z; v1.w = (v1.w - mu) * rs * g1.w + b1.w;
+      hA[ks] = pack_bf16x8(v0, v1);
+      if (p.h && writer) *reinterpret_cast<bf16x8*>(p.h + (size_t)m * FFN_D + col) = hA[ks];
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) hA[ks] = *reinterpret_cast<const bf16x8*>(p.h_in + (size_t)m * FFN_D + 32 * ks + 8 * fq);
+  }
+
+  f32x4 acc2[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses inside a chunk buffer: up-projection tile t (0/1) of this wave's half, K step ks; down-projection tile j
+  const int w1_lane = (32 * half + fr) * 512, w2_lane = FFN_CH * FFN_D * 2 + fr * 128 + (((4 * half + fq) ^ ((fr >> 1) & 7)) << 4);
+#define W1F(buf_, t_, ks_) (*reinterpret_cast<const bf16x8*>((buf_) + w1_lane + (t_) * (16 * 512) + (((4 * (ks_) + fq) ^ fr) << 4)))
+#define W2F(buf_, j_) (*reinterpret_cast<const bf16x8*>((buf_) + w2_lane + (j_) * (16 * 128)))
+
+  for (int c = 0; c < NC; ++c) {
+    // chunk c has landed (this wave's pieces: vmcnt; everybody's: barrier); the barrier also says every wave is done reading
+    // the other buffer (chunk c - 1), which the next stage overwrites
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c + 1 < NC) ffn_stage(p.W1, p.W2, p.FF, c + 1, smem0 + ((c + 1) & 1) * FFN_BUF, wid, lane);
+    const unsigned char* buf = ffn_smem + (c & 1) * FFN_BUF;
+
+    bf16x8 fa[8], fb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = W1F(buf, i & 1, i >> 1);            // K steps 0..3
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fb[i] = W1F(buf, i & 1, 4 + (i >> 1));      // K steps 4..7
+    f32x4 acc1[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc1[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], hA[i >> 1], acc1[i & 1], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = W2F(buf, i);                        // down-projection tiles 0..7
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc1[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], hA[4 + (i >> 1)], acc1[i & 1], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fb[i] = W2F(buf, 8 + i);                    // tiles 8..15
+
+    const int n = c * FFN_CH + 32 * half + 8 * fq;
+    const float4 ba = *reinterpret_cast<const float4*>(lb1 + n), bb = *reinterpret_cast<const float4*>(lb1 + n + 4);
+    float4 v0 = make_float4(acc1[0][0] + ba.x, acc1[0][1] + ba.y, acc1[0][2] + ba.z, acc1[0][3] + ba.w);
+    float4 v1 = make_float4(acc1[1][0] + bb.x, acc1[1][1] + bb.y, acc1[1][2] + bb.z, acc1[1][3] + bb.w);
+    if (p.a && m_ok) *reinterpret_cast<bf16x8*>(p.a + (size_t)m * p.FF + n) = pack_bf16x8(v0, v1);
+    v0.x *= sigmoidf_(v0.x); v0.y *= sigmoidf_(v0.y); v0.z *= sigmoidf_(v0.z); v0.w *= sigmoidf_(v0.w);
+    v1.x *= sigmoidf_(v1.x); v1.y *= sigmoidf_(v1.y); v1.z *= sigmoidf_(v1.z); v1.w *= sigmoidf_(v1.w);
+    const bf16x8 uA = pack_bf16x8(v0, v1);
+    if (p.u && m_ok) *reinterpret_cast<bf16x8*>(p.u + (size_t)m * p.FF + n) = uA;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], uA, acc2[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc2[8 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], uA, acc2[8 + i], 0, 0, 0);
+  }
+#undef W1F
+#undef W2F
+
+  // ---- the two halves of a row group exchange partial sums: half 0 finishes output tiles 0..7, half 1 tiles 8..15
+  // (register arrays are indexed by compile-time constants only: the two roles are two branches of a wave-uniform condition)
+  __syncthreads();                                     // chunk buffers are dead: reuse them ([wave][tile][lane] float4)
+  float4* xch = reinterpret_cast<float4*>(ffn_smem);
+  if (half == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xch[(wid * 8 + i) * 64 + lane] = make_float4(acc2[8 + i][0], acc2[8 + i][1], acc2[8 + i][2], acc2[8 + i][3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xch[(wid * 8 + i) * 64 + lane] = make_float4(acc2[i][0], acc2[i][1], acc2[i][2], acc2[i][3]);
+  }
+  __syncthreads();
+  if (!m_ok) return;
+  const int pw = wid ^ 4;
+  const float* xr = p.x + (size_t)m * FFN_D + 4 * fq + 128 * half;
+  float* orow = p.xo + (size_t)m * FFN_D + 4 * fq + 128 * half;
+  const float* bl = lb2 + 4 * fq + 128 * half;
+  f32x4 mine[8];
+  if (half == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mine[i] = acc2[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mine[i] = acc2[8 + i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 o2 = xch[(pw * 8 + i) * 64 + lane];
+    const float4 r = load4(xr + 16 * i);
+    const float4 b = *reinterpret_cast<const float4*>(bl + 16 * i);
+    float4 o;
+    o.x = r.x + p.alpha * (mine[i][0] + o2.x + b.x); o.y = r.y + p.alpha * (mine[i][1] + o2.y + b.y);
+    o.z = r.z + p.alpha * (mine[i][2] + o2.z + b.z); o.w = r.w + p.alpha * (mine[i][3] + o2.w + b.w);
+    store4(orow + 16 * i, o);
+  }
+}
+
+extern "C" int lidk_ffn_fwd_supported(int M, int d, int ff, int dtype) {
+  return dtype == LIDK_BF16 && d == FFN_D && M > 0 && ff >= FFN_CH && ff % FFN_CH == 0 && 2 * FFN_BUF + (ff + FFN_D) * 4 <= 160 * 1024;
+}
+
+extern "C" int lidk_ffn_fwd(const float* x, const void* h_in, const float* gamma, const float* beta, float eps, const void* W1,
+                            const float* b1, const void* W2, const float* b2, void* h, float* mean, float* rstd, void* a, void* u,
+                            float* xo, float alpha, int M, int d, int ff, int dtype, void* stream) {
+  if (!x || !W1 || !b1 || !W2 || !b2 || !xo) return LIDK_ERR_ARG;
+  if (!h_in && (!gamma || !beta || !mean || !rstd)) return LIDK_ERR_ARG;
+  if (!lidk_ffn_fwd_supported(M, d, ff, dtype)) return LIDK_ERR_UNSUPPORTED;
+  FfnFwd p{x, (const bf16*)h_in, gamma, beta, eps, (const bf16*)W1, b1, (const bf16*)W2, b2, (bf16*)h, mean, rstd, (bf16*)a,
+           (bf16*)u, xo, alpha, M, ff};
+  const int lds = 2 * FFN_BUF + (ff + FFN_D) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int grid = cdiv(M, FFN_BM);
+  if (h_in) ffn_fwd_kernel<false><<<grid, 512, lds, as_stream(stream)>>>(p);
+  else ffn_fwd_kernel<true><<<grid, 512, lds, as_stream(stream)>>>(p);
+  return launch_status();
+}
+
+// =====================================================================================================================
+// Backward of the same module, data path:  given dyT = alpha * d(loss)/d(xo) (T) and the saved pre-activation a,
+//     da = (dyT . W2) * swish'(a)            [M][ff]  (T, stored: operand of the weight gradients dW1 = da^T h, db1)
+//     dh = da . W1                           [M][256]
+//     dx = dres + LN'(dh; x, mean, rstd, gamma)   (f32) and dxT = dxT_scale * dx (T); per-workgroup (dgamma | dbeta) rows
+// Same decomposition as the forward kernel with the roles of the weights exchanged: W2T [ff][256] (row n = W2[:, n]) feeds the
+// first product, W1T [256][ff] (row j = W1[:, j]) the second; the chunk's [64][64] tile of a arrives by LDS-DMA beside them, so the
+// loop holds no register-destination load (hipcc would drain the DMA queue in front of its use).  The workgroup owns complete rows,
+// so the PreNorm's backward runs in the epilogue: dh never exists in HBM (LN_OUT = false writes dh instead, for the site whose
+// LayerNorm backward is fused with the neighbouring block's post_norm).  Replaces 2 x lidk_gemm_nt + lidk_layernorm_bwd.
+// =====================================================================================================================
+#define FFN_ATILE (FFN_BM * FFN_CH * 2)
+
+struct FfnBwd {
+  const bf16* dyT; const bf16* a; const bf16* W2T; const bf16* W1T; bf16* da;
+  const float* x; const float* mean; const float* rstd; const float* gamma; const float* dres;
+  float* dx; bf16* dxT; float dxT_scale; float* partial; bf16* dh;
+  int M; int FF;
+};
+
+template <bool LN_OUT>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+ffn_bwd_kernel(FfnBwd p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];
+  const unsigned smem0 = (unsigned)(size_t)(lds_void_t*)ffn_smem;
+  const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), half = wid >> 2, rw = wid & 3;
+  const int m0 = blockIdx.x * FFN_BM;
+  const int m_raw = m0 + 16 * rw + fr;
+  const bool m_ok = m_raw < p.M;
+  const int m = m_ok ? m_raw : p.M - 1;
+  const int NC = p.FF / FFN_CH;
+
+  // the chunk's tile of a: wave w copies rows 8 w .. + 7 (128 B each), 16-byte chunks XOR-permuted by (row & 7)
+  const int a_row = 8 * wid + (lane >> 3), a_cc = (lane & 7) ^ (a_row & 7);
+  const bf16* a_src = p.a + (size_t)min(m0 + a_row, p.M - 1) * p.FF + a_cc * 8;
+  auto stage = [&](int c, int b) __attribute__((always_inline)) {
+    ffn_stage(p.W2T, p.W1T, p.FF, c, smem0 + b * FFN_BUF, wid, lane);
+    glds16(a_src + c * FFN_CH, smem0 + 2 * FFN_BUF + b * FFN_ATILE + wid * 1024);
+  };
+  stage(0, 0);
+
+  bf16x8 dyA[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) dyA[ks] = *reinterpret_cast<const bf16x8*>(p.dyT + (size_t)m * FFN_D + 32 * ks + 8 * fq);
+
+  f32x4 acc2[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int w1_lane = (32 * half + fr) * 512, w2_lane = FFN_CH * FFN_D * 2 + fr * 128 + (((4 * half + fq) ^ ((fr >> 1) & 7)) << 4);
+  const int at_lane = (16 * rw + fr) * 128 + (((4 * half + fq) ^ (fr & 7)) << 4);
+#define W1F(buf_, t_, ks_) (*reinterpret_cast<const bf16x8*>((buf_) + w1_lane + (t_) * (16 * 512) + (((4 * (ks_) + fq) ^ fr) << 4)))
+#define W2F(buf_, j_) (*reinterpret_cast<const bf16x8*>((buf_) + w2_lane + (j_) * (16 * 128)))
+
+  for (int c = 0; c < NC; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c + 1 < NC) stage(c + 1, (c + 1) & 1);
+    const unsigned char* buf = ffn_smem + (c & 1) * FFN_BUF;
+
+    bf16x8 fa[8], fb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = W1F(buf, i & 1, i >> 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fb[i] = W1F(buf, i & 1, 4 + (i >> 1));
+    const bf16x8 av = *reinterpret_cast<const bf16x8*>(ffn_smem + 2 * FFN_BUF + (c & 1) * FFN_ATILE + at_lane);
+    f32x4 acc1[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc1[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], dyA[i >> 1], acc1[i & 1], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = W2F(buf, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc1[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], dyA[4 + (i >> 1)], acc1[i & 1], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fb[i] = W2F(buf, 8 + i);
+
+    float dv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float a = (float)av[i], sg = sigmoidf_(a);
+      dv[i] = acc1[i >> 2][i & 3] * (sg * (1.f + a * (1.f - sg)));
+    }
+    const bf16x8 daA = pack_bf16x8(make_float4(dv[0], dv[1], dv[2], dv[3]), make_float4(dv[4], dv[5], dv[6], dv[7]));
+    if (m_ok) *reinterpret_cast<bf16x8*>(p.da + (size_t)m * p.FF + c * FFN_CH + 32 * half + 8 * fq) = daA;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], daA, acc2[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc2[8 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], daA, acc2[8 + i], 0, 0, 0);
+  }
+#undef W1F
+#undef W2F
+
+  // ---- halves of a row group exchange partial sums: half h keeps output tiles 8 h .. 8 h + 7 (columns 128 h + 16 i + 4 fq + r)
+  __syncthreads();
+  float4* xch = reinterpret_cast<float4*>(ffn_smem);
+  if (half == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xch[(wid * 8 + i) * 64 + lane] = make_float4(acc2[8 + i][0], acc2[8 + i][1], acc2[8 + i][2], acc2[8 + i][3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xch[(wid * 8 + i) * 64 + lane] = make_float4(acc2[i][0], acc2[i][1], acc2[i][2], acc2[i][3]);
+  }
+  __syncthreads();
+  const int pw = wid ^ 4;
+  float4 dhv[8];
+  if (half == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dhv[i] = make_float4(acc2[i][0], acc2[i][1], acc2[i][2], acc2[i][3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dhv[i] = make_float4(acc2[8 + i][0], acc2[8 + i][1], acc2[8 + i][2], acc2[8 + i][3]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 o = xch[(pw * 8 + i) * 64 + lane];
+    dhv[i].x += o.x; dhv[i].y += o.y; dhv[i].z += o.z; dhv[i].w += o.w;
+  }
+  const int col0 = 128 * half + 4 * fq;               // this lane's columns: col0 + 16 i + (0..3)
+  if (!LN_OUT) {
+    if (m_ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) store4(p.dh + (size_t)m * FFN_D + col0 + 16 * i, dhv[i]);
+    }
+    return;
+  }
+
+  // ---- LayerNorm backward of the complete rows
+  const float mu = p.mean[m], rs = p.rstd[m];
+  float4 xh[8], g[8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 xv = load4(p.x + (size_t)m * FFN_D + col0 + 16 * i), gm = load4(p.gamma + col0 + 16 * i);
+    xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
+    g[i].x = dhv[i].x * gm.x; g[i].y = dhv[i].y * gm.y; g[i].z = dhv[i].z * gm.z; g[i].w = dhv[i].w * gm.w;
+    s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+    s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+  }
+  s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+  __syncthreads();                                   // everybody has read the exchanged tiles: the area is free again
+  float2* rsum = reinterpret_cast<float2*>(ffn_smem);                 // [wave][16 rows]
+  if (fq == 0) rsum[wid * 16 + fr] = make_float2(s1, s2);
+  // per-column (dgamma | dbeta) terms of this workgroup's 64 rows: [row][256] each, behind the row sums
+  float* dgs = reinterpret_cast<float*>(ffn_smem + 1024);
+  float* dbs = dgs + FFN_BM * FFN_D;
+  const int lrow = 16 * rw + fr;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float4 tg = make_float4(0.f, 0.f, 0.f, 0.f), tb = tg;
+    if (m_ok) {
+      tg = make_float4(dhv[i].x * xh[i].x, dhv[i].y * xh[i].y, dhv[i].z * xh[i].z, dhv[i].w * xh[i].w);
+      tb = dhv[i];
+    }
+    *reinterpret_cast<float4*>(dgs + lrow * FFN_D + col0 + 16 * i) = tg;
+    *reinterpret_cast<float4*>(dbs + lrow * FFN_D + col0 + 16 * i) = tb;
+  }
+  __syncthreads();
+  {
+    const float2 o = rsum[pw * 16 + fr];
+    const float m1 = (s1 + o.x) * (1.0f / FFN_D), m2 = (s2 + o.y) * (1.0f / FFN_D);
+    if (m_ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float4 o4;
+        o4.x = rs * (g[i].x - m1 - xh[i].x * m2); o4.y = rs * (g[i].y - m1 - xh[i].y * m2);
+        o4.z = rs * (g[i].z - m1 - xh[i].z * m2); o4.w = rs * (g[i].w - m1 - xh[i].w * m2);
+        const size_t at = (size_t)m * FFN_D + col0 + 16 * i;
+        if (p.dres) { const float4 r = load4(p.dres + at); o4.x += r.x; o4.y += r.y; o4.z += r.z; o4.w += r.w; }
+        if (p.dx) store4(p.dx + at, o4);
+        if (p.dxT) {
+          o4.x *= p.dxT_scale; o4.y *= p.dxT_scale; o4.z *= p.dxT_scale; o4.w *= p.dxT_scale;
+          store4(p.dxT + at, o4);
+        }
+      }
+    }
+  }
+  // column sums over the 64 rows: thread t -> (which = t >> 8, column = t & 255)
+  {
+    const float* src = (tid >> 8) ? dbs : dgs;
+    const int col = tid & 255;
+    float t = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < FFN_BM; ++r) t += src[r * FFN_D + col];
+    p.partial[(size_t)blockIdx.x * 2 * FFN_D + tid] = t;
+  }
+}
+
+extern "C" int lidk_ffn_bwd_partial_rows(int M) { return cdiv(M, FFN_BM); }
+
+extern "C" int lidk_ffn_bwd(const void* dyT, const void* a, const void* W2T, int ldw2t, const void* W1T, int ldw1t, void* da,
+                            const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
+                            void* dxT, float dxT_scale, float* partial, void* dh, int M, int d, int ff, int dtype, void* stream) {
+  if (!dyT || !a || !W2T || !W1T || !da) return LIDK_ERR_ARG;
+  if (!dh && (!x || !mean || !rstd || !gamma || !partial || (!dx && !dxT))) return LIDK_ERR_ARG;
+  if (!lidk_ffn_fwd_supported(M, d, ff, dtype) || ldw2t != FFN_D || ldw1t != ff) return LIDK_ERR_UNSUPPORTED;
+  FfnBwd p{(const bf16*)dyT, (const bf16*)a, (const bf16*)W2T, (const bf16*)W1T, (bf16*)da, x, mean, rstd, gamma, dres, dx, (bf16*)dxT,
+           dxT_scale, partial, (bf16*)dh, M, ff};
+  const int lds = 2 * FFN_BUF + 2 * FFN_ATILE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int grid = cdiv(M, FFN_BM);
+  if (dh) ffn_bwd_kernel<false><<<grid, 512, lds, as_stream(stream)>>>(p);
+  else ffn_bwd_kernel<true><<<grid, 512, lds, as_stream(stream)>>>(p);
+  return launch_status();
+}

@@ -322,6 +322,39 @@ def ln_gemm_nt(x, gamma, beta, B, out, h=None, mean=None, rstd=None, bias=None, 
     return out
 
 
+def ffn_fwd_supported(M, d, ff, dtype):
+    return bool(lib().lidk_ffn_fwd_supported(M, d, ff, dtype_code(dtype)))
+
+
+def ffn_fwd(x, W1, b1, W2, b2, xo, gamma=None, beta=None, h_in=None, h=None, mean=None, rstd=None, a=None, u=None, alpha=0.5,
+            eps=1e-5):
+    """xo = x + alpha * (swish(LN(x) W1^T + b1) W2^T + b2) in one launch (d = 256, bf16 operands); see lidk_ffn_fwd."""
+    M, d = x.shape
+    ff = W1.shape[0]
+    check(lib().lidk_ffn_fwd(_p(x), _pv(h_in), _p(gamma), _p(beta), eps, _pv(W1), _p(b1), _pv(W2), _p(b2), _pv(h), _p(mean),
+                             _p(rstd), _pv(a), _pv(u), _p(xo), alpha, M, d, ff, _code(W1), _stream()), "ffn_fwd")
+    return xo
+
+
+def ffn_bwd_partial_rows(M):
+    return lib().lidk_ffn_bwd_partial_rows(M)
+
+
+def ffn_bwd(dyT, a, W1T, W2T, da, x=None, mean=None, rstd=None, gamma=None, dres=None, dx=None, dxT=None, dxT_scale=1.0,
+            partial=None, dh=None):
+    """da = (dyT W2) * swish'(a); dh = da W1; then the PreNorm backward (dx / dxT / partial dgamma-dbeta rows), or dh itself when
+    ``dh`` is given; see lidk_ffn_bwd.  W1T [256, ff], W2T [ff, 256]: the transposed operand copies."""
+    M, d = dyT.shape
+    ff = a.shape[1]
+    check(lib().lidk_ffn_bwd(_p(dyT), _p(a), _pv(W2T), W2T.stride(0), _pv(W1T), W1T.stride(0), _p(da), _p(x), _p(mean), _p(rstd),
+                             _p(gamma), _p(dres), _p(dx), _p(dxT), dxT_scale, _p(partial), _p(dh), M, d, ff, _code(dyT), _stream()),
+          "ffn_bwd")
+
+
+def layernorm_param_grads_rows(partial, rows, C, dgamma, dbeta):
+    check(lib().lidk_layernorm_param_grads_rows(_p(partial), rows, C, _p(dgamma), _p(dbeta), _stream()), "layernorm_param_grads_rows")
+
+
 def gemm_tn(X, Y, C, colsum=None, alpha=1.0, splitk=1, M=None, N1=None, N2=None):
     """C[N1,N2] (f32) += alpha * X[:M,:N1]^T @ Y[:M,:N2]; colsum[N1] (f32, optional) += alpha * X.sum(0)."""
     M = X.shape[0] if M is None else M

@@ -1,0 +1,169 @@
+"""Fused FeedForward kernels (csrc/ffn.hip) against a torch fp32 computation of lid/conformer.py:153-171 (+ PreNorm :81-89, Scale 0.5 and
+the residual add :252-259) on the bf16-rounded operands the kernel sees, and against the three-launch sequence they replace."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lidk import ops
+from lidk import _lib as L
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def _case(M, ff, seed, d=256):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, d, generator=g) * 1.5 + 0.2
+    gamma, beta = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    W1, b1 = torch.randn(ff, d, generator=g) / 16, 0.1 * torch.randn(ff, generator=g)
+    W2, b2 = torch.randn(d, ff, generator=g) / 32, 0.1 * torch.randn(d, generator=g)
+    return x, gamma, beta, W1, b1, W2, b2
+
+
+def _ref_fwd(x, gamma, beta, W1, b1, W2, b2, alpha=0.5):
+    """fp32 reference on bf16-rounded operands; h, a, u rounded where the kernel rounds them (operands of the next MFMA)."""
+    h = F.layer_norm(x, (x.shape[1],), gamma, beta, 1e-5).to(BF).float()
+    a = h @ W1.to(BF).float().t() + b1
+    u = (a * torch.sigmoid(a)).to(BF).float()
+    xo = x + alpha * (u @ W2.to(BF).float().t() + b2)
+    mean = x.mean(1)
+    rstd = (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    return h, a, u, xo, mean, rstd
+
+
+@pytest.mark.parametrize("M,ff", [(9664, 1024), (64, 64), (200, 256), (151, 1024), (1000, 3072)])
+@pytest.mark.parametrize("ln_in", [True, False])
+def test_ffn_fwd_matches_torch_and_saves_what_the_backward_needs(M, ff, ln_in):
+    x, gamma, beta, W1, b1, W2, b2 = _case(M, ff, seed=M + ff)
+    assert ops.ffn_fwd_supported(M, 256, ff, BF)
+    xd = x.to(DEV)
+    W1d, W2d = W1.to(DEV, BF), W2.to(DEV, BF)
+    e = lambda *s, dt=BF: torch.full(s, float("nan"), device=DEV, dtype=dt)
+    h, a, u, xo, mean, rstd = e(M, 256), e(M, ff), e(M, ff), e(M, 256, dt=torch.float32), e(M, dt=torch.float32), e(M, dt=torch.float32)
+    rh, ra, ru, rxo, rmean, rrstd = _ref_fwd(x, gamma, beta, W1, b1, W2, b2)
+    if ln_in:
+        ops.ffn_fwd(xd, W1d, b1.to(DEV), W2d, b2.to(DEV), xo, gamma=gamma.to(DEV), beta=beta.to(DEV), h=h, mean=mean, rstd=rstd, a=a, u=u)
+        assert float((mean.cpu() - rmean).abs().max()) <= 2e-6 and float(((rstd.cpu() - rrstd) / rrstd).abs().max()) <= 2e-6
+        dh = (h.float().cpu() - rh).abs()
+        assert float(dh.max()) <= 2 ** -6 * float(rh.abs().max()) and float(dh.mean()) <= 1e-4, (float(dh.max()), float(dh.mean()))
+    else:           # h from the fused LayerNorm pair of the previous block: LayerNorm is skipped, mean / rstd / h untouched
+        ops.ffn_fwd(xd, W1d, b1.to(DEV), W2d, b2.to(DEV), xo, h_in=rh.to(DEV, BF), a=a, u=u)
+        assert bool(torch.isnan(mean).all()) and bool(torch.isnan(h.float()).all())
+    torch.cuda.synchronize()
+    # a, u: bf16 roundings of fp32 values that agree to ~1e-5 -> at most one bf16 ulp apart on a handful of elements
+    for name, got, ref in (("a", a, ra.to(BF).float()), ("u", u, ru)):
+        d = (got.float().cpu() - ref).abs()
+        lim = 2 ** -7 * ref.abs() + 1e-6 + (0.03 if ln_in else 0.0)        # ln_in: h itself may differ by a bf16 ulp
+        assert bool((d <= lim).all()), (name, float(d.max()))
+        assert float(d.mean()) <= (2e-3 if ln_in else 1e-4), (name, float(d.mean()))
+    d = (xo.cpu() - rxo).abs()
+    assert float(d.max()) <= (2e-2 if ln_in else 2e-3) and float(d.mean()) <= (1e-3 if ln_in else 1e-4), (float(d.max()), float(d.mean()))
+
+
+def test_ffn_fwd_equals_the_three_launch_sequence():
+    """Same inputs through lidk_layernorm_fwd + 2 x lidk_gemm_nt: the saved tensors and the output agree to bf16 rounding."""
+    M, ff = 9664, 1024
+    x, gamma, beta, W1, b1, W2, b2 = _case(M, ff, seed=7)
+    xd, gd, bd = x.to(DEV), gamma.to(DEV), beta.to(DEV)
+    W1d, W2d, b1d, b2d = W1.to(DEV, BF), W2.to(DEV, BF), b1.to(DEV), b2.to(DEV)
+    e = lambda *s, dt=BF: torch.empty(s, device=DEV, dtype=dt)
+    h0, a0, u0, xo0, mean0, rstd0 = e(M, 256), e(M, ff), e(M, ff), e(M, 256, dt=torch.float32), e(M, dt=torch.float32), e(M, dt=torch.float32)
+    ops.layernorm_fwd(xd, gd, bd, yT=h0, mean=mean0, rstd=rstd0)
+    ops.gemm_nt(h0, W1d, u0, bias=b1d, act=L.ACT_SWISH, out2=a0)
+    ops.gemm_nt(u0, W2d, xo0, bias=b2d, alpha=0.5, res=xd)
+    h1, a1, u1, xo1, mean1, rstd1 = e(M, 256), e(M, ff), e(M, ff), e(M, 256, dt=torch.float32), e(M, dt=torch.float32), e(M, dt=torch.float32)
+    ops.ffn_fwd(xd, W1d, b1d, W2d, b2d, xo1, gamma=gd, beta=bd, h=h1, mean=mean1, rstd=rstd1, a=a1, u=u1)
+    torch.cuda.synchronize()
+    assert float((mean0 - mean1).abs().max()) <= 2e-6
+    assert float((h0.float() - h1.float()).abs().max()) <= 2 ** -6 * float(h0.float().abs().max())
+    assert float((xo0 - xo1).abs().mean()) <= 1e-3 and float((xo0 - xo1).abs().max()) <= 3e-2
+    # with the SAME h the two paths must agree to accumulation order
+    ops.ffn_fwd(xd, W1d, b1d, W2d, b2d, xo1, h_in=h0, a=a1, u=u1)
+    torch.cuda.synchronize()
+    assert float((a0.float() - a1.float()).abs().max()) <= 2 ** -7 * float(a0.float().abs().max())
+    assert float((xo0 - xo1).abs().max()) <= 2e-3
+
+
+def test_ffn_fwd_refuses_other_widths():
+    assert not ops.ffn_fwd_supported(128, 768, 3072, BF)
+    assert not ops.ffn_fwd_supported(128, 256, 1000, BF)
+    assert not ops.ffn_fwd_supported(128, 256, 1024, torch.float32)
+
+
+def _ref_bwd(dyT, a, W1, W2, x, gamma, dres):
+    """fp32 autograd-free restatement on the bf16-rounded operands: da (rounded to bf16 where the kernel rounds it), dh, LN'."""
+    sg = torch.sigmoid(a)
+    da = ((dyT @ W2.to(BF).float()) * (sg * (1 + a * (1 - sg)))).to(BF).float()
+    dh = da @ W1.to(BF).float()
+    mean = x.mean(1, keepdim=True)
+    rstd = (x.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    xh = (x - mean) * rstd
+    g = dh * gamma
+    dx = dres + rstd * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+    return da, dh, dx, (dh * xh).sum(0), dh.sum(0), mean[:, 0], rstd[:, 0]
+
+
+@pytest.mark.parametrize("M,ff", [(9664, 1024), (64, 64), (200, 256), (151, 1024)])
+def test_ffn_bwd_matches_torch(M, ff):
+    x, gamma, beta, W1, b1, W2, b2 = _case(M, ff, seed=3 * M + ff)
+    g = torch.Generator().manual_seed(M)
+    dyT = (0.5 * torch.randn(M, 256, generator=g)).to(BF).float()
+    a = (torch.randn(M, ff, generator=g) * 1.5).to(BF).float()
+    dres = torch.randn(M, 256, generator=g)
+    rda, rdh, rdx, rdg, rdb, mean, rstd = _ref_bwd(dyT, a, W1, W2, x, gamma, dres)
+    W1T, W2T = W1.t().contiguous().to(DEV, BF), W2.t().contiguous().to(DEV, BF)
+    e = lambda *s, dt=BF: torch.full(s, float("nan"), device=DEV, dtype=dt)
+    da, dx, dxT = e(M, ff), e(M, 256, dt=torch.float32), e(M, 256)
+    rows = ops.ffn_bwd_partial_rows(M)
+    partial = e(rows * 512, dt=torch.float32)
+    ops.ffn_bwd(dyT.to(DEV, BF), a.to(DEV, BF), W1T, W2T, da, x=x.to(DEV), mean=mean.to(DEV), rstd=rstd.to(DEV), gamma=gamma.to(DEV),
+                dres=dres.to(DEV), dx=dx, dxT=dxT, dxT_scale=0.5, partial=partial)
+    dg, db = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+    ops.layernorm_param_grads_rows(partial, rows, 256, dg, db)
+    torch.cuda.synchronize()
+    d = (da.float().cpu() - rda).abs()
+    assert bool((d <= 2 ** -7 * rda.abs() + 1e-6).all()) and float(d.mean()) <= 1e-4, float(d.max())
+    scale = float(rdx.abs().max())
+    d = (dx.cpu() - rdx).abs()
+    assert float(d.max()) <= 2e-3 * scale and float(d.mean()) <= 1e-4 * scale, (float(d.max()), float(d.mean()), scale)
+    d = (dxT.float().cpu() - 0.5 * rdx).abs()
+    assert float(d.max()) <= 2 ** -7 * 0.5 * scale
+    for name, got, ref in (("dgamma", dg, rdg), ("dbeta", db, rdb)):
+        assert float((got.cpu() - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-3, name
+    # dh-output form (the LayerNorm backward is left to the caller)
+    dh = e(M, 256)
+    ops.ffn_bwd(dyT.to(DEV, BF), a.to(DEV, BF), W1T, W2T, da, dh=dh)
+    torch.cuda.synchronize()
+    d = (dh.float().cpu() - rdh).abs()
+    assert float(d.max()) <= 2 ** -7 * float(rdh.abs().max()) + 1e-5
+
+
+def test_ffn_bwd_equals_the_launch_sequence_it_replaces():
+    M, ff = 9664, 1024
+    x, gamma, beta, W1, b1, W2, b2 = _case(M, ff, seed=11)
+    g = torch.Generator().manual_seed(5)
+    dyT = (0.5 * torch.randn(M, 256, generator=g)).to(DEV, BF)
+    a = (torch.randn(M, ff, generator=g) * 1.5).to(DEV, BF)
+    dres, xd, gd = torch.randn(M, 256, generator=g).to(DEV), x.to(DEV), gamma.to(DEV)
+    mean, rstd = xd.mean(1), (xd.var(1, unbiased=False) + 1e-5).rsqrt()
+    W1T, W2T = W1.t().contiguous().to(DEV, BF), W2.t().contiguous().to(DEV, BF)
+    e = lambda *s, dt=BF: torch.empty(s, device=DEV, dtype=dt)
+    da0, dh0, dx0, dxT0 = e(M, ff), e(M, 256), e(M, 256, dt=torch.float32), e(M, 256)
+    part0 = e(max(L.LN_PARTIAL_BLOCKS * 2 * 1024, L.LN_BWD_BLOCKS * 512), dt=torch.float32)
+    dg0, db0 = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+    ops.gemm_nt(dyT, W2T, da0, act=L.ACT_SWISH_GRAD, aux=a, N=ff, K=256)
+    ops.gemm_nt(da0, W1T, dh0, N=256, K=ff)
+    ops.layernorm_bwd(dh0, xd, mean, rstd, gd, part0, dres=dres, dx=dx0, dxT=dxT0, dxT_scale=1.0, dgamma=dg0, dbeta=db0)
+    da1, dx1, dxT1 = e(M, ff), e(M, 256, dt=torch.float32), e(M, 256)
+    rows = ops.ffn_bwd_partial_rows(M)
+    part1 = e(rows * 512, dt=torch.float32)
+    dg1, db1 = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+    ops.ffn_bwd(dyT, a, W1T, W2T, da1, x=xd, mean=mean, rstd=rstd, gamma=gd, dres=dres, dx=dx1, dxT=dxT1, dxT_scale=1.0, partial=part1)
+    ops.layernorm_param_grads_rows(part1, rows, 256, dg1, db1)
+    torch.cuda.synchronize()
+    assert float((da0.float() - da1.float()).abs().max()) <= 2 ** -7 * float(da0.float().abs().max())
+    # the sequence rounds dh to bf16 between the GEMM and the LayerNorm backward; the fused kernel keeps it in f32
+    scale = float(dx0.abs().max())
+    assert float((dx0 - dx1).abs().max()) <= 1e-2 * scale and float((dx0 - dx1).abs().mean()) <= 5e-4 * scale
+    assert float((dg0 - dg1).abs().max()) <= 5e-3 * float(dg0.abs().max()) and float((db0 - db1).abs().max()) <= 5e-3 * float(db0.abs().max())
