@@ -17,8 +17,14 @@
 // HBM traffic per row: x read twice (second time from L2), h + a + u + xo written once; the weights (1 MB) stream from L2 once
 // per workgroup.  Replaces lidk_layernorm_fwd + 2 x lidk_gemm_nt (three launches, u re-read, h re-read).
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+
+// LIDK_FFN_DBG (ablations, wrong results): 1 no a / u / da stores, 2 no weight DMA after chunk 0, 16 no chunk loop.  LIDK_FFN_ROT=0:
+// lock-step chunk order.
+static int ffn_dbg() { static const int v = getenv("LIDK_FFN_DBG") ? atoi(getenv("LIDK_FFN_DBG")) : 0; return v; }
+static int ffn_rot() { static const int v = getenv("LIDK_FFN_ROT") ? atoi(getenv("LIDK_FFN_ROT")) : 1; return v; }
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 #define FFN_D 256
@@ -30,7 +36,7 @@ struct FfnFwd {
   const float* x; const bf16* h_in; const float* gamma; const float* beta; float eps;
   const bf16* W1; const float* b1; const bf16* W2; const float* b2;
   bf16* h; float* mean; float* rstd; bf16* a; bf16* u; float* xo;
-  float alpha; int M; int FF;
+  float alpha; int M; int FF; int rot; int dbg;
 };
 
 // LDS-DMA by inline asm: hipcc tracks a builtin global_load_lds as a pending LDS write and drains it (vmcnt(0)) in front of the
@@ -69,35 +75,76 @@ __device__ __forceinline__ void ffn_stage(const bf16* __restrict__ W1, const bf1
   }
 }
 
+// one 1 KB wave instruction of a small f32 vector (bias, LayerNorm weights) -> LDS, unpermuted
+__device__ __forceinline__ void ffn_stage_vec(const float* __restrict__ v, int n_floats, unsigned lds_off, int k, int lane) {
+  const int i = min(k * 256 + lane * 4, n_floats - 4);          // past the end: re-read the last 16 bytes into the image's padding
+  glds16(v + i, lds_off + k * 1024);
+}
+
+// the workgroup's 64 rows of the f32 residual stream -> LDS [64][1 KB], 16-byte chunks XOR-permuted by (row & 15); wave w copies
+// rows 8 w .. 8 w + 7, one row per wave instruction
+__device__ __forceinline__ void ffn_stage_rows(const float* __restrict__ x, int m0, int M, unsigned lds_off, int wid, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = 8 * wid + i;
+    glds16(x + (size_t)min(m0 + row, M - 1) * FFN_D + ((lane ^ (row & 15)) << 2), lds_off + row * 1024);
+  }
+}
+
 // 8 waves: wave (half = wid >> 2, rw = wid & 3) owns rows 16 rw .. + 15 of the workgroup's 64 and HALF of every chunk's hidden
 // columns (32 half .. + 31): its up-projection is 2 column tiles x 8 K steps, its down-projection the K = 32 slice of all 16 output
 // tiles that those hidden columns feed.  The two partial outputs of a row group meet once, after the last chunk, through LDS.
 // Two waves per SIMD, so one wave's LDS latency and barrier waits hide behind the other's MFMAs.
+// Latency chain of a workgroup (all of them run in lock-step, there is no second workgroup on the CU to hide behind): ONE HBM round
+// trip in the prologue - the row loads are issued first, the small vectors (b1, b2, gamma, beta) and chunk 0 follow by LDS-DMA - and
+// none in the epilogue: the residual rows the epilogue adds come back by LDS-DMA during the last chunk, into the free chunk buffer.
 template <bool LN_IN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ffn_fwd_kernel(FfnFwd p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];
   float* lb1 = reinterpret_cast<float*>(ffn_smem + 2 * FFN_BUF);
-  float* lb2 = lb1 + p.FF;
+  const int FFp = (p.FF + 255) & ~255;                        // the b1 image is padded to whole 1 KB wave instructions
+  float* lb2 = lb1 + FFp;
+  float* lgam = lb2 + FFN_D;
+  float* lbet = lgam + FFN_D;
   const unsigned smem0 = (unsigned)(size_t)(lds_void_t*)ffn_smem;
   const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), half = wid >> 2, rw = wid & 3;
-  const int m_raw = blockIdx.x * FFN_BM + 16 * rw + fr;
+  const int m0 = blockIdx.x * FFN_BM;
+  const int m_raw = m0 + 16 * rw + fr;
   const bool m_ok = m_raw < p.M;
   const int m = m_ok ? m_raw : p.M - 1;
-  const int NC = p.FF / FFN_CH;
+  const int NC = (p.dbg & 16) ? 0 : p.FF / FFN_CH;
+  // Chunk order is rotated per workgroup (the sums over chunks commute): the ~19 workgroups sharing an XCD stream different chunks
+  // at any moment, so a chunk is usually already in the XCD's L2 when a workgroup asks for it.
+  const int rot = p.rot ? (blockIdx.x >> 3) % (p.FF / FFN_CH) : 0;
+  auto chunk_of = [&](int c) __attribute__((always_inline)) { const int t = c + rot; return t >= NC ? t - NC : t; };
 
-  for (int i = tid; i < p.FF / 4; i += 512) reinterpret_cast<float4*>(lb1)[i] = load4(p.b1 + 4 * i);
-  if (tid < FFN_D / 4) reinterpret_cast<float4*>(lb2)[tid] = load4(p.b2 + 4 * tid);
-  ffn_stage(p.W1, p.W2, p.FF, 0, smem0, wid, lane);
-
-  // ---- A fragments of the up-projection: LayerNorm of this lane's 64 row elements, or the ready-made h
+  // ---- register loads first: this lane's 64 row elements (or the ready-made h fragments)
   bf16x8 hA[8];
+  float4 xv[16];
   if (LN_IN) {
-    float4 xv[16];
     const float* xr = p.x + (size_t)m * FFN_D + 8 * fq;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) { xv[2 * ks] = load4(xr + 32 * ks); xv[2 * ks + 1] = load4(xr + 32 * ks + 4); }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) hA[ks] = *reinterpret_cast<const bf16x8*>(p.h_in + (size_t)m * FFN_D + 32 * ks + 8 * fq);
+  }
+  // ---- small vectors and chunk 0 by LDS-DMA
+  {
+    const int nb1 = FFp / 256;                                    // wave instructions for b1; then b2, gamma, beta: one each
+    const unsigned vec0 = smem0 + 2 * FFN_BUF;
+    for (int k = wid; k < nb1; k += 8) ffn_stage_vec(p.b1, p.FF, vec0, k, lane);
+    if (wid == (nb1 & 7)) ffn_stage_vec(p.b2, FFN_D, vec0 + FFp * 4, 0, lane);
+    if (LN_IN) {
+      if (wid == ((nb1 + 1) & 7)) ffn_stage_vec(p.gamma, FFN_D, vec0 + FFp * 4 + 1024, 0, lane);
+      if (wid == ((nb1 + 2) & 7)) ffn_stage_vec(p.beta, FFN_D, vec0 + FFp * 4 + 2048, 0, lane);
+    }
+  }
+  if (NC > 0) ffn_stage(p.W1, p.W2, p.FF, chunk_of(0), smem0, wid, lane);
+
+  if (LN_IN) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
@@ -113,10 +160,13 @@ ffn_fwd_kernel(FfnFwd p) {
     const float rs = rsqrtf(q * (1.0f / FFN_D) + p.eps);
     const bool writer = m_ok && half == 0;
     if (fq == 0 && writer) { p.mean[m] = mu; p.rstd[m] = rs; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // gamma / beta (and everything else staged so far) are in LDS
+    __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int col = 32 * ks + 8 * fq;
-      const float4 g0 = load4(p.gamma + col), g1 = load4(p.gamma + col + 4), b0 = load4(p.beta + col), b1 = load4(p.beta + col + 4);
+      const float4 g0 = *reinterpret_cast<const float4*>(lgam + col), g1 = *reinterpret_cast<const float4*>(lgam + col + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(lbet + col), b1 = *reinterpret_cast<const float4*>(lbet + col + 4);
       float4 v0 = xv[2 * ks], v1 = xv[2 * ks + 1];
       v0.x = (v0.x - mu) * rs * g0.x + b0.x; v0.y = (v0.y - mu) * rs * g0.y + b0.y;
       v0.z = (v0.z - mu) * rs * g0.z + b0.z; v0.w = (v0.w - mu) * rs * g0.w + b0.w;
@@ -125,9 +175,6 @@ ffn_fwd_kernel(FfnFwd p) {
       hA[ks] = pack_bf16x8(v0, v1);
       if (p.h && writer) *reinterpret_cast<bf16x8*>(p.h + (size_t)m * FFN_D + col) = hA[ks];
     }
-  } else {
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) hA[ks] = *reinterpret_cast<const bf16x8*>(p.h_in + (size_t)m * FFN_D + 32 * ks + 8 * fq);
   }
 
   f32x4 acc2[16];
@@ -144,8 +191,13 @@ ffn_fwd_kernel(FfnFwd p) {
     // the other buffer (chunk c - 1), which the next stage overwrites
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (c + 1 < NC) ffn_stage(p.W1, p.W2, p.FF, c + 1, smem0 + ((c + 1) & 1) * FFN_BUF, wid, lane);
+    if (c + 1 < NC) {
+      if (!(p.dbg & 2)) ffn_stage(p.W1, p.W2, p.FF, chunk_of(c + 1), smem0 + ((c + 1) & 1) * FFN_BUF, wid, lane);
+    } else {
+      ffn_stage_rows(p.x, m0, p.M, smem0 + ((c + 1) & 1) * FFN_BUF, wid, lane);      // the epilogue's residual rows
+    }
     const unsigned char* buf = ffn_smem + (c & 1) * FFN_BUF;
+    const int cc = chunk_of(c);
 
     bf16x8 fa[8], fb[8];
 #pragma unroll
@@ -162,15 +214,15 @@ ffn_fwd_kernel(FfnFwd p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) fb[i] = W2F(buf, 8 + i);                    // tiles 8..15
 
-    const int n = c * FFN_CH + 32 * half + 8 * fq;
+    const int n = cc * FFN_CH + 32 * half + 8 * fq;
     const float4 ba = *reinterpret_cast<const float4*>(lb1 + n), bb = *reinterpret_cast<const float4*>(lb1 + n + 4);
     float4 v0 = make_float4(acc1[0][0] + ba.x, acc1[0][1] + ba.y, acc1[0][2] + ba.z, acc1[0][3] + ba.w);
     float4 v1 = make_float4(acc1[1][0] + bb.x, acc1[1][1] + bb.y, acc1[1][2] + bb.z, acc1[1][3] + bb.w);
-    if (p.a && m_ok) *reinterpret_cast<bf16x8*>(p.a + (size_t)m * p.FF + n) = pack_bf16x8(v0, v1);
+    if (p.a && m_ok && !(p.dbg & 1)) *reinterpret_cast<bf16x8*>(p.a + (size_t)m * p.FF + n) = pack_bf16x8(v0, v1);
     v0.x *= sigmoidf_(v0.x); v0.y *= sigmoidf_(v0.y); v0.z *= sigmoidf_(v0.z); v0.w *= sigmoidf_(v0.w);
     v1.x *= sigmoidf_(v1.x); v1.y *= sigmoidf_(v1.y); v1.z *= sigmoidf_(v1.z); v1.w *= sigmoidf_(v1.w);
     const bf16x8 uA = pack_bf16x8(v0, v1);
-    if (p.u && m_ok) *reinterpret_cast<bf16x8*>(p.u + (size_t)m * p.FF + n) = uA;
+    if (p.u && m_ok && !(p.dbg & 1)) *reinterpret_cast<bf16x8*>(p.u + (size_t)m * p.FF + n) = uA;
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], uA, acc2[i], 0, 0, 0);
 #pragma unroll
@@ -178,11 +230,16 @@ ffn_fwd_kernel(FfnFwd p) {
   }
 #undef W1F
 #undef W2F
+  if (NC == 0) ffn_stage_rows(p.x, m0, p.M, smem0 + FFN_BUF, wid, lane);       // (ablation only)
 
   // ---- the two halves of a row group exchange partial sums: half 0 finishes output tiles 0..7, half 1 tiles 8..15
-  // (register arrays are indexed by compile-time constants only: the two roles are two branches of a wave-uniform condition)
-  __syncthreads();                                     // chunk buffers are dead: reuse them ([wave][tile][lane] float4)
-  float4* xch = reinterpret_cast<float4*>(ffn_smem);
+  // (register arrays are indexed by compile-time constants only: the two roles are two branches of a wave-uniform condition).
+  // The residual rows sit in the buffer the last chunk did NOT use; the exchange goes through the one it did.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int xb = (NC & 1) ? 1 : (NC == 0 ? 1 : 0);               // buffer holding the rows: (NC - 1 + 1) & 1
+  float4* xch = reinterpret_cast<float4*>(ffn_smem + (1 - xb) * FFN_BUF);
+  const unsigned char* xt = ffn_smem + xb * FFN_BUF;
   if (half == 0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) xch[(wid * 8 + i) * 64 + lane] = make_float4(acc2[8 + i][0], acc2[8 + i][1], acc2[8 + i][2], acc2[8 + i][3]);
@@ -193,9 +250,9 @@ ffn_fwd_kernel(FfnFwd p) {
   __syncthreads();
   if (!m_ok) return;
   const int pw = wid ^ 4;
-  const float* xr = p.x + (size_t)m * FFN_D + 4 * fq + 128 * half;
   float* orow = p.xo + (size_t)m * FFN_D + 4 * fq + 128 * half;
   const float* bl = lb2 + 4 * fq + 128 * half;
+  const unsigned char* xrow = xt + (16 * rw + fr) * 1024;
   f32x4 mine[8];
   if (half == 0) {
 #pragma unroll
@@ -207,7 +264,7 @@ ffn_fwd_kernel(FfnFwd p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const float4 o2 = xch[(pw * 8 + i) * 64 + lane];
-    const float4 r = load4(xr + 16 * i);
+    const float4 r = *reinterpret_cast<const float4*>(xrow + (((32 * half + 4 * i + fq) ^ fr) << 4));
     const float4 b = *reinterpret_cast<const float4*>(bl + 16 * i);
     float4 o;
     o.x = r.x + p.alpha * (mine[i][0] + o2.x + b.x); o.y = r.y + p.alpha * (mine[i][1] + o2.y + b.y);
@@ -217,7 +274,7 @@ ffn_fwd_kernel(FfnFwd p) {
 }
 
 extern "C" int lidk_ffn_fwd_supported(int M, int d, int ff, int dtype) {
-  return dtype == LIDK_BF16 && d == FFN_D && M > 0 && ff >= FFN_CH && ff % FFN_CH == 0 && 2 * FFN_BUF + (ff + FFN_D) * 4 <= 160 * 1024;
+  return dtype == LIDK_BF16 && d == FFN_D && M > 0 && ff >= FFN_CH && ff % FFN_CH == 0 && 2 * FFN_BUF + (((ff + 255) & ~255) + 3 * FFN_D) * 4 <= 160 * 1024;
 }
 
 extern "C" int lidk_ffn_fwd(const float* x, const void* h_in, const float* gamma, const float* beta, float eps, const void* W1,
@@ -227,8 +284,8 @@ extern "C" int lidk_ffn_fwd(const float* x, const void* h_in, const float* gamma
   if (!h_in && (!gamma || !beta || !mean || !rstd)) return LIDK_ERR_ARG;
   if (!lidk_ffn_fwd_supported(M, d, ff, dtype)) return LIDK_ERR_UNSUPPORTED;
   FfnFwd p{x, (const bf16*)h_in, gamma, beta, eps, (const bf16*)W1, b1, (const bf16*)W2, b2, (bf16*)h, mean, rstd, (bf16*)a,
-           (bf16*)u, xo, alpha, M, ff};
-  const int lds = 2 * FFN_BUF + (ff + FFN_D) * 4;
+           (bf16*)u, xo, alpha, M, ff, ffn_rot(), ffn_dbg()};
+  const int lds = 2 * FFN_BUF + (((ff + 255) & ~255) + 3 * FFN_D) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -258,7 +315,7 @@ struct FfnBwd {
   const bf16* dyT; const bf16* a; const bf16* W2T; const bf16* W1T; bf16* da;
   const float* x; const float* mean; const float* rstd; const float* gamma; const float* dres;
   float* dx; bf16* dxT; float dxT_scale; float* partial; bf16* dh;
-  int M; int FF;
+  int M; int FF; int rot; int dbg;
 };
 
 template <bool LN_OUT>
@@ -273,6 +330,13 @@ ffn_bwd_kernel(FfnBwd p) {
   const bool m_ok = m_raw < p.M;
   const int m = m_ok ? m_raw : p.M - 1;
   const int NC = p.FF / FFN_CH;
+  const int rot = p.rot ? (blockIdx.x >> 3) % NC : 0;  // rotated chunk order, as in the forward kernel
+  auto chunk_of = [&](int c) __attribute__((always_inline)) { const int t = c + rot; return t >= NC ? t - NC : t; };
+
+  // register loads first (one HBM round trip in the prologue)
+  bf16x8 dyA[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) dyA[ks] = *reinterpret_cast<const bf16x8*>(p.dyT + (size_t)m * FFN_D + 32 * ks + 8 * fq);
 
   // the chunk's tile of a: wave w copies rows 8 w .. + 7 (128 B each), 16-byte chunks XOR-permuted by (row & 7)
   const int a_row = 8 * wid + (lane >> 3), a_cc = (lane & 7) ^ (a_row & 7);
@@ -281,11 +345,7 @@ ffn_bwd_kernel(FfnBwd p) {
     ffn_stage(p.W2T, p.W1T, p.FF, c, smem0 + b * FFN_BUF, wid, lane);
     glds16(a_src + c * FFN_CH, smem0 + 2 * FFN_BUF + b * FFN_ATILE + wid * 1024);
   };
-  stage(0, 0);
-
-  bf16x8 dyA[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) dyA[ks] = *reinterpret_cast<const bf16x8*>(p.dyT + (size_t)m * FFN_D + 32 * ks + 8 * fq);
+  stage(chunk_of(0), 0);
 
   f32x4 acc2[16];
 #pragma unroll
@@ -299,7 +359,12 @@ ffn_bwd_kernel(FfnBwd p) {
   for (int c = 0; c < NC; ++c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (c + 1 < NC) stage(c + 1, (c + 1) & 1);
+    if (c + 1 < NC) {
+      if (!(p.dbg & 2)) stage(chunk_of(c + 1), (c + 1) & 1);
+    } else if (LN_OUT) {
+      ffn_stage_rows(p.x, m0, p.M, smem0 + ((c + 1) & 1) * FFN_BUF, wid, lane);   // the LayerNorm backward's rows of x
+    }
+    const int cc = chunk_of(c);
     const unsigned char* buf = ffn_smem + (c & 1) * FFN_BUF;
 
     bf16x8 fa[8], fb[8];
@@ -325,7 +390,7 @@ ffn_bwd_kernel(FfnBwd p) {
       dv[i] = acc1[i >> 2][i & 3] * (sg * (1.f + a * (1.f - sg)));
     }
     const bf16x8 daA = pack_bf16x8(make_float4(dv[0], dv[1], dv[2], dv[3]), make_float4(dv[4], dv[5], dv[6], dv[7]));
-    if (m_ok) *reinterpret_cast<bf16x8*>(p.da + (size_t)m * p.FF + c * FFN_CH + 32 * half + 8 * fq) = daA;
+    if (m_ok && !(p.dbg & 1)) *reinterpret_cast<bf16x8*>(p.da + (size_t)m * p.FF + cc * FFN_CH + 32 * half + 8 * fq) = daA;
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], daA, acc2[i], 0, 0, 0);
 #pragma unroll
@@ -334,9 +399,25 @@ ffn_bwd_kernel(FfnBwd p) {
 #undef W1F
 #undef W2F
 
-  // ---- halves of a row group exchange partial sums: half h keeps output tiles 8 h .. 8 h + 7 (columns 128 h + 16 i + 4 fq + r)
+  // ---- halves of a row group exchange partial sums: half h keeps output tiles 8 h .. 8 h + 7 (columns 128 h + 16 i + 4 fq + r).
+  // The rows of x sit in the buffer the last chunk did not use; the exchange goes through the one it did.  The epilogue's HBM
+  // operands (dres, gamma, mean, rstd) are requested before the barriers so that their latency hides behind the exchange.
+  const int col0 = 128 * half + 4 * fq;               // this lane's columns: col0 + 16 i + (0..3)
+  float4 rv[8], gmv[8];
+  float mu = 0.f, rs = 0.f;
+  if (LN_OUT) {
+    mu = p.mean[m]; rs = p.rstd[m];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      rv[i] = p.dres ? load4(p.dres + (size_t)m * FFN_D + col0 + 16 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gmv[i] = load4(p.gamma + col0 + 16 * i);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  float4* xch = reinterpret_cast<float4*>(ffn_smem);
+  const int xb = NC & 1;
+  float4* xch = reinterpret_cast<float4*>(ffn_smem + (1 - xb) * FFN_BUF);
+  const unsigned char* xrow = ffn_smem + xb * FFN_BUF + (16 * rw + fr) * 1024;
   if (half == 0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) xch[(wid * 8 + i) * 64 + lane] = make_float4(acc2[8 + i][0], acc2[8 + i][1], acc2[8 + i][2], acc2[8 + i][3]);
@@ -359,7 +440,6 @@ ffn_bwd_kernel(FfnBwd p) {
     const float4 o = xch[(pw * 8 + i) * 64 + lane];
     dhv[i].x += o.x; dhv[i].y += o.y; dhv[i].z += o.z; dhv[i].w += o.w;
   }
-  const int col0 = 128 * half + 4 * fq;               // this lane's columns: col0 + 16 i + (0..3)
   if (!LN_OUT) {
     if (m_ok) {
 #pragma unroll
@@ -369,12 +449,11 @@ ffn_bwd_kernel(FfnBwd p) {
   }
 
   // ---- LayerNorm backward of the complete rows
-  const float mu = p.mean[m], rs = p.rstd[m];
   float4 xh[8], g[8];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const float4 xv = load4(p.x + (size_t)m * FFN_D + col0 + 16 * i), gm = load4(p.gamma + col0 + 16 * i);
+    const float4 xv = *reinterpret_cast<const float4*>(xrow + (((32 * half + 4 * i + fq) ^ fr) << 4)), gm = gmv[i];
     xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
     g[i].x = dhv[i].x * gm.x; g[i].y = dhv[i].y * gm.y; g[i].z = dhv[i].z * gm.z; g[i].w = dhv[i].w * gm.w;
     s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
@@ -410,7 +489,7 @@ ffn_bwd_kernel(FfnBwd p) {
         o4.x = rs * (g[i].x - m1 - xh[i].x * m2); o4.y = rs * (g[i].y - m1 - xh[i].y * m2);
         o4.z = rs * (g[i].z - m1 - xh[i].z * m2); o4.w = rs * (g[i].w - m1 - xh[i].w * m2);
         const size_t at = (size_t)m * FFN_D + col0 + 16 * i;
-        if (p.dres) { const float4 r = load4(p.dres + at); o4.x += r.x; o4.y += r.y; o4.z += r.z; o4.w += r.w; }
+        o4.x += rv[i].x; o4.y += rv[i].y; o4.z += rv[i].z; o4.w += rv[i].w;
         if (p.dx) store4(p.dx + at, o4);
         if (p.dxT) {
           o4.x *= p.dxT_scale; o4.y *= p.dxT_scale; o4.z *= p.dxT_scale; o4.w *= p.dxT_scale;
@@ -439,7 +518,7 @@ extern "C" int lidk_ffn_bwd(const void* dyT, const void* a, const void* W2T, int
   if (!dh && (!x || !mean || !rstd || !gamma || !partial || (!dx && !dxT))) return LIDK_ERR_ARG;
   if (!lidk_ffn_fwd_supported(M, d, ff, dtype) || ldw2t != FFN_D || ldw1t != ff) return LIDK_ERR_UNSUPPORTED;
   FfnBwd p{(const bf16*)dyT, (const bf16*)a, (const bf16*)W2T, (const bf16*)W1T, (bf16*)da, x, mean, rstd, gamma, dres, dx, (bf16*)dxT,
-           dxT_scale, partial, (bf16*)dh, M, ff};
+           dxT_scale, partial, (bf16*)dh, M, ff, ffn_rot(), ffn_dbg()};
   const int lds = 2 * FFN_BUF + 2 * FFN_ATILE;
   static bool attr_set = false;
   if (!attr_set) {

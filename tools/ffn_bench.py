@@ -70,6 +70,6 @@ print(f"backward dgrad x 2 + LN bwd (4 launches incl. colreduce) {usb:7.1f} us")
 if hasattr(ops, "ffn_bwd"):
     def bwd1(i):
         s = S[i]
-        ops.ffn_bwd(s["dyT"], s["a"], s["W1T"], s["W2T"], s["x"], s["mean"], s["rstd"], s["gam"], s["dres"], s["da"], s["dx"], s["dxT"],
-                    partial)
+        ops.ffn_bwd(s["dyT"], s["a"], s["W1T"], s["W2T"], s["da"], x=s["x"], mean=s["mean"], rstd=s["rstd"], gamma=s["gam"],
+                    dres=s["dres"], dx=s["dx"], dxT=s["dxT"], partial=partial)
     print(f"backward fused lidk_ffn_bwd          {t(bwd1):7.1f} us")
