@@ -509,7 +509,24 @@ class Engine:
             self.k.layernorm_fwd(x, P["ln_w"], P["ln_b"], yT=h, mean=mean, rstd=rstd)
             self.k.gemm_nt(h, W, out, **epi)
 
+    def _ffn_fused(self, M: int, ff: int) -> bool:
+        """The whole FeedForward module as one launch forward and one backward (csrc/ffn.hip: d = 256, bf16; LIDK_FFN_FUSED=0 restores
+        the LayerNorm / GEMM / GEMM sequences)."""
+        key = ("ffn", M, ff)
+        ok = self._split_ok.get(key)
+        if ok is None:
+            ok = self._split_ok[key] = bool(self._hip and hasattr(self.k, "ffn_fwd") and _os_env("LIDK_FFN_FUSED", "1") == "1"
+                                            and self.k.ffn_fwd_supported(M, self.cfg.d, ff, self.act_dtype))
+        return ok
+
     def _ff_fwd(self, x, P, h, a, u, xo, mean, rstd, ln_done: bool = False):
+        if self._ffn_fused(x.shape[0], a.shape[1]):
+            if ln_done:                  # h / mean / rstd were written by the previous block's fused LayerNorm pair
+                self.k.ffn_fwd(x, P["w1"][0], P["b1"], P["w2"][0], P["b2"], xo, h_in=h, a=a, u=u, alpha=0.5)
+            else:
+                self.k.ffn_fwd(x, P["w1"][0], P["b1"], P["w2"][0], P["b2"], xo, gamma=P["ln_w"], beta=P["ln_b"], h=h, mean=mean,
+                               rstd=rstd, a=a, u=u, alpha=0.5)
+            return
         self._ln_gemm(x, P, P["w1"][0], u, h, mean, rstd, ln_done=ln_done, bias=P["b1"], act=L.ACT_SWISH, out2=a)
         self.k.gemm_nt(u, P["w2"][0], xo, bias=P["b2"], alpha=0.5, res=x)
 
@@ -716,13 +733,30 @@ class Engine:
         PreNorm's backward and that block's post_norm backward run as one launch: dx (f32) -> w.dxa, 0.5*dx (T) ->
         S_prev.dyTs[0], partial rows of both LayerNorms into their own buffers; dx_out is not written."""
         M, d, ff = w.M, self.cfg.d, a.shape[1]
+        lnp_rows = w.__dict__.setdefault("_lnp_rows", {})       # partial-row count of the sites whose rows came from lidk_ffn_bwd
         if wg:
             self._wgrad(w, dyT, u, P["dw2"], d, ff, P["db2"])
         da = da_buf if da_buf.shape[1] == ff else da_buf.view(-1)[:M * ff].view(M, ff)
-        self.k.gemm_nt(dyT, P["w2"][1], da, act=L.ACT_SWISH_GRAD, aux=a, N=ff, K=d)
-        if wg:
-            self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
-        self.k.gemm_nt(da, P["w1"][1], w.dh, N=d, K=ff)
+        if self._ffn_fused(M, ff):
+            # both data-gradient products (and, unless this PreNorm's backward is paired with the next block's post_norm, the
+            # LayerNorm backward too) in one launch; the partial (dgamma | dbeta) rows are one per 64-row workgroup
+            rows = self.k.ffn_bwd_partial_rows(M)
+            lnp_rows[id(lnp)] = rows if fuse is None else 0
+            if fuse is None:
+                self.k.ffn_bwd(dyT, a, P["w1"][1], P["w2"][1], da, x=x_in, mean=mean, rstd=rstd, gamma=P["ln_w"], dres=dx_res,
+                               dx=dx_out, dxT=dxT_out, dxT_scale=dxT_scale, partial=lnp)
+                if wg:
+                    self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
+                    self.k.layernorm_param_grads_rows(lnp, rows, d, P["dln_w"], P["dln_b"])
+                return
+            self.k.ffn_bwd(dyT, a, P["w1"][1], P["w2"][1], da, dh=w.dh)
+            if wg:
+                self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
+        else:
+            self.k.gemm_nt(dyT, P["w2"][1], da, act=L.ACT_SWISH_GRAD, aux=a, N=ff, K=d)
+            if wg:
+                self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
+            self.k.gemm_nt(da, P["w1"][1], w.dh, N=d, K=ff)
         if fuse is not None:
             pbb, post, Sp, forked = fuse
             if forked:          # S_prev's buffers are still read by the weight gradients running on the second stream
@@ -814,8 +848,13 @@ class Engine:
         sites = [(1, bp.ff2), (2, bp.conv), (3, bp.attn), (4, bp.ff1)]
         if post_norm:
             sites.append((0, dict(dln_w=bp.post["dw"], dln_b=bp.post["db"])))
+        lnp_rows = w.__dict__.get("_lnp_rows", {})
         for i, P in sites:
-            self.k.layernorm_param_grads(S.lnp[i], M, d, P["dln_w"], P["dln_b"])
+            rows = lnp_rows.get(id(S.lnp[i]), 0)
+            if rows:
+                self.k.layernorm_param_grads_rows(S.lnp[i], rows, d, P["dln_w"], P["dln_b"])
+            else:
+                self.k.layernorm_param_grads(S.lnp[i], M, d, P["dln_w"], P["dln_b"])
         C, A = bp.conv, bp.attn
         ci, K = C["dw"].shape[0], C["dw"].shape[2]
         inner = bp.heads * bp.dh
