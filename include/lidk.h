@@ -117,6 +117,10 @@ int lidk_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
 int lidk_layernorm_param_grads(const float* partial, int M, int C, float* dgamma, float* dbeta, void* stream);
 /* Same finaliser for `rows` partial rows of (dgamma | dbeta) [2*C] written by a kernel with its own grid (lidk_ffn_bwd). */
 int lidk_layernorm_param_grads_rows(const float* partial, int rows, int C, float* dgamma, float* dbeta, void* stream);
+/* n finalisers in one launch: descs = device array of n records {const float* partial; float* dgamma; float* dbeta; int rows; int C;}
+ * (lidk_ln_param_grads_desc_bytes() bytes each, C equal in all records); sums are bit-identical to the single launches. */
+int lidk_ln_param_grads_desc_bytes(void);
+int lidk_layernorm_param_grads_grouped(const void* descs, int n, int C, void* stream);
 /* Two LayerNorms in a row (C <= 256): post_norm of ConformerBlock i followed by the first FeedForward PreNorm of block i + 1
  * (lid/conformer.py:252-259, 153-171).  y1 = LN1(x) f32, y2 = LN2(y1) in T, statistics of both; one pass over x. */
 int lidk_layernorm2_fwd(const float* x, const float* g1, const float* b1, float* y1, float* mean1, float* rstd1, const float* g2,

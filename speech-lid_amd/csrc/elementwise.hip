@@ -624,6 +624,40 @@ extern "C" int lidk_layernorm_param_grads(const float* partial, int M, int C, fl
   return launch_status();
 }
 
+// Several finalisers in one launch (a ConformerBlock has five LayerNorms: five 5 us launches on the weight-gradient stream
+// otherwise).  descs: device array of n records; record i reduces rows_i partial rows of (dgamma | dbeta) [2*C].
+struct LnPgDesc { const float* partial; float* dgamma; float* dbeta; int rows; int C; };
+__global__ void __launch_bounds__(1024)
+ln_param_grads_grouped_kernel(const LnPgDesc* __restrict__ descs) {
+  __shared__ float red[16][64];
+  const LnPgDesc e = descs[blockIdx.y];
+  const int ncols = 2 * e.C;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane >> 4;
+  const int c = blockIdx.x * 16 + (lane & 15);
+  float acc = 0.f;
+  if (c < ncols) {
+#pragma unroll 4
+    for (int p = w * 4 + sub; p < e.rows; p += 64) acc += e.partial[(size_t)p * ncols + c];
+  }
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && lane < 16 && c < ncols) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s += red[i][q * 16 + lane];             // same order as colreduce_kernel: bit-identical sums
+    float* dst = (c < e.C) ? e.dgamma + c : e.dbeta + (c - e.C);
+    *dst += s;
+  }
+}
+extern "C" int lidk_ln_param_grads_desc_bytes(void) { return (int)sizeof(LnPgDesc); }
+extern "C" int lidk_layernorm_param_grads_grouped(const void* descs, int n, int C, void* stream) {
+  if (!descs || n <= 0 || C <= 0) return LIDK_ERR_ARG;
+  ln_param_grads_grouped_kernel<<<dim3(cdiv(2 * C, 16), n), 1024, 0, as_stream(stream)>>>((const LnPgDesc*)descs);
+  return launch_status();
+}
+
 extern "C" int lidk_layernorm_param_grads_rows(const float* partial, int rows, int C, float* dgamma, float* dbeta, void* stream) {
   if (!partial || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAX_VEC || (!dgamma && !dbeta)) return LIDK_ERR_ARG;
   colreduce_kernel<float, float, true><<<cdiv(2 * C, 16), 1024, 0, as_stream(stream)>>>(partial, rows, 2 * C, dgamma, dbeta, C, 1.0f);

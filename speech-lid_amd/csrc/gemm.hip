@@ -941,13 +941,18 @@ struct TnDesc {
 };
 template <bool FULL>
 __global__ void __launch_bounds__(256)
-gemm_tn_grouped_kernel(const TnDesc* __restrict__ descs, int n_desc) {
-  const int item = xcd_tile(blockIdx.x, gridDim.x);
-  int g = 0;
-  while (g + 1 < n_desc && item >= descs[g + 1].item0) ++g;
-  const TnDesc d = descs[g];
-  gemm_tn_tile<64, 64, FULL>(d.X, d.ldx, d.Y, d.ldy, d.C, d.ldc, d.colsum, d.M, d.N1, d.N2, d.mchunk, d.alpha, item - d.item0,
-                             d.nsplit > 1);
+gemm_tn_grouped_kernel(const TnDesc* __restrict__ descs, int n_desc, int total_items) {
+  // grid == total_items: one item per workgroup.  A smaller grid (LIDK_WGRAD_GRID) walks the items with a stride: the launch then
+  // occupies a bounded share of every CU for longer, leaving room for the data-gradient chain it runs beside.
+  for (int it = blockIdx.x; it < total_items; it += gridDim.x) {
+    const int item = xcd_tile(it, total_items);
+    int g = 0;
+    while (g + 1 < n_desc && item >= descs[g + 1].item0) ++g;
+    const TnDesc d = descs[g];
+    gemm_tn_tile<64, 64, FULL>(d.X, d.ldx, d.Y, d.ldy, d.C, d.ldc, d.colsum, d.M, d.N1, d.N2, d.mchunk, d.alpha, item - d.item0,
+                               d.nsplit > 1);
+    __syncthreads();                  // the tile's LDS staging area is reused by the next item
+  }
 }
 
 extern "C" int lidk_gemm_tn_desc_bytes(void) { return (int)sizeof(TnDesc); }
@@ -958,8 +963,10 @@ extern "C" int lidk_gemm_tn_desc_bytes(void) { return (int)sizeof(TnDesc); }
 extern "C" int lidk_gemm_tn_grouped(const void* descs, int n_desc, int total_items, int full, void* stream) {
   if (!descs || n_desc <= 0 || total_items <= 0) return LIDK_ERR_ARG;
   hipStream_t s = as_stream(stream);
-  if (full) gemm_tn_grouped_kernel<true><<<total_items, 256, 0, s>>>((const TnDesc*)descs, n_desc);
-  else gemm_tn_grouped_kernel<false><<<total_items, 256, 0, s>>>((const TnDesc*)descs, n_desc);
+  static const int cap = getenv("LIDK_WGRAD_GRID") ? atoi(getenv("LIDK_WGRAD_GRID")) : 0;      // 0: one workgroup per item
+  const int grid = cap > 0 && cap < total_items ? cap : total_items;
+  if (full) gemm_tn_grouped_kernel<true><<<grid, 256, 0, s>>>((const TnDesc*)descs, n_desc, total_items);
+  else gemm_tn_grouped_kernel<false><<<grid, 256, 0, s>>>((const TnDesc*)descs, n_desc, total_items);
   return launch_status();
 }
 

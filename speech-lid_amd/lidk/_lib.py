@@ -53,6 +53,8 @@ SIGNATURES = {
     "lidk_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_layernorm_param_grads": (_I, [_P, _I, _I, _P, _P, _P]),
     "lidk_layernorm_param_grads_rows": (_I, [_P, _I, _I, _P, _P, _P]),
+    "lidk_ln_param_grads_desc_bytes": (_I, []),
+    "lidk_layernorm_param_grads_grouped": (_I, [_P, _I, _I, _P]),
     "lidk_layernorm2_fwd": (_I, [_P] * 11 + [_I, _I, _F, _I, _P]),
     "lidk_layernorm2_bwd": (_I, [_P] * 12 + [_F, _P, _P, _I, _I, _I, _P]),
     "lidk_gemm_nt": (_I, [C.POINTER(GemmArgs), _I, _P]),

@@ -355,6 +355,31 @@ def layernorm_param_grads_rows(partial, rows, C, dgamma, dbeta):
     check(lib().lidk_layernorm_param_grads_rows(_p(partial), rows, C, _p(dgamma), _p(dbeta), _stream()), "layernorm_param_grads_rows")
 
 
+class _LnPgDesc(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("rows", C.c_int), ("C", C.c_int)]
+
+
+def build_ln_param_group(entries):
+    """Descriptor table for layernorm_param_grads_grouped.  entries: list of (partial, rows, C, dgamma, dbeta); raw pointers inside."""
+    if lib().lidk_ln_param_grads_desc_bytes() != C.sizeof(_LnPgDesc):
+        raise LidkError("LnPgDesc layout mismatch between ops.py and liblidk.so")
+    arr = (_LnPgDesc * len(entries))()
+    for i, (partial, rows, Cn, dg, db) in enumerate(entries):
+        arr[i].partial, arr[i].dgamma, arr[i].dbeta, arr[i].rows, arr[i].C = _p(partial), _p(dg), _p(db), rows, Cn
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(entries[0][0].device), len(entries), entries[0][2]
+
+
+def layernorm_param_grads_grouped(group):
+    table, n, Cn = group
+    check(lib().lidk_layernorm_param_grads_grouped(_p(table), n, Cn, _stream()), "layernorm_param_grads_grouped")
+
+
+def layernorm_bwd_partial_rows(M):
+    """Partial rows lidk_layernorm_bwd / lidk_layernorm2_bwd write for M rows (what lidk_layernorm_param_grads assumes)."""
+    return min(-(-M // 4), L.LN_BWD_BLOCKS)
+
+
 def gemm_tn(X, Y, C, colsum=None, alpha=1.0, splitk=1, M=None, N1=None, N2=None):
     """C[N1,N2] (f32) += alpha * X[:M,:N1]^T @ Y[:M,:N2]; colsum[N1] (f32, optional) += alpha * X.sum(0)."""
     M = X.shape[0] if M is None else M

@@ -167,3 +167,21 @@ def test_ffn_bwd_equals_the_launch_sequence_it_replaces():
     scale = float(dx0.abs().max())
     assert float((dx0 - dx1).abs().max()) <= 1e-2 * scale and float((dx0 - dx1).abs().mean()) <= 5e-4 * scale
     assert float((dg0 - dg1).abs().max()) <= 5e-3 * float(dg0.abs().max()) and float((db0 - db1).abs().max()) <= 5e-3 * float(db0.abs().max())
+
+
+def test_grouped_layernorm_param_grads_equal_the_single_launches():
+    """lidk_layernorm_param_grads_grouped: five finalisers (mixed row counts) in one launch, bit-identical to the separate ones."""
+    g = torch.Generator().manual_seed(3)
+    M, Cn = 9664, 256
+    rows = [ops.layernorm_bwd_partial_rows(M), ops.ffn_bwd_partial_rows(M), 1024, 151, 7]
+    parts = [torch.randn(r * 2 * Cn, generator=g).to(DEV) for r in rows]
+    dg0 = [torch.randn(Cn, generator=g).to(DEV) for _ in rows]
+    db0 = [torch.randn(Cn, generator=g).to(DEV) for _ in rows]
+    dg1, db1 = [t.clone() for t in dg0], [t.clone() for t in db0]
+    for p, r, a, b in zip(parts, rows, dg0, db0):
+        ops.layernorm_param_grads_rows(p, r, Cn, a, b)
+    grp = ops.build_ln_param_group([(p, r, Cn, a, b) for p, r, a, b in zip(parts, rows, dg1, db1)])
+    ops.layernorm_param_grads_grouped(grp)
+    torch.cuda.synchronize()
+    for a, b in zip(dg0 + db0, dg1 + db1):
+        assert torch.equal(a, b)

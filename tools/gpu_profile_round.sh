@@ -9,5 +9,5 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --cavg-steps 0 --fit-epochs 0 $BENCH_ARGS > gpurun_out/prof.log 2>&1; echo "prof rc=$?"
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/kernel_stats.csv; head -12 gpurun_out/kernel_stats.csv | cut -c1-160
 t=$(find gpurun_out/prof -name "*kernel_trace.csv" | head -1)
-if [ -n "$t" ] && [ -f tools/timeline_busy.py ]; then python3 tools/timeline_busy.py "$t" > gpurun_out/timeline_busy.txt 2>&1; tail -6 gpurun_out/timeline_busy.txt; fi
+if [ -n "$t" ] && [ -f tools/timeline_busy.py ]; then python3 tools/timeline_busy.py "$t" gpurun_out/step_timeline.txt > gpurun_out/timeline_busy.txt 2>&1; tail -6 gpurun_out/timeline_busy.txt; fi
 rm -rf gpurun_out/prof

@@ -31,6 +31,18 @@ def main(path):
         spans.append((t1 - t0) / 1e6); unions.append(u / 1e6); sums.append(sum(byq.values()) / 1e6); mains.append(max(byq.values()) / 1e6)
     n = len(spans)
     med = lambda v: sorted(v)[len(v) // 2]
+    if len(sys.argv) > 2:                                  # one steady-state step, kernel by kernel: start offset, duration, queue
+        st = len(ends) * 3 // 4
+        seg = rows[ends[st] + 1:ends[st + 1] + 1]
+        t0 = int(seg[0]["Start_Timestamp"])
+        qs = sorted({r["Queue_Id"] for r in seg})
+        with open(sys.argv[2], "w") as f:
+            last_end = {q: t0 for q in qs}
+            for r in seg:
+                a, b, q = int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"]
+                f.write(f"{(a - t0) / 1e3:9.1f} us  {(b - a) / 1e3:7.1f} us  q{qs.index(q)}  gap {(a - last_end[q]) / 1e3:6.1f}  "
+                        f"{r['Kernel_Name'].split('(')[0][:70]}\n")
+                last_end[q] = b
     print(f"{n} steps: span {med(spans):.3f} ms, union-busy {med(unions):.3f} ms ({100 * med(unions) / med(spans):.1f} %), "
           f"sum of kernel times {med(sums):.3f} ms, busiest queue {med(mains):.3f} ms")
 
