@@ -341,21 +341,26 @@ def _replay_ms(calls, reps=9):
 
 
 def roofline(trainer, batches, step_fn):
-    """The dominant kernel (gemm_nt: every Linear / 1x1 conv forward and its data gradient), the weight-gradient GEMM
-    (gemm_tn) and the feature path, measured live and WITHOUT any calibration constant: one training step runs through the
-    eager launch path with every launch of these kernels recorded (operands are the step's own workspace buffers); the
-    recorded launches of a kind are then captured into ONE hipGraph, back-to-back in step order, and that graph is replayed
-    between two HIP events on its stream: average launch = replay time / launches.  The figure includes the gap between
-    consecutive kernel nodes (it can only under-state the kernel); the launch-weighted average of the same kernels in the
-    committed rocprofv3 --kernel-trace --stats summary of this command is printed beside it (``rocprof_avg_us``).
-    With K = 256..1024 these GEMMs sit below the machine balance (about 150 FLOP per algorithmic byte against
-    2500 TF/s / 8 TB/s = 312), so the roofline that bounds them is HBM: achieved = algorithmic bytes (operands read once,
-    outputs written once) / measured time.  The MFMA rate of the same launches is reported beside it."""
+    """The step's three big kernel families - gemm_nt (Linear / 1x1 conv forward and data gradients), the fused FeedForward
+    kernels (ffn_fwd / ffn_bwd: LayerNorm + both projections + residual, and their data gradients + LayerNorm backward) and the
+    grouped weight-gradient GEMM (gemm_tn_grouped) - plus the feature path, measured live and WITHOUT any calibration constant:
+    one training step runs through the eager launch path with every launch of these kernels recorded (operands are the step's
+    own workspace buffers); the recorded launches of a family are then captured into ONE hipGraph, back-to-back in step order,
+    and that graph is replayed between two HIP events on its stream: average launch = replay time / launches.  The figure
+    includes the gap between consecutive kernel nodes (it can only under-state the kernel); the launch-weighted average of the
+    same kernels in the committed rocprofv3 --kernel-trace --stats summary of this command is printed beside it.
+    The headline object describes the family with the most device time per step (``family_ms_per_step`` lists all three).
+    Every one of them sits below the machine balance (100-160 FLOP per algorithmic byte against 2500 TF/s / 8 TB/s = 312), so
+    the roofline that bounds them is HBM: achieved = algorithmic bytes (operands read once, outputs written once; DESIGN.md
+    section 5) / measured time.  The MFMA rate of the same launches is reported beside it."""
     from lid.audio_processor import WaveBatch
     eng = trainer.engine
     k = eng.k
-    orig_nt, orig_tn, orig_mel = k.gemm_nt, k.gemm_tn, WaveBatch._compute_mel
-    rec = {"nt": [], "tn": [], "feat": []}
+    names = ("gemm_nt", "gemm_tn", "ffn_fwd", "ffn_bwd", "build_tn_group", "gemm_tn_grouped")
+    orig = {n: getattr(k, n) for n in names if hasattr(k, n)}
+    orig_mel = WaveBatch._compute_mel
+    rec = {"nt": [], "tn": [], "ffn": [], "tng": [], "feat": []}
+    groups = {}
 
     def esz(t):
         return t.element_size()
@@ -367,19 +372,46 @@ def roofline(trainer, batches, step_fn):
         for key in ("out2", "aux", "res"):
             if kw.get(key) is not None:
                 nbytes += m * n * esz(kw[key])
-        for key in ("A2",):                           # recompute epilogues read a second operand panel
-            if kw.get(key) is not None:
-                nbytes += m * kw[key].shape[1] * esz(kw[key])
         if kw.get("bias") is not None:
             nbytes += n * 4
-        rec["nt"].append((lambda: orig_nt(A, B, out, *a, M=M, N=N, K=K, **kw), 2.0 * m * n * kk, nbytes))
-        return orig_nt(A, B, out, *a, M=M, N=N, K=K, **kw)
+        rec["nt"].append((lambda: orig["gemm_nt"](A, B, out, *a, M=M, N=N, K=K, **kw), 2.0 * m * n * kk, nbytes))
+        return orig["gemm_nt"](A, B, out, *a, M=M, N=N, K=K, **kw)
 
     def timed_tn(X, Y, C, *a, M=None, N1=None, N2=None, **kw):
         m, n1, n2 = (X.shape[0] if M is None else M), (X.shape[1] if N1 is None else N1), (Y.shape[1] if N2 is None else N2)
         nbytes = m * n1 * esz(X) + m * n2 * esz(Y) + n1 * n2 * 4
-        rec["tn"].append((lambda: orig_tn(X, Y, C, *a, M=M, N1=N1, N2=N2, **kw), 2.0 * m * n1 * n2, nbytes))
-        return orig_tn(X, Y, C, *a, M=M, N1=N1, N2=N2, **kw)
+        rec["tn"].append((lambda: orig["gemm_tn"](X, Y, C, *a, M=M, N1=N1, N2=N2, **kw), 2.0 * m * n1 * n2, nbytes))
+        return orig["gemm_tn"](X, Y, C, *a, M=M, N1=N1, N2=N2, **kw)
+
+    def timed_ffn_fwd(x, W1, b1, W2, b2, xo, **kw):
+        m, d, ff = x.shape[0], x.shape[1], W1.shape[0]
+        # x (f32) in, xo (f32) out, W1 + W2 + biases, a and u out (T), h out - or in, when the LayerNorm pair produced it
+        nbytes = 2 * m * d * 4 + 2 * ff * d * 2 + (ff + d) * 4 + 2 * m * ff * 2 + m * d * 2 + (0 if kw.get("h_in") is not None else 8 * m)
+        rec["ffn"].append((lambda: orig["ffn_fwd"](x, W1, b1, W2, b2, xo, **kw), 4.0 * m * d * ff, nbytes))
+        return orig["ffn_fwd"](x, W1, b1, W2, b2, xo, **kw)
+
+    def timed_ffn_bwd(dyT, a, W1T, W2T, da, **kw):
+        m, d, ff = dyT.shape[0], dyT.shape[1], a.shape[1]
+        nbytes = m * d * 2 + 2 * m * ff * 2 + 2 * ff * d * 2            # dyT, a in, da out, both weight operands
+        if kw.get("dh") is not None:
+            nbytes += m * d * 2
+        else:                                                          # x + dres in, dx (+ dxT) out, statistics, partial rows
+            nbytes += m * d * 4 * (2 if kw.get("dres") is not None else 1) + (m * d * 4 if kw.get("dx") is not None else 0) \
+                + (m * d * 2 if kw.get("dxT") is not None else 0) + 8 * m
+        rec["ffn"].append((lambda: orig["ffn_bwd"](dyT, a, W1T, W2T, da, **kw), 4.0 * m * d * ff, nbytes))
+        return orig["ffn_bwd"](dyT, a, W1T, W2T, da, **kw)
+
+    def timed_build(entries, **kw):
+        grp = orig["build_tn_group"](entries, **kw)
+        groups[id(grp[0])] = (sum(2.0 * M * n1 * n2 for _, _, _, _, M, n1, n2 in entries),
+                              sum(M * n1 * 2 + M * n2 * 2 + n1 * n2 * 4 for _, _, _, _, M, n1, n2 in entries))
+        return grp
+
+    def timed_tng(grp):
+        if id(grp[0]) in groups:
+            fl, by = groups[id(grp[0])]
+            rec["tng"].append((lambda: orig["gemm_tn_grouped"](grp), fl, by))
+        return orig["gemm_tn_grouped"](grp)
 
     def timed_mel(self):
         Bn, Ln = self.wav.shape
@@ -391,12 +423,21 @@ def roofline(trainer, batches, step_fn):
     eng.graphs.enabled = False
     if hasattr(batches[0][0], "_mel"):
         batches[0][0]._mel = batches[0][0]._mel_ready = None    # drop a prefetched copy: this step computes its own features
-    k.gemm_nt, k.gemm_tn, WaveBatch._compute_mel = timed_nt, timed_tn, timed_mel
+    w0 = getattr(eng, "_ctx", {}).get("w") if isinstance(getattr(eng, "_ctx", None), dict) else None
+    if w0 is not None:
+        w0.__dict__.pop("_tn_groups", None)           # rebuild the descriptor tables under the recorder (shapes come from there)
+    wraps = {"gemm_nt": timed_nt, "gemm_tn": timed_tn, "ffn_fwd": timed_ffn_fwd, "ffn_bwd": timed_ffn_bwd,
+             "build_tn_group": timed_build, "gemm_tn_grouped": timed_tng}
+    for n in orig:
+        setattr(k, n, wraps[n])
+    WaveBatch._compute_mel = timed_mel
     try:
         step_fn(0, batches[0])
         torch.cuda.synchronize()
     finally:
-        k.gemm_nt, k.gemm_tn, WaveBatch._compute_mel = orig_nt, orig_tn, orig_mel
+        for n, f in orig.items():
+            setattr(k, n, f)
+        WaveBatch._compute_mel = orig_mel
         eng.graphs.enabled = graphs_on
 
     def tot(kind):
@@ -405,50 +446,59 @@ def roofline(trainer, batches, step_fn):
         ms = _replay_ms([c for c, _, _ in rec[kind]])
         return ms, sum(f for _, f, _ in rec[kind]), sum(n for _, _, n in rec[kind]), len(rec[kind])
 
-    ms, fl, by, n = tot("nt")
-    ms2, fl2, by2, n2 = tot("tn")
-    ms3, _, by3, n3 = tot("feat")
+    fam = {kind: tot(kind) for kind in ("nt", "ffn", "tng", "tn", "feat")}
     trainer._zero_grad()                               # the replayed weight-gradient launches accumulated into the arena
     torch.cuda.synchronize()
-    gbs = by / (ms * 1e-3) / 1e9
-    tfs = fl / (ms * 1e-3) / 1e12
     method = ("all launches of one step captured back-to-back into one hipGraph, replay time / launches between two HIP events "
               "(nothing subtracted; contains the inter-node gaps)")
-    rp_us, rp_n, rp_src = _rocprof_avg_us(("gemm_nt_bf16_",))
-    rp2_us, _, _ = _rocprof_avg_us(("gemm_tn_bf16_kernel",))
-    if fl / max(by, 1) > MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):          # above the machine balance: MFMA-bound
-        return {"bound": "mfma", "achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tfs / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "traffic_source": None,
-                "kernel": "gemm_nt (gemm_nt_bf16_direct_kernel, 64x64 tiles: strided-view convolutions, projections, FFN)",
-                "launches_per_step": n, "avg_launch_us": round(ms * 1e3 / n, 2), "kernel_ms_per_step": round(ms, 3),
-                "flops_per_launch": round(fl / n), "algorithmic_bytes_per_launch": round(by / n),
-                "flop_per_byte": round(fl / max(by, 1), 1), "method": method,
-                "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
-                "wgrad_kernel": {"kernel": "gemm_tn_bf16_kernel<64,64>", "launches_per_step": n2,
-                                 "avg_launch_us": round(ms2 * 1e3 / max(n2, 1), 2)} if n2 else None}
-    traffic, src = _pmc_traffic("gemm_nt_bf16_")
-    traffic2, _ = _pmc_traffic("gemm_tn_bf16_kernel")
-    feat = None
+    label = {"nt": ("gemm_nt (gemm_nt_bf16_pipe_kernel + gemm_nt_bf16_direct_kernel, 64x64 tiles)", ("gemm_nt_bf16_",)),
+             "ffn": ("fused FeedForward (ffn_fwd_kernel + ffn_bwd_kernel, csrc/ffn.hip: 64-row workgroups, weights by LDS-DMA)",
+                     ("ffn_fwd_kernel", "ffn_bwd_kernel")),
+             "tng": ("grouped weight-gradient GEMM (gemm_tn_grouped_kernel, 64x64 tiles, 4-way row split)", ("gemm_tn_grouped",)),
+             "tn": ("gemm_tn_bf16_kernel<64,64>", ("gemm_tn_bf16_kernel",))}
+
+    def describe(kind):
+        ms, fl, by, n = fam[kind]
+        if not n or ms <= 0:
+            return None
+        gbs, tfs = by / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
+        rp_us, rp_n, rp_src = _rocprof_avg_us(label[kind][1])
+        traffic, src = _pmc_traffic(label[kind][1][0]) if len(label[kind][1]) == 1 else (None, None)
+        if len(label[kind][1]) > 1:                    # launch-weighted over the family's kernels
+            parts = [(_pmc_traffic(px), _rocprof_avg_us((px,))) for px in label[kind][1]]
+            if all(t[0] is not None and r[1] for t, r in parts):
+                traffic = round(sum(t[0] * r[1] for t, r in parts) / sum(r[1] for _, r in parts))
+                src = parts[0][0][1]
+        mfma_bound = fl / max(by, 1) > MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        d = {"bound": "mfma" if mfma_bound else "hbm",
+             "achieved": round(tfs if mfma_bound else gbs, 1), "peak": MFMA_BF16_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+             "unit": "TFLOP/s" if mfma_bound else "GB/s",
+             "frac": round(tfs / MFMA_BF16_PEAK_TFLOPS if mfma_bound else gbs / HBM_PEAK_GBS, 4),
+             "traffic": traffic,
+             "traffic_source": (f"{src} (committed rocprofv3 --pmc pass of this command; not measured in this run)" if src else None),
+             "kernel": label[kind][0], "launches_per_step": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+             "kernel_ms_per_step": round(ms, 3), "algorithmic_bytes_per_launch": round(by / n), "flops_per_launch": round(fl / n),
+             "flop_per_byte": round(fl / max(by, 1), 1), "method": method,
+             "rocprof_avg_us": rp_us, "rocprof_launches": rp_n, "rocprof_source": rp_src,
+             "frac_from_rocprof": (round(by / n / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rp_us and not mfma_bound else None),
+             "mfma": {"achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_BF16_PEAK_TFLOPS, 4)},
+             "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}}
+        return d
+
+    big = max(("nt", "ffn", "tng"), key=lambda kind: fam[kind][0])
+    out = describe(big)
+    out["family_ms_per_step"] = {label[kind][0].split(" (")[0]: round(fam[kind][0], 3) for kind in ("nt", "ffn", "tng") if fam[kind][3]}
+    for kind, key in (("nt", "gemm_nt"), ("ffn", "feedforward_fused"), ("tng", "wgrad_grouped"), ("tn", "wgrad_kernel")):
+        if kind != big:
+            out[key] = describe(kind)
+    ms3, _, by3, n3 = fam["feat"]
+    out["features"] = None
     if n3 and ms3 > 0:
         f_gbs = by3 / (ms3 * 1e-3) / 1e9
-        feat = {"bound": "hbm", "achieved": round(f_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_gbs / HBM_PEAK_GBS, 4),
-                "kernels": "waveform statistics + STFT/mel (normalise, dither and pre-emphasis in its frame load) + dB floor / SpecAugment (one batch)",
-                "ms_per_batch": round(ms3, 4), "algorithmic_bytes_per_batch": int(by3)}
-    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_source": (f"{src} (committed rocprofv3 --pmc pass of this command; not measured in this run)"
-                                                   if src else None),
-            "kernel": "gemm_nt (gemm_nt_bf16_pipe_kernel + gemm_nt_bf16_direct_kernel, 64x64 tiles)",
-            "launches_per_step": n, "avg_launch_us": round(ms * 1e3 / n, 2), "kernel_ms_per_step": round(ms, 3),
-            "algorithmic_bytes_per_launch": round(by / n), "method": method,
-            "rocprof_avg_us": rp_us, "rocprof_launches": rp_n, "rocprof_source": rp_src,
-            "frac_from_rocprof": (round(by / n / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rp_us else None),
-            "mfma": {"achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
-            "wgrad_kernel": {"kernel": "gemm_tn_bf16_kernel<64,64>", "launches_per_step": n2,
-                             "avg_launch_us": round(ms2 * 1e3 / n2, 2), "rocprof_avg_us": rp2_us,
-                             "GB/s": round(by2 / (ms2 * 1e-3) / 1e9, 1),
-                             "TFLOP/s": round(fl2 / (ms2 * 1e-3) / 1e12, 1), "traffic": traffic2},
-            "features": feat}
+        out["features"] = {"bound": "hbm", "achieved": round(f_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_gbs / HBM_PEAK_GBS, 4),
+                           "kernels": "waveform statistics + STFT/mel (normalise, dither and pre-emphasis in its frame load) + dB floor / SpecAugment (one batch)",
+                           "ms_per_batch": round(ms3, 4), "algorithmic_bytes_per_batch": int(by3)}
+    return out
 
 
 def phase_times(trainer, batches, step_fn):
