@@ -48,6 +48,13 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_off) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(g), "s"(lds_off) : "memory");
 }
+// the same with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: the per-lane part is loop-invariant in
+// the chunk loops, so a chunk's staging costs scalar adds only - no vector address arithmetic between the MFMAs
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
 
 __device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
   bf16x8 r;
@@ -56,23 +63,32 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
   return r;
 }
 
-// chunk c of W1 / W2 -> LDS buffer at byte offset `buf` (this wave's 8 of the 64 wave instructions; wid is an SGPR value)
-__device__ __forceinline__ void ffn_stage(const bf16* __restrict__ W1, const bf16* __restrict__ W2, int FF, int c, unsigned buf,
-                                          int wid, int lane) {
-  // W1 rows: LDS row rho (512 B) holds global row n(rho) with its 16-byte chunks XOR-permuted by (rho & 15); rho -> n undoes the
-  // "pair" permutation that makes two adjacent accumulator tiles 8 consecutive columns
+// Per-lane byte offsets (chunk-invariant) of this wave's 8 of the 64 wave instructions that stage a chunk: 4 for the W1 rows, 4 for
+// the W2 columns.  W1 rows: LDS row rho (512 B) holds global row n(rho) with its 16-byte chunks XOR-permuted by (rho & 15); rho -> n
+// undoes the "pair" permutation that makes two adjacent accumulator tiles 8 consecutive columns.  W2 columns: LDS row = output
+// column (128 B), chunks XOR-permuted by ((row >> 1) & 7).
+struct FfnStageOff { unsigned w1[4], w2[4]; };
+__device__ __forceinline__ FfnStageOff ffn_stage_offsets(int FF, int wid, int lane) {
+  FfnStageOff o;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rho = 8 * wid + 2 * i + (lane >> 5), p = lane & 31, cc = p ^ (rho & 15);
     const int n = (rho & 32) + 8 * ((rho >> 2) & 3) + 4 * ((rho >> 4) & 1) + (rho & 3);
-    glds16(W1 + (size_t)(c * FFN_CH + n) * FFN_D + cc * 8, buf + (8 * wid + 2 * i) * 512);
+    o.w1[i] = (unsigned)((n * FFN_D + cc * 8) * 2);
+    const int row = 32 * wid + 8 * i + (lane >> 3), p2 = lane & 7, c2 = p2 ^ ((row >> 1) & 7);
+    o.w2[i] = (unsigned)((row * FF + c2 * 8) * 2);
   }
-  // W2 columns: LDS row = output column (128 B), chunks XOR-permuted by ((row >> 1) & 7)
+  return o;
+}
+// chunk c of W1 / W2 -> LDS buffer at byte offset `buf` (wid is an SGPR value: all address arithmetic here is scalar)
+__device__ __forceinline__ void ffn_stage(const bf16* __restrict__ W1, const bf16* __restrict__ W2, const FfnStageOff& o, int c,
+                                          unsigned buf, int wid) {
+  const bf16* b1 = W1 + (size_t)c * FFN_CH * FFN_D;
+  const bf16* b2 = W2 + (size_t)c * FFN_CH;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 32 * wid + 8 * i + (lane >> 3), p = lane & 7, cc = p ^ ((row >> 1) & 7);
-    glds16(W2 + (size_t)row * FF + c * FFN_CH + cc * 8, buf + FFN_CH * FFN_D * 2 + (32 * wid + 8 * i) * 128);
-  }
+  for (int i = 0; i < 4; ++i) glds16s(b1, o.w1[i], buf + (8 * wid + 2 * i) * 512);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) glds16s(b2, o.w2[i], buf + FFN_CH * FFN_D * 2 + (32 * wid + 8 * i) * 128);
 }
 
 // one 1 KB wave instruction of a small f32 vector (bias, LayerNorm weights) -> LDS, unpermuted
@@ -98,7 +114,7 @@ __device__ __forceinline__ void ffn_stage_rows(const float* __restrict__ x, int 
 // Latency chain of a workgroup (all of them run in lock-step, there is no second workgroup on the CU to hide behind): ONE HBM round
 // trip in the prologue - the row loads are issued first, the small vectors (b1, b2, gamma, beta) and chunk 0 follow by LDS-DMA - and
 // none in the epilogue: the residual rows the epilogue adds come back by LDS-DMA during the last chunk, into the free chunk buffer.
-template <bool LN_IN>
+template <bool LN_IN, int ABL>      // ABL (ablation builds, wrong results): 1 no fragment reads, 2 no MFMAs, 4 no bias / Swish math
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ffn_fwd_kernel(FfnFwd p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];
@@ -119,6 +135,8 @@ ffn_fwd_kernel(FfnFwd p) {
   // at any moment, so a chunk is usually already in the XCD's L2 when a workgroup asks for it.
   const int rot = p.rot ? (blockIdx.x >> 3) % (p.FF / FFN_CH) : 0;
   auto chunk_of = [&](int c) __attribute__((always_inline)) { const int t = c + rot; return t >= NC ? t - NC : t; };
+
+  const FfnStageOff so = ffn_stage_offsets(p.FF, wid, lane);
 
   // ---- register loads first: this lane's 64 row elements (or the ready-made h fragments)
   bf16x8 hA[8];
@@ -142,7 +160,7 @@ ffn_fwd_kernel(FfnFwd p) {
       if (wid == ((nb1 + 2) & 7)) ffn_stage_vec(p.beta, FFN_D, vec0 + FFp * 4 + 2048, 0, lane);
     }
   }
-  if (NC > 0) ffn_stage(p.W1, p.W2, p.FF, chunk_of(0), smem0, wid, lane);
+  if (NC > 0) ffn_stage(p.W1, p.W2, so, chunk_of(0), smem0, wid);
 
   if (LN_IN) {
     float s = 0.f;
@@ -183,50 +201,82 @@ ffn_fwd_kernel(FfnFwd p) {
 
   // fragment addresses inside a chunk buffer: up-projection tile t (0/1) of this wave's half, K step ks; down-projection tile j
   const int w1_lane = (32 * half + fr) * 512, w2_lane = FFN_CH * FFN_D * 2 + fr * 128 + (((4 * half + fq) ^ ((fr >> 1) & 7)) << 4);
-#define W1F(buf_, t_, ks_) (*reinterpret_cast<const bf16x8*>((buf_) + w1_lane + (t_) * (16 * 512) + (((4 * (ks_) + fq) ^ fr) << 4)))
-#define W2F(buf_, j_) (*reinterpret_cast<const bf16x8*>((buf_) + w2_lane + (j_) * (16 * 128)))
+#define W1F(buf_, t_, ks_) ((ABL & 1) ? hA[ks_] : *reinterpret_cast<const bf16x8*>((buf_) + w1_lane + (t_) * (16 * 512) + (((4 * (ks_) + fq) ^ fr) << 4)))
+#define W2F(buf_, j_) ((ABL & 1) ? hA[(j_) & 7] : *reinterpret_cast<const bf16x8*>((buf_) + w2_lane + (j_) * (16 * 128)))
 
-  for (int c = 0; c < NC; ++c) {
-    // chunk c has landed (this wave's pieces: vmcnt; everybody's: barrier); the barrier also says every wave is done reading
-    // the other buffer (chunk c - 1), which the next stage overwrites
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (c + 1 < NC) {
-      if (!(p.dbg & 2)) ffn_stage(p.W1, p.W2, p.FF, chunk_of(c + 1), smem0 + ((c + 1) & 1) * FFN_BUF, wid, lane);
-    } else {
-      ffn_stage_rows(p.x, m0, p.M, smem0 + ((c + 1) & 1) * FFN_BUF, wid, lane);      // the epilogue's residual rows
-    }
-    const unsigned char* buf = ffn_smem + (c & 1) * FFN_BUF;
-    const int cc = chunk_of(c);
-
-    bf16x8 fa[8], fb[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = W1F(buf, i & 1, i >> 1);            // K steps 0..3
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fb[i] = W1F(buf, i & 1, 4 + (i >> 1));      // K steps 4..7
-    f32x4 acc1[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc1[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], hA[i >> 1], acc1[i & 1], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = W2F(buf, i);                        // down-projection tiles 0..7
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc1[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], hA[4 + (i >> 1)], acc1[i & 1], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fb[i] = W2F(buf, 8 + i);                    // tiles 8..15
-
+  // Software pipeline across the chunk barrier.  A chunk's work per wave is 4 + 4 sub-steps of 4 MFMAs; every sub-step is followed
+  // by the 4 fragment reads that refill the register set it has just consumed, with the fragments needed 4 sub-steps later:
+  //     ... | M1(c)[s] , read W2(c)[s] | bias + Swish (c) | BARRIER c | M2(c)[s] , read W1(c+1)[s] | M1(c+1)[s] , read W2(c+1)[s] | ...
+  // so LDS reads and MFMAs alternate through the whole chunk (16 fragments = 64 registers in flight, as before), and the barrier
+  // sits where a wave holds all the operands of its next 16 MFMAs in registers: nobody starts a chunk with a burst of reads in
+  // front of idle matrix cores.  At barrier c every wave has finished reading buffer c & 1 (its W2(c) fragments are in registers),
+  // so chunk c + 2 is staged into it there - one whole chunk of time to land - and chunk c + 1, staged at barrier c - 1, is complete.
+  bf16x8 f[4][4];
+  bf16x8 uA;
+  f32x4 acc1[2];
+  auto act = [&](int cc) __attribute__((always_inline)) {           // bias + Swish of the chunk just projected: a, u out, uA kept
     const int n = cc * FFN_CH + 32 * half + 8 * fq;
     const float4 ba = *reinterpret_cast<const float4*>(lb1 + n), bb = *reinterpret_cast<const float4*>(lb1 + n + 4);
     float4 v0 = make_float4(acc1[0][0] + ba.x, acc1[0][1] + ba.y, acc1[0][2] + ba.z, acc1[0][3] + ba.w);
     float4 v1 = make_float4(acc1[1][0] + bb.x, acc1[1][1] + bb.y, acc1[1][2] + bb.z, acc1[1][3] + bb.w);
     if (p.a && m_ok && !(p.dbg & 1)) *reinterpret_cast<bf16x8*>(p.a + (size_t)m * p.FF + n) = pack_bf16x8(v0, v1);
-    v0.x *= sigmoidf_(v0.x); v0.y *= sigmoidf_(v0.y); v0.z *= sigmoidf_(v0.z); v0.w *= sigmoidf_(v0.w);
-    v1.x *= sigmoidf_(v1.x); v1.y *= sigmoidf_(v1.y); v1.z *= sigmoidf_(v1.z); v1.w *= sigmoidf_(v1.w);
-    const bf16x8 uA = pack_bf16x8(v0, v1);
+    if constexpr (!(ABL & 4)) {
+      v0.x *= sigmoidf_(v0.x); v0.y *= sigmoidf_(v0.y); v0.z *= sigmoidf_(v0.z); v0.w *= sigmoidf_(v0.w);
+      v1.x *= sigmoidf_(v1.x); v1.y *= sigmoidf_(v1.y); v1.z *= sigmoidf_(v1.z); v1.w *= sigmoidf_(v1.w);
+    }
+    uA = pack_bf16x8(v0, v1);
     if (p.u && m_ok && !(p.dbg & 1)) *reinterpret_cast<bf16x8*>(p.u + (size_t)m * p.FF + n) = uA;
+  };
+  // up-projection of the chunk in `nb` from the W1 fragments in f, refilled with that chunk's W2 fragments
+  auto up = [&](const unsigned char* nb) __attribute__((always_inline)) {
+    acc1[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], uA, acc2[i], 0, 0, 0);
+    for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc2[8 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], uA, acc2[8 + i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) { if constexpr (ABL & 2) acc1[i & 1][0] += (float)f[s4][i][0]; else acc1[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[s4][i], hA[2 * s4 + (i >> 1)], acc1[i & 1], 0, 0, 0); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[s4][i] = W2F(nb, 4 * s4 + i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  if (NC > 0) {
+    if (NC == 1) ffn_stage_rows(p.x, m0, p.M, smem0 + FFN_BUF, wid, lane);
+    else if (!(p.dbg & 2)) ffn_stage(p.W1, p.W2, so, chunk_of(1), smem0 + FFN_BUF, wid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // chunk 0 (and the small vectors) landed; chunk 1 rides along
+    __syncthreads();
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[s4][i] = W1F(ffn_smem, i & 1, 2 * s4 + (i >> 1));
+    up(ffn_smem);
+    act(chunk_of(0));
+    for (int c = 0; c + 1 < NC; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // BARRIER c
+      __syncthreads();
+      if (c + 2 < NC) {
+        if (!(p.dbg & 2)) ffn_stage(p.W1, p.W2, so, chunk_of(c + 2), smem0 + (c & 1) * FFN_BUF, wid);
+      } else {
+        ffn_stage_rows(p.x, m0, p.M, smem0 + (c & 1) * FFN_BUF, wid, lane);          // c == NC - 2: the epilogue's residual rows
+      }
+      const unsigned char* nb = ffn_smem + ((c + 1) & 1) * FFN_BUF;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { if constexpr (ABL & 2) acc2[4 * s4 + i][0] += (float)f[s4][i][0]; else acc2[4 * s4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[s4][i], uA, acc2[4 * s4 + i], 0, 0, 0); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[s4][i] = W1F(nb, i & 1, 2 * s4 + (i >> 1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      up(nb);
+      act(chunk_of(c + 1));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // BARRIER NC - 1: the residual rows have landed too
+    __syncthreads();
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { if constexpr (ABL & 2) acc2[4 * s4 + i][0] += (float)f[s4][i][0]; else acc2[4 * s4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[s4][i], uA, acc2[4 * s4 + i], 0, 0, 0); }
   }
 #undef W1F
 #undef W2F
@@ -235,9 +285,11 @@ ffn_fwd_kernel(FfnFwd p) {
   // ---- the two halves of a row group exchange partial sums: half 0 finishes output tiles 0..7, half 1 tiles 8..15
   // (register arrays are indexed by compile-time constants only: the two roles are two branches of a wave-uniform condition).
   // The residual rows sit in the buffer the last chunk did NOT use; the exchange goes through the one it did.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int xb = (NC & 1) ? 1 : (NC == 0 ? 1 : 0);               // buffer holding the rows: (NC - 1 + 1) & 1
+  if (NC == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const int xb = NC == 0 ? 1 : (NC & 1);                         // buffer holding the rows; nobody reads the other one any more
   float4* xch = reinterpret_cast<float4*>(ffn_smem + (1 - xb) * FFN_BUF);
   const unsigned char* xt = ffn_smem + xb * FFN_BUF;
   if (half == 0) {
@@ -288,13 +340,31 @@ extern "C" int lidk_ffn_fwd(const float* x, const void* h_in, const float* gamma
   const int lds = 2 * FFN_BUF + (((ff + 255) & ~255) + 3 * FFN_D) * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef LIDK_FFN_ABLATION
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
     attr_set = true;
   }
   const int grid = cdiv(M, FFN_BM);
-  if (h_in) ffn_fwd_kernel<false><<<grid, 512, lds, as_stream(stream)>>>(p);
-  else ffn_fwd_kernel<true><<<grid, 512, lds, as_stream(stream)>>>(p);
+#ifdef LIDK_FFN_ABLATION
+  const int abl = (p.dbg >> 5) & 7;                // LIDK_FFN_DBG bits 32 / 64 / 128: compile-time ablations of the chunk loop
+  if (!h_in && abl) {
+    if (abl == 1) ffn_fwd_kernel<true, 1><<<grid, 512, lds, as_stream(stream)>>>(p);
+    else if (abl == 2) ffn_fwd_kernel<true, 2><<<grid, 512, lds, as_stream(stream)>>>(p);
+    else if (abl == 3) ffn_fwd_kernel<true, 3><<<grid, 512, lds, as_stream(stream)>>>(p);
+    else if (abl == 4) ffn_fwd_kernel<true, 4><<<grid, 512, lds, as_stream(stream)>>>(p);
+    else ffn_fwd_kernel<true, 7><<<grid, 512, lds, as_stream(stream)>>>(p);
+    return launch_status();
+  }
+#endif
+  if (h_in) ffn_fwd_kernel<false, 0><<<grid, 512, lds, as_stream(stream)>>>(p);
+  else ffn_fwd_kernel<true, 0><<<grid, 512, lds, as_stream(stream)>>>(p);
   return launch_status();
 }
 
@@ -340,10 +410,15 @@ ffn_bwd_kernel(FfnBwd p) {
 
   // the chunk's tile of a: wave w copies rows 8 w .. + 7 (128 B each), 16-byte chunks XOR-permuted by (row & 7)
   const int a_row = 8 * wid + (lane >> 3), a_cc = (lane & 7) ^ (a_row & 7);
+  const FfnStageOff so = ffn_stage_offsets(p.FF, wid, lane);
+  const unsigned a_off = (unsigned)((8 * wid + (lane >> 3)) * p.FF + a_cc * 8) * 2;      // relative to the workgroup's first row of a
+  const bf16* a_base = p.a + (size_t)m0 * p.FF;
+  const bool a_tail = m0 + FFN_BM > p.M;                     // last workgroup of a ragged M: per-lane pointers with the row clamped
   const bf16* a_src = p.a + (size_t)min(m0 + a_row, p.M - 1) * p.FF + a_cc * 8;
   auto stage = [&](int c, int b) __attribute__((always_inline)) {
-    ffn_stage(p.W2T, p.W1T, p.FF, c, smem0 + b * FFN_BUF, wid, lane);
-    glds16(a_src + c * FFN_CH, smem0 + 2 * FFN_BUF + b * FFN_ATILE + wid * 1024);
+    ffn_stage(p.W2T, p.W1T, so, c, smem0 + b * FFN_BUF, wid);
+    if (a_tail) glds16(a_src + c * FFN_CH, smem0 + 2 * FFN_BUF + b * FFN_ATILE + wid * 1024);
+    else glds16s(a_base + c * FFN_CH, a_off, smem0 + 2 * FFN_BUF + b * FFN_ATILE + wid * 1024);
   };
   stage(chunk_of(0), 0);
 
@@ -356,45 +431,68 @@ ffn_bwd_kernel(FfnBwd p) {
 #define W1F(buf_, t_, ks_) (*reinterpret_cast<const bf16x8*>((buf_) + w1_lane + (t_) * (16 * 512) + (((4 * (ks_) + fq) ^ fr) << 4)))
 #define W2F(buf_, j_) (*reinterpret_cast<const bf16x8*>((buf_) + w2_lane + (j_) * (16 * 128)))
 
-  for (int c = 0; c < NC; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (c + 1 < NC) {
-      if (!(p.dbg & 2)) stage(chunk_of(c + 1), (c + 1) & 1);
-    } else if (LN_OUT) {
-      ffn_stage_rows(p.x, m0, p.M, smem0 + ((c + 1) & 1) * FFN_BUF, wid, lane);   // the LayerNorm backward's rows of x
-    }
-    const int cc = chunk_of(c);
-    const unsigned char* buf = ffn_smem + (c & 1) * FFN_BUF;
-
-    bf16x8 fa[8], fb[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = W1F(buf, i & 1, i >> 1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fb[i] = W1F(buf, i & 1, 4 + (i >> 1));
-    const bf16x8 av = *reinterpret_cast<const bf16x8*>(ffn_smem + 2 * FFN_BUF + (c & 1) * FFN_ATILE + at_lane);
-    f32x4 acc1[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc1[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], dyA[i >> 1], acc1[i & 1], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = W2F(buf, i);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc1[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], dyA[4 + (i >> 1)], acc1[i & 1], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fb[i] = W2F(buf, 8 + i);
-
+  // the forward kernel's software pipeline across the chunk barrier (see there): | M1(c)[s] , read W1T(c)[s] | swish'(a) (c) |
+  // BARRIER c | M2(c)[s] , read W2T(c+1)[s] | M1(c+1)[s] , read W1T(c+1)[s] | ...
+  bf16x8 f[4][4];
+  bf16x8 daA;
+  f32x4 acc1[2];
+  auto act = [&](int cc, int b) __attribute__((always_inline)) {     // da = (dyT . W2) * swish'(a) of the chunk in buffer b
+    const bf16x8 av = *reinterpret_cast<const bf16x8*>(ffn_smem + 2 * FFN_BUF + b * FFN_ATILE + at_lane);
     float dv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float a = (float)av[i], sg = sigmoidf_(a);
       dv[i] = acc1[i >> 2][i & 3] * (sg * (1.f + a * (1.f - sg)));
     }
-    const bf16x8 daA = pack_bf16x8(make_float4(dv[0], dv[1], dv[2], dv[3]), make_float4(dv[4], dv[5], dv[6], dv[7]));
+    daA = pack_bf16x8(make_float4(dv[0], dv[1], dv[2], dv[3]), make_float4(dv[4], dv[5], dv[6], dv[7]));
     if (m_ok && !(p.dbg & 1)) *reinterpret_cast<bf16x8*>(p.da + (size_t)m * p.FF + cc * FFN_CH + 32 * half + 8 * fq) = daA;
+  };
+  auto up = [&](const unsigned char* nb) __attribute__((always_inline)) {
+    acc1[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], daA, acc2[i], 0, 0, 0);
+    for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc2[8 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], daA, acc2[8 + i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) acc1[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[s4][i], dyA[2 * s4 + (i >> 1)], acc1[i & 1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[s4][i] = W2F(nb, 4 * s4 + i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  {
+    if (NC == 1) { if (LN_OUT) ffn_stage_rows(p.x, m0, p.M, smem0 + FFN_BUF, wid, lane); }
+    else if (!(p.dbg & 2)) stage(chunk_of(1), 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[s4][i] = W1F(ffn_smem, i & 1, 2 * s4 + (i >> 1));
+    up(ffn_smem);
+    act(chunk_of(0), 0);
+    for (int c = 0; c + 1 < NC; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // BARRIER c
+      __syncthreads();
+      if (c + 2 < NC) {
+        if (!(p.dbg & 2)) stage(chunk_of(c + 2), c & 1);
+      } else if (LN_OUT) {
+        ffn_stage_rows(p.x, m0, p.M, smem0 + (c & 1) * FFN_BUF, wid, lane);           // c == NC - 2: the LayerNorm backward's rows of x
+      }
+      const unsigned char* nb = ffn_smem + ((c + 1) & 1) * FFN_BUF;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc2[4 * s4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[s4][i], daA, acc2[4 * s4 + i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[s4][i] = W1F(nb, i & 1, 2 * s4 + (i >> 1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      up(nb);
+      act(chunk_of(c + 1), (c + 1) & 1);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc2[4 * s4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[s4][i], daA, acc2[4 * s4 + i], 0, 0, 0);
   }
 #undef W1F
 #undef W2F
