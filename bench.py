@@ -423,9 +423,10 @@ def roofline(trainer, batches, step_fn):
     eng.graphs.enabled = False
     if hasattr(batches[0][0], "_mel"):
         batches[0][0]._mel = batches[0][0]._mel_ready = None    # drop a prefetched copy: this step computes its own features
-    w0 = getattr(eng, "_ctx", {}).get("w") if isinstance(getattr(eng, "_ctx", None), dict) else None
-    if w0 is not None:
-        w0.__dict__.pop("_tn_groups", None)           # rebuild the descriptor tables under the recorder (shapes come from there)
+    # The grouped launches read their shapes from descriptor tables the engine caches per workspace.  Set the caches aside (NOT
+    # freed: captured hipGraphs hold raw pointers into those tables) so that this step rebuilds its tables under the recorder,
+    # and put them back afterwards.
+    held = [(w_, w_.__dict__.pop("_tn_groups")) for w_ in list(eng._work.values()) if "_tn_groups" in w_.__dict__]
     wraps = {"gemm_nt": timed_nt, "gemm_tn": timed_tn, "ffn_fwd": timed_ffn_fwd, "ffn_bwd": timed_ffn_bwd,
              "build_tn_group": timed_build, "gemm_tn_grouped": timed_tng}
     for n in orig:
@@ -439,6 +440,9 @@ def roofline(trainer, batches, step_fn):
             setattr(k, n, f)
         WaveBatch._compute_mel = orig_mel
         eng.graphs.enabled = graphs_on
+    fresh = [(w_, w_.__dict__.get("_tn_groups")) for w_, _ in held]      # tables built by this step: referenced by the recorder
+    for w_, cache in held:
+        w_.__dict__["_tn_groups"] = cache
 
     def tot(kind):
         if not rec[kind]:
@@ -449,6 +453,7 @@ def roofline(trainer, batches, step_fn):
     fam = {kind: tot(kind) for kind in ("nt", "ffn", "tng", "tn", "feat")}
     trainer._zero_grad()                               # the replayed weight-gradient launches accumulated into the arena
     torch.cuda.synchronize()
+    del fresh
     method = ("all launches of one step captured back-to-back into one hipGraph, replay time / launches between two HIP events "
               "(nothing subtracted; contains the inter-node gaps)")
     label = {"nt": ("gemm_nt (gemm_nt_bf16_pipe_kernel + gemm_nt_bf16_direct_kernel, 64x64 tiles)", ("gemm_nt_bf16_",)),

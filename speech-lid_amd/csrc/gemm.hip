@@ -939,7 +939,7 @@ struct TnDesc {
   int ldx, ldy, ldc, M, N1, N2, mchunk, item0, nsplit, pad0;
   float alpha; int pad1;
 };
-template <bool FULL>
+template <bool FULL, int BT>
 __global__ void __launch_bounds__(256)
 gemm_tn_grouped_kernel(const TnDesc* __restrict__ descs, int n_desc, int total_items) {
   // grid == total_items: one item per workgroup.  A smaller grid (LIDK_WGRAD_GRID) walks the items with a stride: the launch then
@@ -949,7 +949,7 @@ gemm_tn_grouped_kernel(const TnDesc* __restrict__ descs, int n_desc, int total_i
     int g = 0;
     while (g + 1 < n_desc && item >= descs[g + 1].item0) ++g;
     const TnDesc d = descs[g];
-    gemm_tn_tile<64, 64, FULL>(d.X, d.ldx, d.Y, d.ldy, d.C, d.ldc, d.colsum, d.M, d.N1, d.N2, d.mchunk, d.alpha, item - d.item0,
+    gemm_tn_tile<BT, BT, FULL>(d.X, d.ldx, d.Y, d.ldy, d.C, d.ldc, d.colsum, d.M, d.N1, d.N2, d.mchunk, d.alpha, item - d.item0,
                                d.nsplit > 1);
     __syncthreads();                  // the tile's LDS staging area is reused by the next item
   }
@@ -965,8 +965,16 @@ extern "C" int lidk_gemm_tn_grouped(const void* descs, int n_desc, int total_ite
   hipStream_t s = as_stream(stream);
   static const int cap = getenv("LIDK_WGRAD_GRID") ? atoi(getenv("LIDK_WGRAD_GRID")) : 0;      // 0: one workgroup per item
   const int grid = cap > 0 && cap < total_items ? cap : total_items;
-  if (full) gemm_tn_grouped_kernel<true><<<grid, 256, 0, s>>>((const TnDesc*)descs, n_desc, total_items);
-  else gemm_tn_grouped_kernel<false><<<grid, 256, 0, s>>>((const TnDesc*)descs, n_desc, total_items);
+  if (full) gemm_tn_grouped_kernel<true, 64><<<grid, 256, 0, s>>>((const TnDesc*)descs, n_desc, total_items);
+  else gemm_tn_grouped_kernel<false, 64><<<grid, 256, 0, s>>>((const TnDesc*)descs, n_desc, total_items);
+  return launch_status();
+}
+
+// The same launch on 128x128 output tiles (item0 / total_items counted in 128-tiles; every record needs N1 % 128 == N2 % 128 ==
+// M % 64 == 0): twice the MFMA work per operand byte staged through LDS.
+extern "C" int lidk_gemm_tn_grouped128(const void* descs, int n_desc, int total_items, void* stream) {
+  if (!descs || n_desc <= 0 || total_items <= 0) return LIDK_ERR_ARG;
+  gemm_tn_grouped_kernel<true, 128><<<total_items, 256, 0, as_stream(stream)>>>((const TnDesc*)descs, n_desc, total_items);
   return launch_status();
 }
 

@@ -238,7 +238,12 @@ class _Work:
 
 
 _WGRAD_WGS = int(__import__("os").environ.get("LIDK_WGRAD_WGS", "512"))      # workgroups a weight-gradient launch aims for (tuning knob)
-_WGRAD_SPLIT = int(__import__("os").environ.get("LIDK_WGRAD_SPLIT", "4"))     # row chunks per weight gradient in the grouped launch
+# Grouped weight-gradient launch: output tile and row chunks per weight gradient.  Measured end to end at cfg2 (same box, two rounds
+# each, ms per step): 64-tiles x 4 chunks 7.73 (x 8: 7.86); 128-tiles x 1 / 2 / 3 / 4 / 6 / 8 chunks 7.93 / 7.45 / 7.61 / 7.57 /
+# 7.70 / 7.70 - twice the MFMA work per operand byte fetched from L2 (the 64-tiles pull ~1 GB through L2 per launch) and ~190
+# long items instead of ~1 700 short ones beside the data-gradient chain.
+_WGRAD_TILE = int(__import__("os").environ.get("LIDK_WGRAD_TILE", "128"))
+_WGRAD_SPLIT = int(__import__("os").environ.get("LIDK_WGRAD_SPLIT", "2" if _WGRAD_TILE == 128 else "4"))
 
 
 class Engine:
@@ -888,8 +893,10 @@ class Engine:
             key = (id(bp), id(bb), id(S))
             grp = cache.get(key)
             if grp is None:
+                tile = _WGRAD_TILE if all(n % 128 == 0 and k % 128 == 0 for _, _, _, _, n, k in sites) and M % 64 == 0 else 64
+                split = _WGRAD_SPLIT if tile == _WGRAD_TILE else 4
                 grp = cache[key] = self.k.build_tn_group([(dy, x, dW, db, M, n, k) for dy, x, dW, db, n, k in sites],
-                                                         split=_WGRAD_SPLIT)
+                                                         split=split, tile=tile)
             self.k.gemm_tn_grouped(grp)
         else:
             for dy, x, dW, db, n, k in sites:

@@ -399,7 +399,7 @@ class _TnDesc(C.Structure):
                 ("mchunk", C.c_int), ("item0", C.c_int), ("nsplit", C.c_int), ("pad0", C.c_int), ("alpha", C.c_float), ("pad1", C.c_int)]
 
 
-def build_tn_group(entries, split=4):
+def build_tn_group(entries, split=4, tile=64):
     """Descriptor table of a grouped weight-gradient launch.  entries: list of (X (M, N1) bf16, Y (M, N2) bf16, C (N1, N2) f32,
     colsum (N1,) f32 or None, M, N1, N2): C += X[:M, :N1]^T @ Y[:M, :N2].  -> (device uint8 tensor, n, total_items, full); the
     table holds raw pointers: rebuild it when any buffer is reallocated."""
@@ -417,15 +417,20 @@ def build_tn_group(entries, split=4):
         d.X, d.Y, d.C, d.colsum = X.data_ptr(), Y.data_ptr(), Cm.data_ptr(), (cs.data_ptr() if cs is not None else None)
         d.ldx, d.ldy, d.ldc, d.M, d.N1, d.N2 = X.stride(0), Y.stride(0), Cm.stride(0), M, N1, N2
         d.mchunk, d.item0, d.nsplit, d.alpha = mchunk, item, nsplit, 1.0
-        item += (-(-N1 // 64)) * (-(-N2 // 64)) * nsplit
-        full = full and not (M % 64 or N1 % 64 or N2 % 64)
+        item += (-(-N1 // tile)) * (-(-N2 // tile)) * nsplit
+        full = full and not (M % 64 or N1 % tile or N2 % tile)
         dev = X.device
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-    return host.to(dev), len(entries), item, full
+    if tile != 64 and not full:
+        raise LidkError("build_tn_group: 128-tiles need N1 % 128 == N2 % 128 == M % 64 == 0")
+    return host.to(dev), len(entries), item, (full if tile == 64 else 128)
 
 
 def gemm_tn_grouped(group):
     table, n, items, full = group
+    if full == 128:
+        check(lib().lidk_gemm_tn_grouped128(_p(table), n, items, _stream()), "gemm_tn_grouped128")
+        return
     check(lib().lidk_gemm_tn_grouped(_p(table), n, items, int(full), _stream()), "gemm_tn_grouped")
 
 

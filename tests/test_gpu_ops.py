@@ -978,3 +978,17 @@ def test_grouped_weight_gradients_equal_the_separate_launches(M):
         scale = float(Cr.abs().max())
         assert float((Cg - Cr).abs().max()) <= 2e-3 * scale and float((Cg - Cs).abs().max()) <= 2e-3 * scale
         assert float((csg - csr).abs().max()) <= 2e-3 * float(csr.abs().max())
+    if M % 64:                                   # 128x128 output tiles need full shapes; a ragged group is refused
+        with pytest.raises(LidkError):
+            ops.build_tn_group(ents, split=2, tile=128)
+        return
+    for split in (1, 2, 3):                      # the training default is 128-tiles x 2 row chunks (lidk_gemm_tn_grouped128)
+        ents2 = [(X, Y, torch.zeros_like(Cg), torch.zeros_like(csg), M, n1, n2) for X, Y, Cg, csg, _, n1, n2 in ents]
+        grp = ops.build_tn_group(ents2, split=split, tile=128)
+        assert grp[3] == 128
+        ops.gemm_tn_grouped(grp)
+        torch.cuda.synchronize()
+        for (X, Y, Cg, csg, *_), (Cr, csr) in zip(ents2, refs):
+            ref, refc = X.float().t() @ Y.float(), X.float().sum(0)
+            assert float((Cg - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+            assert float((csg - refc).abs().max()) <= 2e-3 * float(refc.abs().max())
