@@ -198,6 +198,17 @@ int lidk_ffn_bwd(const void* dyT, const void* a, const void* W2T, int ldw2t, con
                  const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx, void* dxT, float dxT_scale,
                  float* partial, void* dh, int M, int d, int ff, int dtype, void* stream);
 
+/* Data gradient of a Linear / 1x1 Conv1d whose INPUT is a PreNorm output (N == 256 = the model width), fused with that LayerNorm's
+ * backward (lid/conformer.py:81-89 with the q/kv projections :98-100 and the conv module's first pointwise conv :192), bf16:
+ *     dh [M][256] = dy [M][K] . W [K][256]   (WT = W^T [256][ldwt == K], the transposed operand copy; K % 64 == 0)
+ *     dx (f32, optional) = dres (f32, optional) + LN'(dh; x, mean, rstd, gamma);  dxT (T, optional) = dxT_scale * dx
+ * partial: lidk_ffn_bwd_partial_rows(M) rows of (dgamma | dbeta) - finish with lidk_layernorm_param_grads_rows.  dh never exists in
+ * HBM.  The kernel is the second half of lidk_ffn_bwd (same workgroup / LDS-DMA structure).  Replaces lidk_gemm_nt + lidk_layernorm_bwd. */
+int lidk_dgrad_ln_bwd_supported(int M, int N, int K, int dtype);
+int lidk_dgrad_ln_bwd(const void* dy, const void* WT, int ldwt, const float* x, const float* mean, const float* rstd,
+                      const float* gamma, const float* dres, float* dx, void* dxT, float dxT_scale, float* partial, int M, int N,
+                      int K, int dtype, void* stream);
+
 /* Weight-gradient GEMM ("TN"): C[N1][N2] (f32) += alpha * sum_{m<M} X[m][n1] * Y[m][n2]; colsum[n1] (f32, optional) += alpha *
  * sum_m X[m][n1] (the bias gradient).  X [M][ldx], Y [M][ldy] are the activations as stored (T, row-major); rows are readable
  * (zero padded) up to the next multiple of 8 columns; ldx, ldy % 8 == 0.  The contraction over M is split `splitk` ways with

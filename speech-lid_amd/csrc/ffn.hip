@@ -388,7 +388,9 @@ struct FfnBwd {
   int M; int FF; int rot; int dbg;
 };
 
-template <bool LN_OUT>
+// GEMM = true: only the second product - dh = A . W with A = p.a [M][K = p.FF] (T) and p.W1T = W^T [256][K] - followed by the same
+// epilogue: the data gradient of any Linear / 1x1 conv that feeds a PreNorm (N = 256), fused with that LayerNorm's backward.
+template <bool LN_OUT, bool GEMM>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ffn_bwd_kernel(FfnBwd p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];
@@ -405,8 +407,10 @@ ffn_bwd_kernel(FfnBwd p) {
 
   // register loads first (one HBM round trip in the prologue)
   bf16x8 dyA[8];
+  if (!GEMM) {
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) dyA[ks] = *reinterpret_cast<const bf16x8*>(p.dyT + (size_t)m * FFN_D + 32 * ks + 8 * fq);
+    for (int ks = 0; ks < 8; ++ks) dyA[ks] = *reinterpret_cast<const bf16x8*>(p.dyT + (size_t)m * FFN_D + 32 * ks + 8 * fq);
+  }
 
   // the chunk's tile of a: wave w copies rows 8 w .. + 7 (128 B each), 16-byte chunks XOR-permuted by (row & 7)
   const int a_row = 8 * wid + (lane >> 3), a_cc = (lane & 7) ^ (a_row & 7);
@@ -416,7 +420,13 @@ ffn_bwd_kernel(FfnBwd p) {
   const bool a_tail = m0 + FFN_BM > p.M;                     // last workgroup of a ragged M: per-lane pointers with the row clamped
   const bf16* a_src = p.a + (size_t)min(m0 + a_row, p.M - 1) * p.FF + a_cc * 8;
   auto stage = [&](int c, int b) __attribute__((always_inline)) {
-    ffn_stage(p.W2T, p.W1T, so, c, smem0 + b * FFN_BUF, wid);
+    if (GEMM) {
+      const bf16* b2 = p.W1T + (size_t)c * FFN_CH;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16s(b2, so.w2[i], smem0 + b * FFN_BUF + FFN_CH * FFN_D * 2 + (32 * wid + 8 * i) * 128);
+    } else {
+      ffn_stage(p.W2T, p.W1T, so, c, smem0 + b * FFN_BUF, wid);
+    }
     if (a_tail) glds16(a_src + c * FFN_CH, smem0 + 2 * FFN_BUF + b * FFN_ATILE + wid * 1024);
     else glds16s(a_base + c * FFN_CH, a_off, smem0 + 2 * FFN_BUF + b * FFN_ATILE + wid * 1024);
   };
@@ -431,6 +441,25 @@ ffn_bwd_kernel(FfnBwd p) {
 #define W1F(buf_, t_, ks_) (*reinterpret_cast<const bf16x8*>((buf_) + w1_lane + (t_) * (16 * 512) + (((4 * (ks_) + fq) ^ fr) << 4)))
 #define W2F(buf_, j_) (*reinterpret_cast<const bf16x8*>((buf_) + w2_lane + (j_) * (16 * 128)))
 
+  if (GEMM) {
+    // one product per chunk: 16 fragments of W^T, the wave's K slice of the chunk's A tile from LDS, 16 MFMAs
+    for (int c = 0; c < NC; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (c + 1 < NC) {
+        stage(chunk_of(c + 1), (c + 1) & 1);
+      } else if (LN_OUT) {
+        ffn_stage_rows(p.x, m0, p.M, smem0 + ((c + 1) & 1) * FFN_BUF, wid, lane);
+      }
+      const unsigned char* buf = ffn_smem + (c & 1) * FFN_BUF;
+      const bf16x8 av = *reinterpret_cast<const bf16x8*>(ffn_smem + 2 * FFN_BUF + (c & 1) * FFN_ATILE + at_lane);
+      bf16x8 fw[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) fw[j] = W2F(buf, j);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], av, acc2[j], 0, 0, 0);
+    }
+  } else {
   // the forward kernel's software pipeline across the chunk barrier (see there): | M1(c)[s] , read W1T(c)[s] | swish'(a) (c) |
   // BARRIER c | M2(c)[s] , read W2T(c+1)[s] | M1(c+1)[s] , read W1T(c+1)[s] | ...
   bf16x8 f[4][4];
@@ -493,6 +522,7 @@ ffn_bwd_kernel(FfnBwd p) {
     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc2[4 * s4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[s4][i], daA, acc2[4 * s4 + i], 0, 0, 0);
+  }
   }
 #undef W1F
 #undef W2F
@@ -620,12 +650,33 @@ extern "C" int lidk_ffn_bwd(const void* dyT, const void* a, const void* W2T, int
   const int lds = 2 * FFN_BUF + 2 * FFN_ATILE;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int grid = cdiv(M, FFN_BM);
-  if (dh) ffn_bwd_kernel<false><<<grid, 512, lds, as_stream(stream)>>>(p);
-  else ffn_bwd_kernel<true><<<grid, 512, lds, as_stream(stream)>>>(p);
+  if (dh) ffn_bwd_kernel<false, false><<<grid, 512, lds, as_stream(stream)>>>(p);
+  else ffn_bwd_kernel<true, false><<<grid, 512, lds, as_stream(stream)>>>(p);
+  return launch_status();
+}
+
+extern "C" int lidk_dgrad_ln_bwd_supported(int M, int N, int K, int dtype) {
+  return dtype == LIDK_BF16 && N == FFN_D && M > 0 && K >= FFN_CH && K % FFN_CH == 0;
+}
+
+extern "C" int lidk_dgrad_ln_bwd(const void* dy, const void* WT, int ldwt, const float* x, const float* mean, const float* rstd,
+                                 const float* gamma, const float* dres, float* dx, void* dxT, float dxT_scale, float* partial, int M,
+                                 int N, int K, int dtype, void* stream) {
+  if (!dy || !WT || !x || !mean || !rstd || !gamma || !partial || (!dx && !dxT)) return LIDK_ERR_ARG;
+  if (!lidk_dgrad_ln_bwd_supported(M, N, K, dtype) || ldwt != K) return LIDK_ERR_UNSUPPORTED;
+  FfnBwd p{nullptr, (const bf16*)dy, nullptr, (const bf16*)WT, nullptr, x, mean, rstd, gamma, dres, dx, (bf16*)dxT, dxT_scale, partial,
+           nullptr, M, K, ffn_rot(), ffn_dbg()};
+  const int lds = 2 * FFN_BUF + 2 * FFN_ATILE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  ffn_bwd_kernel<true, true><<<cdiv(M, FFN_BM), 512, lds, as_stream(stream)>>>(p);
   return launch_status();
 }

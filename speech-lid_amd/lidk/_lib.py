@@ -64,6 +64,8 @@ SIGNATURES = {
     "lidk_ffn_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
     "lidk_ffn_bwd_partial_rows": (_I, [_I]),
     "lidk_ffn_bwd": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P]),
+    "lidk_dgrad_ln_bwd_supported": (_I, [_I, _I, _I, _I]),
+    "lidk_dgrad_ln_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     "lidk_gemm_tn": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _I, _I, _P]),
     "lidk_gemm_tn_desc_bytes": (_I, []),
     "lidk_gemm_tn_grouped": (_I, [_P, _I, _I, _I, _P]),

@@ -731,6 +731,30 @@ class Engine:
         else:
             self.k.layernorm_bwd(dy, x, mean, rstd, P["ln_w"], lnp, dtype=self.act_dtype, **kw)
 
+    def _dgrad_ln_bwd(self, w: _Work, dy, WT, K: int, x, mean, rstd, P, lnp, wg: bool, dres, dx, dxT, dxT_scale):
+        """Data gradient of the projection behind a PreNorm (N = d) followed by that LayerNorm's backward: lidk_gemm_nt +
+        lidk_layernorm_bwd through w.dh, or (LIDK_DGRAD_LN=1) the one-launch form lidk_dgrad_ln_bwd (csrc/ffn.hip).  The fused form is
+        correct (tests/test_gpu_ffn.py) but measured no faster end to end - 7.43-7.46 vs 7.34-7.43 ms per step, same box, two rounds:
+        151 row-panel workgroups do not beat a 604-workgroup GEMM plus a streaming pass when only one intermediate ([M, 256] bf16)
+        is saved - so it is off by default and kept for the record."""
+        M, d = w.M, self.cfg.d
+        key = ("dln", M, K)
+        ok = self._split_ok.get(key)
+        if ok is None:
+            ok = self._split_ok[key] = bool(self._hip and hasattr(self.k, "dgrad_ln_bwd") and _os_env("LIDK_DGRAD_LN", "0") == "1"
+                                            and WT.stride(0) == K and self.k.dgrad_ln_bwd_supported(M, d, K, self.act_dtype))
+        lnp_rows = w.__dict__.setdefault("_lnp_rows", {})
+        if not ok:
+            lnp_rows[id(lnp)] = 0
+            self.k.gemm_nt(dy, WT, w.dh, N=d, K=K)
+            self._ln_bwd(w, w.dh, x, mean, rstd, P, lnp, wg, dres=dres, dx=dx, dxT=dxT, dxT_scale=dxT_scale)
+            return
+        rows = self.k.ffn_bwd_partial_rows(M)
+        lnp_rows[id(lnp)] = rows
+        self.k.dgrad_ln_bwd(dy, WT, x, mean, rstd, P["ln_w"], lnp, dres=dres, dx=dx, dxT=dxT, dxT_scale=dxT_scale)
+        if wg:
+            self.k.layernorm_param_grads_rows(lnp, rows, d, P["dln_w"], P["dln_b"])
+
     def _ff_bwd(self, w: _Work, dx_res, dyT, x_in, P, h, a, u, mean, rstd, dx_out, dxT_out, dxT_scale, da_buf, wg: bool, lnp,
                 fuse=None):
         """dyT = 0.5*dx_res (T).  Produces dx_out = dx_res + LN'(dh) and optional T copy for the next stage.
@@ -804,8 +828,7 @@ class Engine:
             if wg:
                 self._conv_wgrad(w, bp, bb, S)
                 self._wgrad(w, dy1, bb.h3, C["dw1"].view(2 * ci, d), 2 * ci, d, C["db1"])
-            self.k.gemm_nt(dy1, C["w1"][1], w.dh, N=d, K=2 * ci)
-            self._ln_bwd(w, w.dh, bb.x2, bb.mean[2], bb.rstd[2], C, S.lnp[2], wg, dres=dx3, dx=b, dxT=t2, dxT_scale=1.0)
+            self._dgrad_ln_bwd(w, dy1, C["w1"][1], 2 * ci, bb.x2, bb.mean[2], bb.rstd[2], C, S.lnp[2], wg, dx3, b, t2, 1.0)
             dx2 = b
             # ---- attention: y = x1 + attn(x1)
             A = bp.attn
@@ -822,8 +845,7 @@ class Engine:
                             None if split else A["demb"], S.dsc, B, T, bp.heads, bp.dh, rel_emb_T=A["embT"])
             if wg:
                 self._wgrad(w, dqkv, bb.h2, A["dwqkv"], 3 * inner, d)
-            self.k.gemm_nt(dqkv, A["wqkv"][1], w.dh, N=d, K=3 * inner)
-            self._ln_bwd(w, w.dh, bb.x1, bb.mean[1], bb.rstd[1], A, S.lnp[3], wg, dres=dx2, dx=a, dxT=t3, dxT_scale=0.5)
+            self._dgrad_ln_bwd(w, dqkv, A["wqkv"][1], 3 * inner, bb.x1, bb.mean[1], bb.rstd[1], A, S.lnp[3], wg, dx2, a, t3, 0.5)
             dx1 = a
             # ---- ff1
             self._ff_bwd(w, dx1, t3, x_in, bp.ff1, bb.h1, bb.a1, bb.u1, bb.mean[0], bb.rstd[0], dx_in_out, None, 1.0, S.da[1], wg,

@@ -351,6 +351,17 @@ def ffn_bwd(dyT, a, W1T, W2T, da, x=None, mean=None, rstd=None, gamma=None, dres
           "ffn_bwd")
 
 
+def dgrad_ln_bwd_supported(M, N, K, dtype):
+    return bool(lib().lidk_dgrad_ln_bwd_supported(M, N, K, dtype_code(dtype)))
+
+
+def dgrad_ln_bwd(dy, WT, x, mean, rstd, gamma, partial, dres=None, dx=None, dxT=None, dxT_scale=1.0):
+    """dh = dy @ W (WT = W^T [256, K]); dx = dres + LN'(dh), dxT = dxT_scale * dx; partial (dgamma | dbeta) rows; see lidk_dgrad_ln_bwd."""
+    M, K = dy.shape
+    check(lib().lidk_dgrad_ln_bwd(_p(dy), _pv(WT), WT.stride(0), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dxT),
+                                  dxT_scale, _p(partial), M, WT.shape[0], K, _code(dy), _stream()), "dgrad_ln_bwd")
+
+
 def layernorm_param_grads_rows(partial, rows, C, dgamma, dbeta):
     check(lib().lidk_layernorm_param_grads_rows(_p(partial), rows, C, _p(dgamma), _p(dbeta), _stream()), "layernorm_param_grads_rows")
 

@@ -185,3 +185,47 @@ def test_grouped_layernorm_param_grads_equal_the_single_launches():
     torch.cuda.synchronize()
     for a, b in zip(dg0 + db0, dg1 + db1):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,K", [(9664, 1024), (9664, 768), (200, 64), (151, 512)])
+def test_dgrad_ln_bwd_matches_torch_and_the_two_launches(M, K):
+    """lidk_dgrad_ln_bwd: data gradient of a projection behind a PreNorm + that LayerNorm's backward (lid/conformer.py:81-89 with
+    :98-100 / :192), against fp32 torch on the bf16-rounded operands and against lidk_gemm_nt + lidk_layernorm_bwd."""
+    g = torch.Generator().manual_seed(M + K)
+    dy = (0.5 * torch.randn(M, K, generator=g)).to(BF).float()
+    W = (torch.randn(K, 256, generator=g) / 16).to(BF).float()           # y = h @ W^T-style weight [K_out = K][256]
+    x = torch.randn(M, 256, generator=g) * 1.5 + 0.2
+    gamma = 1 + 0.1 * torch.randn(256, generator=g)
+    dres = torch.randn(M, 256, generator=g)
+    dh = dy @ W
+    mean = x.mean(1, keepdim=True)
+    rstd = (x.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    xh = (x - mean) * rstd
+    gg = dh * gamma
+    rdx = dres + rstd * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True))
+    rdg, rdb = (dh * xh).sum(0), dh.sum(0)
+    assert ops.dgrad_ln_bwd_supported(M, 256, K, BF)
+    WT = W.t().contiguous().to(DEV, BF)                                  # [256][K]
+    e = lambda *s, dt=BF: torch.full(s, float("nan"), device=DEV, dtype=dt)
+    dx, dxT = e(M, 256, dt=torch.float32), e(M, 256)
+    rows = ops.ffn_bwd_partial_rows(M)
+    partial = e(rows * 512, dt=torch.float32)
+    args = dict(x=x.to(DEV), mean=mean[:, 0].contiguous().to(DEV), rstd=rstd[:, 0].contiguous().to(DEV), gamma=gamma.to(DEV))
+    ops.dgrad_ln_bwd(dy.to(DEV, BF), WT, args["x"], args["mean"], args["rstd"], args["gamma"], partial, dres=dres.to(DEV), dx=dx, dxT=dxT,
+                     dxT_scale=0.5)
+    dg, db = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+    ops.layernorm_param_grads_rows(partial, rows, 256, dg, db)
+    torch.cuda.synchronize()
+    scale = float(rdx.abs().max())
+    d = (dx.cpu() - rdx).abs()
+    assert float(d.max()) <= 2e-3 * scale and float(d.mean()) <= 1e-4 * scale, (float(d.max()), float(d.mean()), scale)
+    assert float((dxT.float().cpu() - 0.5 * rdx).abs().max()) <= 2 ** -7 * 0.5 * scale
+    for name, got, ref in (("dgamma", dg, rdg), ("dbeta", db, rdb)):
+        assert float((got.cpu() - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-3, name
+    # the two launches it replaces (dh rounded to bf16 in between)
+    dh0, dx0 = torch.empty(M, 256, device=DEV, dtype=BF), torch.empty(M, 256, device=DEV)
+    part0 = torch.empty(max(L.LN_PARTIAL_BLOCKS * 2 * 1024, L.LN_BWD_BLOCKS * 512), device=DEV)
+    ops.gemm_nt(dy.to(DEV, BF), WT, dh0, N=256, K=K)
+    ops.layernorm_bwd(dh0, args["x"], args["mean"], args["rstd"], args["gamma"], part0, dres=dres.to(DEV), dx=dx0)
+    torch.cuda.synchronize()
+    assert float((dx0 - dx).abs().max()) <= 1e-2 * scale and float((dx0 - dx).abs().mean()) <= 5e-4 * scale
