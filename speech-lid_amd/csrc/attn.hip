@@ -4,6 +4,7 @@
 // relative term is q.(E[i-j]) read from an LDS slice of the embedding table.
 //   scores[i][j] = scale * sum_d q[i][d] * (k[j][d] + emb[clamp(i-j,-P,P)+P][d])
 #include "common.h"
+#include <stdlib.h>
 
 #define ATT_ROWS 16   // query rows per workgroup (4 waves x 4 rows)
 
@@ -875,6 +876,9 @@ static void att_bwd_relpos_launch(const void* qkv, const void* dsT, int ldp, flo
 #undef LIDK_COLS_LAUNCH
 
 // ------------------------------------------------------------------------------------ host side
+// key-tiled MFMA kernels with Shaw relative positions (attn_shaw.hip)
+int att_shaw_fwd(const void* qkv, const void* embT, void* out, void* probs, int ldp, int B, int T_, int H, int dh, int max_pos,
+                 hipStream_t s);
 // key-tiled kernels for sequences whose K / V / E do not fit in LDS (attn_long.hip)
 template <typename T>
 int att_long_fwd(const void* qkv, const float* emb, void* out, void* probs, int ldp, int B, int T_, int H, int dh, int max_pos,
@@ -911,6 +915,10 @@ extern "C" int lidk_attn_fwd(const void* qkv, const float* rel_emb, const void* 
     }
     return launch_status();
   }
+  // beyond the resident MFMA kernels (T > 256): the key-tiled MFMA kernel of attn_shaw.hip (LIDK_ATTN_SHAW=0: the VALU kernels)
+  static const bool shaw = !(getenv("LIDK_ATTN_SHAW") && atoi(getenv("LIDK_ATTN_SHAW")) == 0);
+  if (shaw && dtype == LIDK_BF16 && rel_emb_T && (dh == 32 || dh == 64))
+    return att_shaw_fwd(qkv, rel_emb_T, out, probs, ldp, B, T_, heads, dh, max_pos, s);
   dim3 grid(cdiv(T_, ATT_ROWS), heads, B);
   if (dtype == LIDK_BF16) {
     size_t lds = att_rows_lds<bf16>(T_, dh);

@@ -309,7 +309,8 @@ def test_attention_fwd_bwd(dt, B, T, H, dh, maxpos, path):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("B,T,H,dh,maxpos", [(1, 600, 4, 64, 512), (1, 835, 2, 64, 512), (2, 420, 8, 32, 512), (1, 1100, 1, 64, 512)])
+@pytest.mark.parametrize("B,T,H,dh,maxpos", [(1, 600, 4, 64, 512), (1, 835, 2, 64, 512), (2, 420, 8, 32, 512), (1, 1100, 1, 64, 512),
+                                             (2, 301, 4, 64, 512), (1, 257, 8, 32, 512)])
 def test_attention_long_sequences(dt, B, T, H, dh, maxpos):
     """Sequences beyond the LDS-resident kernels (ADVICE r1: conf max_duration 12 s -> T = 600, validation 16.7 s -> T = 835;
     T = 1100 also exceeds the relative-position table, so offsets clamp at +-512): the key-tiled kernels against torch."""
