@@ -879,6 +879,10 @@ static void att_bwd_relpos_launch(const void* qkv, const void* dsT, int ldp, flo
 // key-tiled MFMA kernels with Shaw relative positions (attn_shaw.hip)
 int att_shaw_fwd(const void* qkv, const void* embT, void* out, void* probs, int ldp, int B, int T_, int H, int dh, int max_pos,
                  hipStream_t s);
+int att_shaw_bwd_rows(const void* qkv, const void* embT, const void* probs, int ldp, const void* dout, void* dqkv, float* dscores,
+                      int B, int T_, int H, int dh, int max_pos, hipStream_t s);
+int att_long_cols_bf16(const void* qkv, const void* probs, int ldp, const void* dout, const float* dscores, void* dqkv, float* demb,
+                       int B, int T_, int H, int dh, int max_pos, hipStream_t s);
 // key-tiled kernels for sequences whose K / V / E do not fit in LDS (attn_long.hip)
 template <typename T>
 int att_long_fwd(const void* qkv, const float* emb, void* out, void* probs, int ldp, int B, int T_, int H, int dh, int max_pos,
@@ -1003,6 +1007,13 @@ extern "C" int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* 
     if (dh == 64) att_bwd_mfma_launch<64>(qkv, rel_emb_T, probs, ldp, dout, dqkv, drel_emb, dscores, g, s);
     else att_bwd_mfma_launch<32>(qkv, rel_emb_T, probs, ldp, dout, dqkv, drel_emb, dscores, g, s);
     return launch_status();
+  }
+  // beyond the resident MFMA kernels: row side (dS, dQ) by the key-tiled MFMA kernel of attn_shaw.hip, key side by attn_long.hip
+  static const bool shaw = !(getenv("LIDK_ATTN_SHAW") && atoi(getenv("LIDK_ATTN_SHAW")) == 0);
+  if (shaw && dtype == LIDK_BF16 && rel_emb_T && probs && drel_emb && (dh == 32 || dh == 64)) {
+    const int rc = att_shaw_bwd_rows(qkv, rel_emb_T, probs, ldp, dout, dqkv, dscores, B, T_, heads, dh, max_pos, s);
+    if (rc != LIDK_OK) return rc;
+    return att_long_cols_bf16(qkv, probs, ldp, dout, dscores, dqkv, drel_emb, B, T_, heads, dh, max_pos, s);
   }
   if (dtype == LIDK_BF16) return att_bwd_launch<bf16>(qkv, rel_emb, probs, ldp, dout, dqkv, drel_emb, dscores, g, s);
   if (dtype == LIDK_F32) return att_bwd_launch<float>(qkv, rel_emb, probs, ldp, dout, dqkv, drel_emb, dscores, g, s);

@@ -307,6 +307,17 @@ int att_long_bwd(const void* qkv, const float* emb, const void* probs, int ldp, 
   return launch_status();
 }
 
+// only the key-side kernel (dK, dV, relative-embedding gradient from probs + dscores): attn_shaw.hip supplies the row side
+int att_long_cols_bf16(const void* qkv, const void* probs, int ldp, const void* dout, const float* dscores, void* dqkv, float* demb,
+                       int B, int T_, int H, int dh, int max_pos, hipStream_t s) {
+  AttGeomL g{B, T_, H, dh, max_pos, H * dh, 3 * H * dh};
+  const float scale = 1.0f / sqrtf((float)dh);
+  if (dh == 64) atl_cols_launch<bf16, 64>(qkv, probs, dout, dscores, dqkv, demb, g, ldp, scale, s);
+  else if (dh == 32) atl_cols_launch<bf16, 32>(qkv, probs, dout, dscores, dqkv, demb, g, ldp, scale, s);
+  else return LIDK_ERR_UNSUPPORTED;
+  return launch_status();
+}
+
 template int att_long_fwd<bf16>(const void*, const float*, void*, void*, int, int, int, int, int, int, hipStream_t);
 template int att_long_fwd<float>(const void*, const float*, void*, void*, int, int, int, int, int, int, hipStream_t);
 template int att_long_bwd<bf16>(const void*, const float*, const void*, int, const void*, void*, float*, float*, int, int, int,

@@ -175,6 +175,143 @@ attn_fwd_shaw_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT
   }
 }
 
+// ------------------------------------------------------------------------------------ backward: dS rows and dQ
+// Same decomposition, STORED probabilities (the forward above wrote them):
+//   pass A (V tiles): dP^T = V . dO^T by MFMA, delta_i = sum_j P_ij dP_ij;
+//   pass B (K / V / E tiles): dS = P (dP - delta) -> dscores [B][H][T][T] f32 (unscaled: the key-side kernel of attn_long.hip reads
+//           it for dK, dV and the relative-embedding gradient), dQ += dS . K (the dS accumulators, packed, are the A operand) and
+//           dQ += dR . E_window, where dR[i][e] = dS[i][j = i - base - e] is scattered into a per-wave [16][96] bf16 LDS tile
+//           (each (i, e) is hit by exactly one key of the tile, the rest of the zeroed tile stays 0) and read back as A fragments.
+#define SH_DLD 104                  // row pitch (bf16) of the per-wave dR tile [16][96]
+
+template <int DH>
+__global__ void __launch_bounds__(256)
+attn_bwd_rows_shaw_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT, const bf16* __restrict__ probs, int ldp,
+                          const bf16* __restrict__ dout, bf16* __restrict__ dqkv, float* __restrict__ dscores, ShGeom g) {
+  constexpr int LDK = DH + 8, KS = DH / 32, NT = DH / 16;
+  __shared__ __attribute__((aligned(16))) bf16 Ks[SH_TILE * LDK];
+  __shared__ __attribute__((aligned(16))) bf16 Vs[SH_TILE * LDK];
+  __shared__ __attribute__((aligned(16))) bf16 Es[SH_EROWS * LDK];
+  __shared__ __attribute__((aligned(16))) bf16 Dl[4 * 16 * SH_DLD];
+  const int T_ = g.T, H = g.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H, I0 = blockIdx.y * SH_TILE;
+  const bf16* base = qkv + (size_t)b * T_ * g.ld + h * DH;
+  const int i = I0 + 16 * wave + fr, ic = min(i, T_ - 1);
+  bf16* D = Dl + wave * 16 * SH_DLD;
+  bf16x8 dof[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    dof[ks] = *reinterpret_cast<const bf16x8*>(dout + ((size_t)b * T_ + ic) * g.inner + h * DH + ks * 32 + 8 * fq);
+  const bf16* prow = probs + ((size_t)bh * T_ + ic) * ldp;
+  const bool pvec = !(ldp & 3);
+  // P of this lane's query against keys jt0 + 16 t + 4 fq + r (0 beyond T)
+  auto load_p = [&](float (&pv)[4][4], int jt0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = jt0 + 16 * t + 4 * fq;
+      if (pvec && j + 3 < T_) {
+        const float4 v = load4(prow + j);
+        pv[t][0] = v.x; pv[t][1] = v.y; pv[t][2] = v.z; pv[t][3] = v.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[t][r] = (j + r < T_) ? (float)prow[j + r] : 0.f;
+      }
+    }
+  };
+  auto dp_tiles = [&](float (&dp)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vs[(16 * t + fr) * LDK + ks * 32 + 8 * fq]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dp[t][r] = acc[r];
+    }
+  };
+
+  // ---- pass A: delta_i = sum_j P_ij * dP_ij
+  float delta = 0.f;
+  for (int jt0 = 0; jt0 < T_; jt0 += SH_TILE) {
+    __syncthreads();
+    sh_stage_rows<DH>(Vs, base + 2 * g.inner, g.ld, jt0, T_);
+    __syncthreads();
+    float pv[4][4], dp[4][4];
+    load_p(pv, jt0);
+    dp_tiles(dp);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) delta = fmaf(pv[t][r], dp[t][r], delta);
+  }
+  delta += __shfl_xor(delta, 16, 64);
+  delta += __shfl_xor(delta, 32, 64);
+
+  // ---- pass B: dS (stored), dQ
+  f32x4 dq[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) dq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float* dsrow = dscores + ((size_t)bh * T_ + ic) * T_;
+  const bool svec = !(T_ & 3);
+  for (int jt0 = 0; jt0 < T_; jt0 += SH_TILE) {
+    __syncthreads();
+    sh_stage_rows<DH>(Ks, base + g.inner, g.ld, jt0, T_);
+    sh_stage_rows<DH>(Vs, base + 2 * g.inner, g.ld, jt0, T_);
+    sh_stage_e<DH>(Es, embT, I0 - jt0 - 63, g.max_pos);
+    // zero this wave's dR tile (16 x 104 bf16 = 208 16-byte pieces)
+    for (int c = lane; c < 16 * SH_DLD / 8; c += 64) *reinterpret_cast<uint4*>(&D[c * 8]) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    float pv[4][4], ds[4][4];
+    load_p(pv, jt0);
+    dp_tiles(ds);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[t][r] = pv[t][r] * (ds[t][r] - delta);
+      const int j = jt0 + 16 * t + 4 * fq;
+      if (i < T_) {
+        if (svec && j + 3 < T_) {
+          *reinterpret_cast<float4*>(dsrow + j) = make_float4(ds[t][0], ds[t][1], ds[t][2], ds[t][3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (j + r < T_) dsrow[j + r] = ds[t][r];
+        }
+      }
+      // scatter into dR[i = fr][e = fr + 63 - (16 t + 4 fq + r)]
+      bf16* drow = D + fr * SH_DLD + fr + 63 - 16 * t - 4 * fq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) drow[-r] = (bf16)ds[t][r];
+    }
+    // dQ += dS . K : the dS accumulators (two stacked 16-key tiles, slot-permuted) are the A operand
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bf16x8 sf = sh_pack(ds[2 * c], ds[2 * c + 1]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        dq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, tr_frag_split(Ks, LDK, 32 * c, nt * 16, fq, fr), dq[nt], 0, 0, 0);
+    }
+    // dQ += dR . E_window : A = dR rows (LDS), B = E_window^T by transposed reads; 96 window rows = 3 K steps
+#pragma unroll
+    for (int k3 = 0; k3 < 3; ++k3) {
+      const bf16x8 rf = *reinterpret_cast<const bf16x8*>(&D[fr * SH_DLD + 32 * k3 + 8 * fq]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        dq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf, tr_frag(Es + 16 * wave * LDK, LDK, 32 * k3, nt * 16, fq, fr), dq[nt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int io = I0 + 16 * wave + 4 * fq + r;
+    if (io < T_) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) dqkv[((size_t)b * T_ + io) * g.ld + h * DH + nt * 16 + fr] = (bf16)(dq[nt][r] * g.scale);
+    }
+  }
+}
+
 // host side (called from lidk_attn_fwd, attn.hip)
 int att_shaw_fwd(const void* qkv, const void* embT, void* out, void* probs, int ldp, int B, int T_, int H, int dh, int max_pos,
                  hipStream_t s) {
@@ -182,6 +319,19 @@ int att_shaw_fwd(const void* qkv, const void* embT, void* out, void* probs, int 
   const dim3 grid(B * H, cdiv(T_, SH_TILE));
   if (dh == 64) attn_fwd_shaw_kernel<64><<<grid, 256, 0, s>>>((const bf16*)qkv, (const bf16*)embT, (bf16*)out, (bf16*)probs, ldp, g);
   else if (dh == 32) attn_fwd_shaw_kernel<32><<<grid, 256, 0, s>>>((const bf16*)qkv, (const bf16*)embT, (bf16*)out, (bf16*)probs, ldp, g);
+  else return LIDK_ERR_UNSUPPORTED;
+  return launch_status();
+}
+
+// writes the dQ third of dqkv and dscores [B][H][T][T] (f32); the key-side kernel of attn_long.hip follows (lidk_attn_bwd)
+int att_shaw_bwd_rows(const void* qkv, const void* embT, const void* probs, int ldp, const void* dout, void* dqkv, float* dscores,
+                      int B, int T_, int H, int dh, int max_pos, hipStream_t s) {
+  ShGeom g{B, T_, H, max_pos, H * dh, 3 * H * dh, 1.0f / sqrtf((float)dh)};
+  const dim3 grid(B * H, cdiv(T_, SH_TILE));
+  if (dh == 64) attn_bwd_rows_shaw_kernel<64><<<grid, 256, 0, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)probs, ldp,
+                                                                   (const bf16*)dout, (bf16*)dqkv, dscores, g);
+  else if (dh == 32) attn_bwd_rows_shaw_kernel<32><<<grid, 256, 0, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)probs, ldp,
+                                                                        (const bf16*)dout, (bf16*)dqkv, dscores, g);
   else return LIDK_ERR_UNSUPPORTED;
   return launch_status();
 }
