@@ -883,6 +883,8 @@ int att_shaw_bwd_rows(const void* qkv, const void* embT, const void* probs, int 
                       int B, int T_, int H, int dh, int max_pos, hipStream_t s);
 int att_long_cols_bf16(const void* qkv, const void* probs, int ldp, const void* dout, const float* dscores, void* dqkv, float* demb,
                        int B, int T_, int H, int dh, int max_pos, hipStream_t s);
+int att_shaw_bwd_cols(const void* qkv, const void* probs, int ldp, const void* dout, const float* dscores, void* dqkv, float* demb,
+                      int B, int T_, int H, int dh, int max_pos, hipStream_t s);
 // key-tiled kernels for sequences whose K / V / E do not fit in LDS (attn_long.hip)
 template <typename T>
 int att_long_fwd(const void* qkv, const float* emb, void* out, void* probs, int ldp, int B, int T_, int H, int dh, int max_pos,
@@ -1013,6 +1015,8 @@ extern "C" int lidk_attn_bwd(const void* qkv, const float* rel_emb, const void* 
   if (shaw && dtype == LIDK_BF16 && rel_emb_T && probs && drel_emb && (dh == 32 || dh == 64)) {
     const int rc = att_shaw_bwd_rows(qkv, rel_emb_T, probs, ldp, dout, dqkv, dscores, B, T_, heads, dh, max_pos, s);
     if (rc != LIDK_OK) return rc;
+    static const bool shaw_cols = !(getenv("LIDK_ATTN_SHAW_COLS") && atoi(getenv("LIDK_ATTN_SHAW_COLS")) == 0);
+    if (shaw_cols) return att_shaw_bwd_cols(qkv, probs, ldp, dout, dscores, dqkv, drel_emb, B, T_, heads, dh, max_pos, s);
     return att_long_cols_bf16(qkv, probs, ldp, dout, dscores, dqkv, drel_emb, B, T_, heads, dh, max_pos, s);
   }
   if (dtype == LIDK_BF16) return att_bwd_launch<bf16>(qkv, rel_emb, probs, ldp, dout, dqkv, drel_emb, dscores, g, s);

@@ -312,6 +312,128 @@ attn_bwd_rows_shaw_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------ backward: dK, dV
+// Workgroup = 64 keys of one (batch, head), a wave owns 16 of them; loop over 64-row query tiles.  The stored P (bf16) and dS (f32,
+// rounded to bf16 here) tiles are staged row-major [query][key] in LDS with coalesced loads and enter the MFMAs through transposed
+// reads: dV += P^T . dO, dK += dS^T . Q with A[row = key][k = query] = tr_frag(P or dS tile), B[k = query][n = d] = tr_frag(dO or Q tile).
+#define SH_PLD 72                   // row pitch (bf16) of the staged [64][64] P / dS tiles
+
+// tile[il][jl] = src[(row0 + il) * pitch + col0 + jl] (0 outside [0, T) x [0, T)), 64 x 64, T = float or bf16 -> bf16 in LDS
+template <typename TS>
+__device__ __forceinline__ void sh_stage_tile(bf16* dst, const TS* __restrict__ src, size_t pitch, int row0, int col0, int T_) {
+  for (int c = threadIdx.x; c < 64 * 16; c += blockDim.x) {
+    const int il = c >> 4, jl = (c & 15) * 4, i = row0 + il, j = col0 + jl;
+    union { bf16 e[4]; uint2 u; } pk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pk.e[r] = (i < T_ && j + r < T_) ? (bf16)(float)src[(size_t)i * pitch + j + r] : (bf16)0.f;
+    *reinterpret_cast<uint2*>(&dst[il * SH_PLD + jl]) = pk.u;
+  }
+}
+
+template <int DH>
+__global__ void __launch_bounds__(256)
+attn_bwd_kv_shaw_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ probs, int ldp, const bf16* __restrict__ dout,
+                        const float* __restrict__ dscores, bf16* __restrict__ dqkv, ShGeom g) {
+  constexpr int LDK = DH + 8, NT = DH / 16;
+  __shared__ __attribute__((aligned(16))) bf16 Qs[SH_TILE * LDK];
+  __shared__ __attribute__((aligned(16))) bf16 Ds[SH_TILE * LDK];
+  __shared__ __attribute__((aligned(16))) bf16 Ps[SH_TILE * SH_PLD];
+  __shared__ __attribute__((aligned(16))) bf16 Ss[SH_TILE * SH_PLD];
+  const int T_ = g.T, H = g.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H, J0 = blockIdx.y * SH_TILE;
+  const bf16* base = qkv + (size_t)b * T_ * g.ld + h * DH;
+  const bf16* pb = probs + (size_t)bh * T_ * ldp;
+  const float* sb = dscores + (size_t)bh * T_ * T_;
+  f32x4 dk[NT], dv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { dk[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int it0 = 0; it0 < T_; it0 += SH_TILE) {
+    __syncthreads();
+    sh_stage_rows<DH>(Qs, base, g.ld, it0, T_);
+    sh_stage_rows<DH>(Ds, dout + (size_t)b * T_ * g.inner + h * DH, g.inner, it0, T_);
+    sh_stage_tile<bf16>(Ps, pb, ldp, it0, J0, T_);
+    sh_stage_tile<float>(Ss, sb, T_, it0, J0, T_);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bf16x8 pa = tr_frag(Ps, SH_PLD, 32 * c, 16 * wave, fq, fr), sa = tr_frag(Ss, SH_PLD, 32 * c, 16 * wave, fq, fr);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        dv[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, tr_frag(Ds, LDK, 32 * c, nt * 16, fq, fr), dv[nt], 0, 0, 0);
+        dk[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, tr_frag(Qs, LDK, 32 * c, nt * 16, fq, fr), dk[nt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int jo = J0 + 16 * wave + 4 * fq + r;
+    if (jo < T_) {
+      bf16* row = dqkv + ((size_t)b * T_ + jo) * g.ld + h * DH;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        row[g.inner + nt * 16 + fr] = (bf16)(dk[nt][r] * g.scale);
+        row[2 * g.inner + nt * 16 + fr] = (bf16)dv[nt][r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ backward: relative-embedding gradient
+// dE[clamp(o) + P][d] += scale * sum_i dS[i][i - o] q_i[d].  Workgroup = 64 consecutive offsets o0 .. o0 + 63 of one (batch, head), a
+// wave owns 16 of them; loop over the 64-row query tiles whose diagonals intersect the score matrix.  The skewed tile
+// Sk[i][o] = dS[i][i - o] is built in LDS from contiguous pieces of dS rows (64 consecutive keys per query, reversed), then
+// dE_tile += Sk^T . Q by MFMA (contraction over the 64 queries); one atomic flush per workgroup at the end.
+template <int DH>
+__global__ void __launch_bounds__(256)
+attn_bwd_rel_shaw_kernel(const bf16* __restrict__ qkv, const float* __restrict__ dscores, float* __restrict__ demb, ShGeom g) {
+  constexpr int LDK = DH + 8, NT = DH / 16;
+  __shared__ __attribute__((aligned(16))) bf16 Qs[SH_TILE * LDK];
+  __shared__ __attribute__((aligned(16))) bf16 Sk[SH_TILE * SH_PLD];
+  const int T_ = g.T, H = g.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int o0 = (int)blockIdx.y * SH_TILE - (T_ - 1);                 // offsets o0 .. o0 + 63 (i - j ranges over -(T-1) .. T-1)
+  const bf16* base = qkv + (size_t)b * T_ * g.ld + h * DH;
+  const float* sb = dscores + (size_t)bh * T_ * T_;
+  f32x4 de[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) de[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // queries with a valid key for some offset of the window: 0 <= i - o < T for o in [o0, o0 + 63]  ->  i in [max(0, o0), min(T, T + o0 + 63))
+  const int ilo = max(0, o0) / SH_TILE * SH_TILE, ihi = min(T_, T_ + o0 + 63);
+  for (int it0 = ilo; it0 < ihi; it0 += SH_TILE) {
+    __syncthreads();
+    sh_stage_rows<DH>(Qs, base, g.ld, it0, T_);
+    for (int c = threadIdx.x; c < 64 * 16; c += blockDim.x) {
+      const int il = c >> 4, ol = (c & 15) * 4, i = it0 + il;
+      union { bf16 e[4]; uint2 u; } pk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = i - (o0 + ol + r);
+        pk.e[r] = (i < T_ && j >= 0 && j < T_) ? (bf16)sb[(size_t)i * T_ + j] : (bf16)0.f;
+      }
+      *reinterpret_cast<uint2*>(&Sk[il * SH_PLD + ol]) = pk.u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bf16x8 sa = tr_frag(Sk, SH_PLD, 32 * c, 16 * wave, fq, fr);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        de[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, tr_frag(Qs, LDK, 32 * c, nt * 16, fq, fr), de[nt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = o0 + 16 * wave + 4 * fq + r;
+    if (o <= T_ - 1) {
+      const int row = max(-g.max_pos, min(g.max_pos, o)) + g.max_pos;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) atomicAdd(&demb[(size_t)row * DH + nt * 16 + fr], de[nt][r] * g.scale);
+    }
+  }
+}
+
 // host side (called from lidk_attn_fwd, attn.hip)
 int att_shaw_fwd(const void* qkv, const void* embT, void* out, void* probs, int ldp, int B, int T_, int H, int dh, int max_pos,
                  hipStream_t s) {
@@ -333,5 +455,22 @@ int att_shaw_bwd_rows(const void* qkv, const void* embT, const void* probs, int 
   else if (dh == 32) attn_bwd_rows_shaw_kernel<32><<<grid, 256, 0, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)probs, ldp,
                                                                         (const bf16*)dout, (bf16*)dqkv, dscores, g);
   else return LIDK_ERR_UNSUPPORTED;
+  return launch_status();
+}
+
+// key side on the MFMA path: dK, dV thirds of dqkv from the stored P and dS, then the relative-embedding gradient (accumulated)
+int att_shaw_bwd_cols(const void* qkv, const void* probs, int ldp, const void* dout, const float* dscores, void* dqkv, float* demb,
+                      int B, int T_, int H, int dh, int max_pos, hipStream_t s) {
+  ShGeom g{B, T_, H, max_pos, H * dh, 3 * H * dh, 1.0f / sqrtf((float)dh)};
+  const dim3 grid(B * H, cdiv(T_, SH_TILE)), grid_e(B * H, cdiv(2 * T_ - 1, SH_TILE));
+  if (dh == 64) {
+    attn_bwd_kv_shaw_kernel<64><<<grid, 256, 0, s>>>((const bf16*)qkv, (const bf16*)probs, ldp, (const bf16*)dout, dscores, (bf16*)dqkv, g);
+    if (demb) attn_bwd_rel_shaw_kernel<64><<<grid_e, 256, 0, s>>>((const bf16*)qkv, dscores, demb, g);
+  } else if (dh == 32) {
+    attn_bwd_kv_shaw_kernel<32><<<grid, 256, 0, s>>>((const bf16*)qkv, (const bf16*)probs, ldp, (const bf16*)dout, dscores, (bf16*)dqkv, g);
+    if (demb) attn_bwd_rel_shaw_kernel<32><<<grid_e, 256, 0, s>>>((const bf16*)qkv, dscores, demb, g);
+  } else {
+    return LIDK_ERR_UNSUPPORTED;
+  }
   return launch_status();
 }
