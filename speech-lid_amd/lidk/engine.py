@@ -207,7 +207,11 @@ class _Work:
         class _Set:
             pass
         self.sets = []
-        for _ in range(2):
+        # LIDK_SCRATCH_SETS=3: a third set lets the whole-chain backward leave the weight-gradient stream alone until the end of
+        # a block (with two sets the fused LayerNorm pair at a block's tail writes into the set the previous block's weight
+        # gradients are still reading, so the data-gradient chain joins the second stream before it: a second cross-queue hop per
+        # block in the captured graph).  Measured: 7.39 / 7.30 vs 7.39 / 7.36 ms per step - within noise, so the default stays 2.
+        for _ in range(max(2, int(_os_env("LIDK_SCRATCH_SETS", "2")))):
             S = _Set()
             S.da = [e(M, ff), e(M, ff)]                       # ff2 / ff1 hidden gradients
             S.dy1 = e(M, 2 * ci)                              # conv pointwise-1 output gradient
@@ -1026,13 +1030,14 @@ class Engine:
                 fuse_ok = defer and self._ln2_ok()
                 post_done = False
                 for n, (kind, tag, bpk, bbk, x_in, stage) in enumerate(blocks):
-                    S = w.sets[n & 1]
+                    ns = len(w.sets)
+                    S = w.sets[n % ns]
                     # x_in of this block is the output of the block that follows in backward order (an encoder block, unless
                     # this is encoder block 0): fuse this block's first-PreNorm backward with that block's post_norm backward
                     fuse = None
                     if fuse_ok and n + 1 < len(blocks):
                         nxt = blocks[n + 1]
-                        fuse = (nxt[3], nxt[2].post, w.sets[(n + 1) & 1], prv is not None)
+                        fuse = (nxt[3], nxt[2].post, w.sets[(n + 1) % ns], prv is not None and ns < 3)
                     if prv is not None:
                         with self._fork():
                             self._block_wgrads(w, prv[1], prv[2], prv[3], prv[0][0] == "enc")
