@@ -230,9 +230,10 @@ int lidk_gemm_tn_grouped128(const void* descs, int n_desc, int total_items, void
  * qkv [B*T][3*heads*dh] (T): q | k | v column blocks, head h at columns h*dh.. within each.  rel_emb [2*max_pos+1][dh] f32.
  * scores = (q.k^T + q.rel_emb[clamp(i-j)+max_pos]) * dh^-0.5 ; probs = softmax_j ; out = probs.v -> [B*T][heads*dh] (T).
  * probs [B][heads][T][ldp] (T) is saved for backward. */
-/* Sequence-length limits: the MFMA kernels take T <= 256, the LDS-resident v1 kernels T <= ~390 (dh = 64); longer sequences
- * (12 s training utterances give T = 600, 16.7 s validation utterances T = 835) run through key-tiled kernels of the same
- * arithmetic.  lidk_attn_max_frames = the largest T those accept for a head dimension (16 score rows of T floats must fit in
+/* Sequence-length limits: the resident MFMA kernels take T <= 256 (K, V and the relative-embedding slice of a (batch, head) in LDS);
+ * longer sequences (12 s training utterances give T = 600, 16.7 s validation utterances T = 835) run through key-tiled kernels of
+ * the same arithmetic: for bf16 with rel_emb_T and dh in {32, 64} the MFMA kernels of csrc/attn_shaw.hip (probs and dscores are then
+ * REQUIRED: the four kernels hand P and dS to each other through them), otherwise the VALU kernels of csrc/attn_long.hip.  lidk_attn_max_frames = the largest T those accept for a head dimension (16 score rows of T floats must fit in
  * LDS: 2,069 for bf16 / dh = 64 = 41 s of audio, 1,655 in f32 mode); beyond it lidk_attn_fwd / lidk_attn_bwd return LIDK_ERR_UNSUPPORTED. */
 int lidk_attn_max_frames(int dh, int dtype);
 int lidk_attn_fwd(const void* qkv, const float* rel_emb, const void* rel_emb_T, void* out, void* probs, int ldp, int B, int T,
