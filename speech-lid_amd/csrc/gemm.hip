@@ -514,6 +514,110 @@ gemm_nt_bf16_big_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, 
   }
 }
 
+// ------------------------------------------------------------------------------------ bf16 MFMA kernel, 128x128 tile, LDS-DMA
+// Round 3.  The 128x128 kernel above stages its operands through registers (8 prefetch registers x 4, one barrier per K tile,
+// two waves per SIMD by register count) and only pays for K >= 2048.  Here both operand tiles arrive by global_load_lds_dwordx4
+// (no staging registers, no ds_write pass; csrc/ffn.hip explains the inline asm and the scalar-base addressing): 2 x 32 KB of
+// LDS and ~110 VGPRs per workgroup, so two workgroups (8 waves) share a CU and one's MFMAs cover the other's barrier and DMA
+// waits.  LDS images are lane-linear per wave instruction (8 rows of 128 B); the XOR swizzle of the fragment reads - and, for
+// bf16 outputs, the row permutation that gives a lane 8 consecutive output columns - are applied on the SOURCE addresses.
+// For the d = 768 / ffn 3072 shapes of the transformer backbones (K = 768 ... 3072, hundreds of 128-tiles).
+__device__ __forceinline__ void gemm_glds16s(const void* sbase, unsigned voff, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gemm_nt_bf16_dma_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K, int lda, int ldb, Epi e) {
+  constexpr int BM = 128, BN = 128, TM = 4, TN = 4;
+  typedef __attribute__((address_space(3))) void lds_v;
+  const int n_tiles = N / BN;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  extern __shared__ __attribute__((aligned(16))) unsigned char dma_smem[];       // [2][A 16 KB | B 16 KB]
+  const unsigned smem0 = (unsigned)(size_t)(lds_v*)dma_smem;
+  const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
+  const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+  const bool pair = !e.out_f32;
+  // per-lane byte offsets of this wave's 4 + 4 wave instructions per K tile (tile-row 32 wid + 8 i + lane / 8, chunk lane % 8)
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 32 * wid + 8 * i + (lane >> 3), c = (lane & 7) ^ (row & 7);
+    aoff[i] = (unsigned)(((size_t)(min(m0 + row, M - 1) - m0) * lda + c * 8) * 2);
+    const int n = pair ? (row & ~31) + (((row >> 2) & 3) << 3) + (((row >> 4) & 1) << 2) + (row & 3) : row;   // LDS row -> column
+    boff[i] = (unsigned)(((size_t)n * ldb + c * 8) * 2);
+  }
+  const bf16* abase = A + (size_t)m0 * lda;
+  const bf16* bbase = B + (size_t)n0 * ldb;
+  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+    const unsigned dst = smem0 + buf * 32768 + (32 * wid) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gemm_glds16s(abase + kt * BK, aoff[i], dst + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gemm_glds16s(bbase + kt * BK, boff[i], dst + 16384 + i * 1024);
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nt = K / BK;
+  stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile t landed (this wave's pieces), barrier: everybody's; and
+    __syncthreads();                                       // every wave is done reading the other buffer
+    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+    const bf16* a = reinterpret_cast<const bf16*>(dma_smem + (t & 1) * 32768);
+    const bf16* b = a + BM * BK;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; kk += 4) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(&a[(wm * 64 + i * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(&b[(wn * 64 + j * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  const bool vec = !(e.ldo & 7) && (!e.res || !(e.ldres & 3)) && (!e.out2 || !(e.ldo2 & 7)) && (!e.aux || !(e.ldaux & 7));
+#pragma clang loop unroll(full)
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= M) continue;
+    if (pair) {
+#pragma clang loop unroll(full)
+      for (int c = 0; c < TN / 2; ++c) {
+        const int n = n0 + wn * 64 + 32 * c + 8 * fq;
+        const float4 a0 = make_float4(acc[i][2 * c][0], acc[i][2 * c][1], acc[i][2 * c][2], acc[i][2 * c][3]);
+        const float4 a1 = make_float4(acc[i][2 * c + 1][0], acc[i][2 * c + 1][1], acc[i][2 * c + 1][2], acc[i][2 * c + 1][3]);
+        if (vec) {
+          float4 p0, p1;
+          const float4 v0 = epi_math4(e, m, n, a0, &p0);
+          const float4 v1 = epi_math4(e, m, n + 4, a1, &p1);
+          if ((e.act == LIDK_ACT_SWISH || e.act == LIDK_ACT_GELU) && e.out2) st16(e, (bf16*)e.out2 + (size_t)m * e.ldo2 + n, pack8(p0, p1));
+          st16(e, (bf16*)e.out + (size_t)m * e.ldo + n, pack8(v0, v1));
+        } else {
+          epi_store4<bf16>(e, m, n, N, a0);
+          epi_store4<bf16>(e, m, n + 4, N, a1);
+        }
+      }
+    } else {
+#pragma clang loop unroll(full)
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 64 + 16 * j + 4 * fq;
+        epi_store4<bf16>(e, m, n, N, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ bf16 MFMA kernel, pipelined tiles
 // For the wide K = 256 GEMMs (ff up-projection, its data gradient, QKV, pointwise conv 1) the output stores are half of a
 // launch (ablation in DESIGN.md section 5) and, in gemm_nt_bf16_direct_kernel, purely additive: a wave keeps its slot until
@@ -729,6 +833,28 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
 #undef LIDK_PIPE_LAUNCH
         return launch_status();
       }
+    }
+    // LDS-DMA 128x128 kernel: opt-in, K >= LIDK_GEMM_DMA (e.g. 512; default 0 = never), N % 128 == 0, >= 384 tiles.  Faster per launch
+    // on the backbones' big-K shapes (below) but NOT end to end: WavLM frozen / fine-tune 25.05 / 31.65 ms per step with it against
+    // 24.68 / 31.30 without, wav2vec2 on 1-10 s batches 49.2 / 48.8 against 48.2 / 48.7 (two 64 KB workgroups per CU leave the
+    // weight-gradient stream less room beside it), so it stays off.
+    const char* dma_env = getenv("LIDK_GEMM_DMA");                 // read per call (a test flips it inside one process)
+    const int dma_min_k = dma_env ? atoi(dma_env) : 0;
+    // Measured against the 64x64 / register-staged 128x128 kernels on the backbone shapes (tools/gemm_bench_wavlm.py): K = 3072
+    // +36 % (798 TFLOP/s), conv stack K = 1536 +7...20 %, K = 768 single output +0...7 %; it LOSES with the two-output GELU
+    // epilogue at K = 768 (store-bound) and when the tile count leaves a mostly empty second round (512 < tiles < 1024).
+    const long dma_tiles = (long)cdiv(g->M, 128) * (g->N / 128);
+    if (direct && splitk == 1 && dma_min_k > 0 && g->K >= dma_min_k && (g->K & 63) == 0 && !(g->N & 127) &&
+        (g->K >= 1024 || !g->out2) && dma_tiles >= 384 && (dma_tiles <= 512 || dma_tiles >= 1024) &&
+        (size_t)128 * g->lda * 2 < (1ull << 31) && (size_t)128 * g->ldb * 2 < (1ull << 31)) {
+      const int grid = (g->N / 128) * cdiv(g->M, 128);
+      static bool dma_attr = false;
+      if (!dma_attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        dma_attr = true;
+      }
+      gemm_nt_bf16_dma_kernel<<<grid, 256, 65536, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->K, g->lda, g->ldb, e);
+      return launch_status();
     }
     static const int big_min = getenv("LIDK_GEMM_BIG") ? atoi(getenv("LIDK_GEMM_BIG")) : 256;      // 0 = never
     if (direct && splitk == 1 && (g->K & 63) == 0 && big_min > 0 && g->K >= 2048 && !(g->N & 127) &&

@@ -583,6 +583,40 @@ def test_gemm_nt_long_k_large_shape_uses_the_128_tile(mode):
         check("gemm_big_gelu", out, F.gelu(ref + bias), 3e-2, 1e-2)
 
 
+@pytest.mark.parametrize("mode", ["bf16_plain", "f32_bias_res", "gelu_pre", "strided_view"])
+def test_gemm_nt_lds_dma_128_tile(mode, monkeypatch):
+    """With LIDK_GEMM_DMA=512 (opt-in, read per call), K >= 512, N % 128 == 0 and >= 384 tiles of 128x128 dispatch
+    gemm_nt_bf16_dma_kernel (operands by global_load_lds, the transformer
+    backbones' d = 768 shapes); M is not a multiple of 128 (clamped last row tile); 'strided_view': overlapping rows
+    (lda < K), the conv feature extractor's operand form.  Reference: f32 matmul of the bf16-rounded operands."""
+    monkeypatch.setenv("LIDK_GEMM_DMA", "512")
+    M, N, K = 9536 + 77, 768, 768
+    A = (torch.randn(M, K, generator=g(170)) * 0.5).bfloat16()
+    B = (torch.randn(N, K, generator=g(171)) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, generator=g(172))
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    if mode == "strided_view":
+        x = (torch.randn(2 * M + 8, 256, generator=g(173)) * 0.5).bfloat16()
+        Ad = x.to(DEV).as_strided((M, K), (512, 1))                 # row t = 768 contiguous values from input row 2 t
+        A = x.as_strided((M, K), (512, 1))
+    ref = A.float() @ B.float().t()
+    if mode in ("bf16_plain", "strided_view"):
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(Ad, Bd, out)
+        check("gemm_dma_bf16", out, ref, 3e-2, 1e-2)
+    elif mode == "f32_bias_res":
+        res = torch.randn(M, N, generator=g(174))
+        out = torch.empty(M, N, device=DEV)
+        ops.gemm_nt(Ad, Bd, out, bias=bias.to(DEV), alpha=0.5, res=res.to(DEV))
+        check("gemm_dma_f32", out, 0.5 * (ref + bias) + res, 2e-3, 1e-4)
+    else:
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        pre = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(Ad, Bd, out, bias=bias.to(DEV), act=L.ACT_GELU, out2=pre)
+        check("gemm_dma_pre", pre, ref + bias, 3e-2, 1e-2)
+        check("gemm_dma_gelu", out, F.gelu(ref + bias), 3e-2, 1e-2)
+
+
 @pytest.mark.parametrize("M,C", [(9664, 256), (453, 144), (7, 64)])
 def test_double_layernorm_equals_two_single_launches(M, C):
     """lidk_layernorm2_fwd / _bwd (post_norm of block i + the first PreNorm of block i + 1 in one pass) against two
