@@ -524,8 +524,10 @@ class Engine:
         key = ("ffn", M, ff)
         ok = self._split_ok.get(key)
         if ok is None:
+            # the backward writes one partial (dgamma | dbeta) row per 64 input rows into a buffer of LN_BWD_BLOCKS rows
             ok = self._split_ok[key] = bool(self._hip and hasattr(self.k, "ffn_fwd") and _os_env("LIDK_FFN_FUSED", "1") == "1"
-                                            and self.k.ffn_fwd_supported(M, self.cfg.d, ff, self.act_dtype))
+                                            and self.k.ffn_fwd_supported(M, self.cfg.d, ff, self.act_dtype)
+                                            and self.k.ffn_bwd_partial_rows(M) <= L.LN_BWD_BLOCKS)
         return ok
 
     def _ff_fwd(self, x, P, h, a, u, xo, mean, rstd, ln_done: bool = False):
@@ -746,7 +748,8 @@ class Engine:
         ok = self._split_ok.get(key)
         if ok is None:
             ok = self._split_ok[key] = bool(self._hip and hasattr(self.k, "dgrad_ln_bwd") and _os_env("LIDK_DGRAD_LN", "0") == "1"
-                                            and WT.stride(0) == K and self.k.dgrad_ln_bwd_supported(M, d, K, self.act_dtype))
+                                            and WT.stride(0) == K and self.k.dgrad_ln_bwd_supported(M, d, K, self.act_dtype)
+                                            and self.k.ffn_bwd_partial_rows(M) <= L.LN_BWD_BLOCKS)
         lnp_rows = w.__dict__.setdefault("_lnp_rows", {})
         if not ok:
             lnp_rows[id(lnp)] = 0
