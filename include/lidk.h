@@ -183,6 +183,17 @@ int lidk_ffn_fwd(const float* x, const void* h_in, const float* gamma, const flo
                  const void* W2, const float* b2, void* h, float* mean, float* rstd, void* a, void* u, float* xo, float alpha, int M,
                  int d, int ff, int dtype, void* stream);
 
+/* lidk_ffn_fwd that also applies the LayerNorm(s) CONSUMING its output, in the epilogue (the workgroup owns complete rows):
+ *   A: yA = LN(xo; gA, bA)  -> yA32 (f32, optional) and / or yAT (T, optional), meanA / rstdA [M]
+ *   B (optional, gB != NULL): yB = LN(yA; gB, bB) -> yBT (T), meanB / rstdB [M]
+ * i.e. the PreNorm of the module that follows (lid/conformer.py:81-89: attention after ff1), or post_norm followed by the next
+ * block's first PreNorm (lid/conformer.py:252-259 then :153-171) - what lidk_layernorm_fwd / lidk_layernorm2_fwd would compute from
+ * xo in one more launch each.  Same arithmetic (two-pass statistics, eps as the PreNorm's). */
+int lidk_ffn_fwd_ln(const float* x, const void* h_in, const float* gamma, const float* beta, float eps, const void* W1, const float* b1,
+                    const void* W2, const float* b2, void* h, float* mean, float* rstd, void* a, void* u, float* xo, float alpha,
+                    const float* gA, const float* bA, float* yA32, void* yAT, float* meanA, float* rstdA, const float* gB,
+                    const float* bB, void* yBT, float* meanB, float* rstdB, int M, int d, int ff, int dtype, void* stream);
+
 /* Data path of the FeedForward backward in ONE launch (autograd of lid/conformer.py:153-171 + PreNorm :81-89), d == 256, bf16:
  *     da [M][ff] (T, stored)  = (dyT . W2) * swish'(a)        dyT [M][256] (T) = alpha * d(loss)/d(xo), a = saved pre-activation
  *     dh [M][256]             = da . W1

@@ -37,6 +37,9 @@ struct FfnFwd {
   const bf16* W1; const float* b1; const bf16* W2; const float* b2;
   bf16* h; float* mean; float* rstd; bf16* a; bf16* u; float* xo;
   float alpha; int M; int FF; int rot; int dbg;
+  // LayerNorm(s) that consume xo, applied in the epilogue (rows are complete): A on xo, optionally B on A's output
+  const float* gA; const float* bA; float* yA32; bf16* yAT; float* meanA; float* rstdA;
+  const float* gB; const float* bB; bf16* yBT; float* meanB; float* rstdB;
 };
 
 // LDS-DMA by inline asm: hipcc tracks a builtin global_load_lds as a pending LDS write and drains it (vmcnt(0)) in front of the
@@ -158,6 +161,14 @@ ffn_fwd_kernel(FfnFwd p) {
     if (LN_IN) {
       if (wid == ((nb1 + 1) & 7)) ffn_stage_vec(p.gamma, FFN_D, vec0 + FFp * 4 + 1024, 0, lane);
       if (wid == ((nb1 + 2) & 7)) ffn_stage_vec(p.beta, FFN_D, vec0 + FFp * 4 + 2048, 0, lane);
+    }
+    if (p.gA) {
+      if (wid == ((nb1 + 3) & 7)) ffn_stage_vec(p.gA, FFN_D, vec0 + FFp * 4 + 3072, 0, lane);
+      if (wid == ((nb1 + 4) & 7)) ffn_stage_vec(p.bA, FFN_D, vec0 + FFp * 4 + 4096, 0, lane);
+    }
+    if (p.gB) {
+      if (wid == ((nb1 + 5) & 7)) ffn_stage_vec(p.gB, FFN_D, vec0 + FFp * 4 + 5120, 0, lane);
+      if (wid == ((nb1 + 6) & 7)) ffn_stage_vec(p.bB, FFN_D, vec0 + FFp * 4 + 6144, 0, lane);
     }
   }
   if (NC > 0) ffn_stage(p.W1, p.W2, so, chunk_of(0), smem0, wid);
@@ -300,7 +311,6 @@ ffn_fwd_kernel(FfnFwd p) {
     for (int i = 0; i < 8; ++i) xch[(wid * 8 + i) * 64 + lane] = make_float4(acc2[i][0], acc2[i][1], acc2[i][2], acc2[i][3]);
   }
   __syncthreads();
-  if (!m_ok) return;
   const int pw = wid ^ 4;
   float* orow = p.xo + (size_t)m * FFN_D + 4 * fq + 128 * half;
   const float* bl = lb2 + 4 * fq + 128 * half;
@@ -313,31 +323,82 @@ ffn_fwd_kernel(FfnFwd p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) mine[i] = acc2[8 + i];
   }
+  float4 ov[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const float4 o2 = xch[(pw * 8 + i) * 64 + lane];
     const float4 r = *reinterpret_cast<const float4*>(xrow + (((32 * half + 4 * i + fq) ^ fr) << 4));
     const float4 b = *reinterpret_cast<const float4*>(bl + 16 * i);
-    float4 o;
-    o.x = r.x + p.alpha * (mine[i][0] + o2.x + b.x); o.y = r.y + p.alpha * (mine[i][1] + o2.y + b.y);
-    o.z = r.z + p.alpha * (mine[i][2] + o2.z + b.z); o.w = r.w + p.alpha * (mine[i][3] + o2.w + b.w);
-    store4(orow + 16 * i, o);
+    ov[i].x = r.x + p.alpha * (mine[i][0] + o2.x + b.x); ov[i].y = r.y + p.alpha * (mine[i][1] + o2.y + b.y);
+    ov[i].z = r.z + p.alpha * (mine[i][2] + o2.z + b.z); ov[i].w = r.w + p.alpha * (mine[i][3] + o2.w + b.w);
+    if (m_ok) store4(orow + 16 * i, ov[i]);
+  }
+  if (!p.gA) return;                                  // kernel-uniform
+
+  // ---- the LayerNorm(s) that consume xo (lid/conformer.py:81-89 PreNorm of the next module; :252-259 post_norm, then the next
+  // block's first PreNorm): this wave holds 128 of a row's 256 columns, its partner (wid ^ 4) the rest; two-pass statistics,
+  // the halves meeting through a small LDS array.  Same arithmetic as ln_fwd_kernel / ln2_fwd_c256_kernel.
+  const float* lgA = lbet + FFN_D, *lbA = lgA + FFN_D, *lgB = lbA + FFN_D, *lbB = lgB + FFN_D;
+  float* rs_x = lbet + 5 * FFN_D;                     // [4 slots][8 waves][16 rows] behind the staged vectors
+  const int ccol = 128 * half + 4 * fq;               // this lane's columns: ccol + 16 i + (0..3)
+  auto row_stat = [&](float v, int slot) __attribute__((always_inline)) {      // sum over the row's 256 columns
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if (fq == 0) rs_x[(slot * 8 + wid) * 16 + fr] = v;
+    __syncthreads();
+    return v + rs_x[(slot * 8 + pw) * 16 + fr];
+  };
+  auto layer_norm = [&](float4 (&v)[8], const float* lg, const float* lb, float* mean_out, float* rstd_out, int slot)
+      __attribute__((always_inline)) {
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mu = row_stat(sm, slot) * (1.0f / FFN_D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rs = rsqrtf(row_stat(q, slot + 1) * (1.0f / FFN_D) + p.eps);
+    if (fq == 0 && half == 0 && m_ok) { mean_out[m] = mu; rstd_out[m] = rs; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 g = *reinterpret_cast<const float4*>(lg + ccol + 16 * i), b = *reinterpret_cast<const float4*>(lb + ccol + 16 * i);
+      v[i].x = (v[i].x - mu) * rs * g.x + b.x; v[i].y = (v[i].y - mu) * rs * g.y + b.y;
+      v[i].z = (v[i].z - mu) * rs * g.z + b.z; v[i].w = (v[i].w - mu) * rs * g.w + b.w;
+    }
+  };
+  layer_norm(ov, lgA, lbA, p.meanA, p.rstdA, 0);
+  if (m_ok) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const size_t at = (size_t)m * FFN_D + ccol + 16 * i;
+      if (p.yA32) store4(p.yA32 + at, ov[i]);
+      if (p.yAT) store4(p.yAT + at, ov[i]);
+    }
+  }
+  if (!p.gB) return;
+  layer_norm(ov, lgB, lbB, p.meanB, p.rstdB, 2);
+  if (m_ok) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) store4(p.yBT + (size_t)m * FFN_D + ccol + 16 * i, ov[i]);
   }
 }
 
 extern "C" int lidk_ffn_fwd_supported(int M, int d, int ff, int dtype) {
-  return dtype == LIDK_BF16 && d == FFN_D && M > 0 && ff >= FFN_CH && ff % FFN_CH == 0 && 2 * FFN_BUF + (((ff + 255) & ~255) + 3 * FFN_D) * 4 <= 160 * 1024;
+  return dtype == LIDK_BF16 && d == FFN_D && M > 0 && ff >= FFN_CH && ff % FFN_CH == 0 && 2 * FFN_BUF + (((ff + 255) & ~255) + 7 * FFN_D) * 4 + 2048 <= 160 * 1024;
 }
 
-extern "C" int lidk_ffn_fwd(const float* x, const void* h_in, const float* gamma, const float* beta, float eps, const void* W1,
+static int ffn_fwd_launch(const float* gA, const float* bA, float* yA32, void* yAT, float* meanA, float* rstdA, const float* gB,
+                          const float* bB, void* yBT, float* meanB, float* rstdB, const float* x, const void* h_in, const float* gamma, const float* beta, float eps, const void* W1,
                             const float* b1, const void* W2, const float* b2, void* h, float* mean, float* rstd, void* a, void* u,
                             float* xo, float alpha, int M, int d, int ff, int dtype, void* stream) {
   if (!x || !W1 || !b1 || !W2 || !b2 || !xo) return LIDK_ERR_ARG;
   if (!h_in && (!gamma || !beta || !mean || !rstd)) return LIDK_ERR_ARG;
   if (!lidk_ffn_fwd_supported(M, d, ff, dtype)) return LIDK_ERR_UNSUPPORTED;
   FfnFwd p{x, (const bf16*)h_in, gamma, beta, eps, (const bf16*)W1, b1, (const bf16*)W2, b2, (bf16*)h, mean, rstd, (bf16*)a,
-           (bf16*)u, xo, alpha, M, ff, ffn_rot(), ffn_dbg()};
-  const int lds = 2 * FFN_BUF + (((ff + 255) & ~255) + 3 * FFN_D) * 4;
+           (bf16*)u, xo, alpha, M, ff, ffn_rot(), ffn_dbg(), gA, bA, yA32, (bf16*)yAT, meanA, rstdA, gB, bB, (bf16*)yBT, meanB, rstdB};
+  const int lds = 2 * FFN_BUF + (((ff + 255) & ~255) + 7 * FFN_D) * 4 + 2048;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -366,6 +427,24 @@ extern "C" int lidk_ffn_fwd(const float* x, const void* h_in, const float* gamma
   if (h_in) ffn_fwd_kernel<false, 0><<<grid, 512, lds, as_stream(stream)>>>(p);
   else ffn_fwd_kernel<true, 0><<<grid, 512, lds, as_stream(stream)>>>(p);
   return launch_status();
+}
+
+extern "C" int lidk_ffn_fwd(const float* x, const void* h_in, const float* gamma, const float* beta, float eps, const void* W1,
+                            const float* b1, const void* W2, const float* b2, void* h, float* mean, float* rstd, void* a, void* u,
+                            float* xo, float alpha, int M, int d, int ff, int dtype, void* stream) {
+  return ffn_fwd_launch(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, h_in,
+                        gamma, beta, eps, W1, b1, W2, b2, h, mean, rstd, a, u, xo, alpha, M, d, ff, dtype, stream);
+}
+
+extern "C" int lidk_ffn_fwd_ln(const float* x, const void* h_in, const float* gamma, const float* beta, float eps, const void* W1,
+                               const float* b1, const void* W2, const float* b2, void* h, float* mean, float* rstd, void* a, void* u,
+                               float* xo, float alpha, const float* gA, const float* bA, float* yA32, void* yAT, float* meanA,
+                               float* rstdA, const float* gB, const float* bB, void* yBT, float* meanB, float* rstdB, int M, int d,
+                               int ff, int dtype, void* stream) {
+  if (!gA || !bA || !meanA || !rstdA || (!yA32 && !yAT)) return LIDK_ERR_ARG;
+  if (gB && (!bB || !yBT || !meanB || !rstdB)) return LIDK_ERR_ARG;
+  return ffn_fwd_launch(gA, bA, yA32, yAT, meanA, rstdA, gB, bB, yBT, meanB, rstdB, x, h_in, gamma, beta, eps, W1, b1, W2, b2, h, mean,
+                        rstd, a, u, xo, alpha, M, d, ff, dtype, stream);
 }
 
 // =====================================================================================================================

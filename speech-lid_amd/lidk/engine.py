@@ -530,28 +530,35 @@ class Engine:
                                             and self.k.ffn_bwd_partial_rows(M) <= L.LN_BWD_BLOCKS)
         return ok
 
-    def _ff_fwd(self, x, P, h, a, u, xo, mean, rstd, ln_done: bool = False):
+    def _ff_fwd(self, x, P, h, a, u, xo, mean, rstd, ln_done: bool = False, next_ln=None) -> bool:
+        """One FeedForward module.  next_ln: the LayerNorm(s) that consume its output (ops.ffn_fwd's ``next_ln``); the fused kernel
+        applies them in its epilogue and the function returns True - otherwise the caller launches them."""
         if self._ffn_fused(x.shape[0], a.shape[1]):
+            if _os_env("LIDK_FFN_NEXT_LN", "1") != "1":
+                next_ln = None
             if ln_done:                  # h / mean / rstd were written by the previous block's fused LayerNorm pair
-                self.k.ffn_fwd(x, P["w1"][0], P["b1"], P["w2"][0], P["b2"], xo, h_in=h, a=a, u=u, alpha=0.5)
+                self.k.ffn_fwd(x, P["w1"][0], P["b1"], P["w2"][0], P["b2"], xo, h_in=h, a=a, u=u, alpha=0.5, next_ln=next_ln)
             else:
                 self.k.ffn_fwd(x, P["w1"][0], P["b1"], P["w2"][0], P["b2"], xo, gamma=P["ln_w"], beta=P["ln_b"], h=h, mean=mean,
-                               rstd=rstd, a=a, u=u, alpha=0.5)
-            return
+                               rstd=rstd, a=a, u=u, alpha=0.5, next_ln=next_ln)
+            return next_ln is not None
         self._ln_gemm(x, P, P["w1"][0], u, h, mean, rstd, ln_done=ln_done, bias=P["b1"], act=L.ACT_SWISH, out2=a)
         self.k.gemm_nt(u, P["w2"][0], xo, bias=P["b2"], alpha=0.5, res=x)
+        return False
 
     def _block_fwd(self, x, bp: _BlockParams, bb: _BlockBuf, w: _Work, training: bool, part: str = "all",
-                   ff1_ln_done: bool = False):
+                   ff1_ln_done: bool = False, tail=None) -> bool:
         """One ConformerBlock up to x4 (before post_norm).  ``part`` splits the launch sequence at the SyncBatchNorm
         collective: 'a' = up to the BatchNorm partial sums, 'b' = from the BatchNorm statistics on, 'all' = both."""
         B, T, M = w.B, w.T, w.M
         C = bp.conv
         ci, K = C["dw"].shape[0], C["dw"].shape[2]
         if part in ("all", "a"):
-            self._ff_fwd(x, bp.ff1, bb.h1, bb.a1, bb.u1, bb.x1, bb.mean[0], bb.rstd[0], ln_done=ff1_ln_done)
             A = bp.attn
-            self._ln_gemm(bb.x1, A, A["wqkv"][0], bb.qkv, bb.h2, bb.mean[1], bb.rstd[1])
+            # the attention's PreNorm is applied in the first FeedForward's epilogue where the fused kernel runs
+            ln_a = self._ff_fwd(x, bp.ff1, bb.h1, bb.a1, bb.u1, bb.x1, bb.mean[0], bb.rstd[0], ln_done=ff1_ln_done,
+                                next_ln=dict(gA=A["ln_w"], bA=A["ln_b"], yAT=bb.h2, meanA=bb.mean[1], rstdA=bb.rstd[1]))
+            self._ln_gemm(bb.x1, A, A["wqkv"][0], bb.qkv, bb.h2, bb.mean[1], bb.rstd[1], ln_done=ln_a)
             self.k.attn_fwd(bb.qkv, A["emb"], bb.o, None if self._attn_recompute(T, bp.dh) else bb.probs, B, T, bp.heads, bp.dh,
                             rel_emb_T=A["embT"])
             self.k.gemm_nt(bb.o, A["wo"][0], bb.x2, bias=A["bo"], res=bb.x1)
@@ -575,8 +582,8 @@ class Engine:
                 self.k.bn_eval_stats(C["rm"], C["rv"], bb.bn_mean, bb.bn_rstd)
             self.k.bn_swish_fwd(bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], bb.s)
             self.k.gemm_nt(bb.s, C["w2"][0], bb.x3, bias=C["b2"], res=bb.x2)
-            self._ff_fwd(bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.x4, bb.mean[3], bb.rstd[3])
-        return bb.x4
+            return self._ff_fwd(bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.x4, bb.mean[3], bb.rstd[3], next_ln=tail)
+        return False
 
     def _whole_graphs(self, keep) -> bool:
         """One launch sequence for all encoder blocks (forward) / the whole block chain (backward), captured as ONE hipGraph
@@ -609,10 +616,15 @@ class Engine:
         """fuse_next: block i + 1 follows directly, so post_norm and its first PreNorm run as one launch (which leaves h1 /
         mean / rstd of block i + 1 in place); ln_done: this block's first PreNorm was already produced that way."""
         bp, bb = self.enc_params[i], w.enc[i]
-        x4 = self._block_fwd(x, bp, bb, w, training, part, ff1_ln_done=ln_done)
-        if part in ("all", "b"):
+        x4 = bb.x4
+        # post_norm (and, with fuse_next, the next block's first PreNorm) ride in the second FeedForward's epilogue when it is fused
+        tail = dict(gA=bp.post["w"], bA=bp.post["b"], yA32=bb.out, meanA=bb.mean[4], rstdA=bb.rstd[4])
+        if fuse_next:
+            nb, nbb = self.enc_params[i + 1], w.enc[i + 1]
+            tail.update(gB=nb.ff1["ln_w"], bB=nb.ff1["ln_b"], yBT=nbb.h1, meanB=nbb.mean[0], rstdB=nbb.rstd[0])
+        done = self._block_fwd(x, bp, bb, w, training, part, ff1_ln_done=ln_done, tail=tail)
+        if part in ("all", "b") and not done:
             if fuse_next:
-                nb, nbb = self.enc_params[i + 1], w.enc[i + 1]
                 self.k.layernorm2_fwd(x4, bp.post["w"], bp.post["b"], bb.out, bb.mean[4], bb.rstd[4], nb.ff1["ln_w"],
                                       nb.ff1["ln_b"], nbb.h1, nbb.mean[0], nbb.rstd[0])
             else:
@@ -633,15 +645,23 @@ class Engine:
         bp, bb = self.head_params[lang], w.head
         x4 = bb.x4
         ci = bp.conv["dw"].shape[0]
-        self._run_split(("hf", id(w), lang, feat.data_ptr(), training), lambda part: self._block_fwd(feat, bp, bb, w, training, part),
+        drop = training and cfg.dropout > 0
+        tail = dict(gA=bp.post["w"], bA=bp.post["b"], meanA=bb.mean[4], rstdA=bb.rstd[4])
+        tail["yA32" if drop else "yAT"] = bb.out if drop else w.head_h
+        done = []
+        self._run_split(("hf", id(w), lang, feat.data_ptr(), training),
+                        lambda part: done.append(self._block_fwd(feat, bp, bb, w, training, part, tail=tail)),
                         self._bn_collective(w, ci, training))
+        # under graph replay the lambda does not run: whether post_norm rode in the FeedForward epilogue is a property of the shape
+        fused_tail = self._ffn_fused(w.M, bb.a4.shape[1]) and _os_env("LIDK_FFN_NEXT_LN", "1") == "1"
         p = f"model.last_projects.{lang}.linear"
-        if training and cfg.dropout > 0:
-            self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
-                              dtype=self.act_dtype)
+        if drop:
+            if not fused_tail:
+                self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], y32=bb.out, mean=bb.mean[4], rstd=bb.rstd[4],
+                                     dtype=self.act_dtype)
             self.k.dropout(bb.out, w.head_h, cfg.dropout, seed=seed + 7919, keep_in=self._forced_masks.get("head"),
                         keep_out=w.head_keep)
-        else:
+        elif not fused_tail:
             self.k.layernorm_fwd(x4, bp.post["w"], bp.post["b"], yT=w.head_h, mean=bb.mean[4], rstd=bb.rstd[4])
         self.k.gemm_nt(w.head_h, self.wview(p + ".weight")[0], logits, bias=self.pview(p + ".bias"))
 

@@ -327,12 +327,21 @@ def ffn_fwd_supported(M, d, ff, dtype):
 
 
 def ffn_fwd(x, W1, b1, W2, b2, xo, gamma=None, beta=None, h_in=None, h=None, mean=None, rstd=None, a=None, u=None, alpha=0.5,
-            eps=1e-5):
-    """xo = x + alpha * (swish(LN(x) W1^T + b1) W2^T + b2) in one launch (d = 256, bf16 operands); see lidk_ffn_fwd."""
+            eps=1e-5, next_ln=None):
+    """xo = x + alpha * (swish(LN(x) W1^T + b1) W2^T + b2) in one launch (d = 256, bf16 operands); see lidk_ffn_fwd.
+    next_ln: dict(gA, bA, meanA, rstdA, yA32 and / or yAT[, gB, bB, yBT, meanB, rstdB]) - the LayerNorm(s) consuming xo, applied in
+    the epilogue (lidk_ffn_fwd_ln)."""
     M, d = x.shape
     ff = W1.shape[0]
-    check(lib().lidk_ffn_fwd(_p(x), _pv(h_in), _p(gamma), _p(beta), eps, _pv(W1), _p(b1), _pv(W2), _p(b2), _pv(h), _p(mean),
-                             _p(rstd), _pv(a), _pv(u), _p(xo), alpha, M, d, ff, _code(W1), _stream()), "ffn_fwd")
+    if next_ln is None:
+        check(lib().lidk_ffn_fwd(_p(x), _pv(h_in), _p(gamma), _p(beta), eps, _pv(W1), _p(b1), _pv(W2), _p(b2), _pv(h), _p(mean),
+                                 _p(rstd), _pv(a), _pv(u), _p(xo), alpha, M, d, ff, _code(W1), _stream()), "ffn_fwd")
+        return xo
+    n = next_ln
+    check(lib().lidk_ffn_fwd_ln(_p(x), _pv(h_in), _p(gamma), _p(beta), eps, _pv(W1), _p(b1), _pv(W2), _p(b2), _pv(h), _p(mean),
+                                _p(rstd), _pv(a), _pv(u), _p(xo), alpha, _p(n["gA"]), _p(n["bA"]), _p(n.get("yA32")), _p(n.get("yAT")),
+                                _p(n["meanA"]), _p(n["rstdA"]), _p(n.get("gB")), _p(n.get("bB")), _p(n.get("yBT")), _p(n.get("meanB")),
+                                _p(n.get("rstdB")), M, d, ff, _code(W1), _stream()), "ffn_fwd_ln")
     return xo
 
 

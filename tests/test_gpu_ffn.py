@@ -229,3 +229,38 @@ def test_dgrad_ln_bwd_matches_torch_and_the_two_launches(M, K):
     ops.layernorm_bwd(dh0, args["x"], args["mean"], args["rstd"], args["gamma"], part0, dres=dres.to(DEV), dx=dx0)
     torch.cuda.synchronize()
     assert float((dx0 - dx).abs().max()) <= 1e-2 * scale and float((dx0 - dx).abs().mean()) <= 5e-4 * scale
+
+
+@pytest.mark.parametrize("M,ff", [(9664, 1024), (151, 256)])
+@pytest.mark.parametrize("pair", [False, True])
+def test_ffn_fwd_applies_the_consuming_layernorms_in_its_epilogue(M, ff, pair):
+    """lidk_ffn_fwd_ln: A = LN(xo) (the next module's PreNorm, or post_norm) and optionally B = LN(A) (the next block's first
+    PreNorm) against lidk_layernorm_fwd / torch on the kernel's own xo."""
+    x, gamma, beta, W1, b1, W2, b2 = _case(M, ff, seed=5 * M + ff)
+    g = torch.Generator().manual_seed(M + 1)
+    gA, bA = 1 + 0.1 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g)
+    gB, bB = 1 + 0.1 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g)
+    e = lambda *s, dt=BF: torch.full(s, float("nan"), device=DEV, dtype=dt)
+    f = lambda *s: e(*s, dt=torch.float32)
+    h, a, u, xo, mean, rstd = e(M, 256), e(M, ff), e(M, ff), f(M, 256), f(M), f(M)
+    yA32, yAT, meanA, rstdA, yBT, meanB, rstdB = f(M, 256), e(M, 256), f(M), f(M), e(M, 256), f(M), f(M)
+    nl = dict(gA=gA.to(DEV), bA=bA.to(DEV), yA32=yA32, yAT=yAT, meanA=meanA, rstdA=rstdA)
+    if pair:
+        nl.update(gB=gB.to(DEV), bB=bB.to(DEV), yBT=yBT, meanB=meanB, rstdB=rstdB)
+    ops.ffn_fwd(x.to(DEV), W1.to(DEV, BF), b1.to(DEV), W2.to(DEV, BF), b2.to(DEV), xo, gamma=gamma.to(DEV), beta=beta.to(DEV), h=h,
+                mean=mean, rstd=rstd, a=a, u=u, next_ln=nl)
+    torch.cuda.synchronize()
+    xo_c = xo.cpu()
+    assert bool(torch.isfinite(xo_c).all())
+    rA = F.layer_norm(xo_c, (256,), gA, bA, 1e-5)
+    assert float((yA32.cpu() - rA).abs().max()) <= 2e-5 * max(1.0, float(rA.abs().max()))
+    assert float((yAT.float().cpu() - rA).abs().max()) <= 2 ** -7 * float(rA.abs().max())
+    assert float((meanA.cpu() - xo_c.mean(1)).abs().max()) <= 2e-6 * max(1.0, float(xo_c.abs().max()))
+    assert float(((rstdA.cpu() - (xo_c.var(1, unbiased=False) + 1e-5).rsqrt()) * xo_c.std(1)).abs().max()) <= 1e-5
+    if pair:
+        yA = yA32.cpu()
+        rB = F.layer_norm(yA, (256,), gB, bB, 1e-5)
+        assert float((yBT.float().cpu() - rB).abs().max()) <= 2 ** -7 * float(rB.abs().max())
+        assert float((meanB.cpu() - yA.mean(1)).abs().max()) <= 2e-6
+    else:
+        assert bool(torch.isnan(yBT.float()).all())
