@@ -205,6 +205,15 @@ int lidk_ffn_fwd_ln(const float* x, const void* h_in, const float* gamma, const 
  * post_norm (lidk_layernorm2_bwd).  da feeds the weight gradients (lidk_gemm_tn: dW1 = da^T h, db1 = colsum da; dW2 = dyT^T u).
  * Replaces 2 x lidk_gemm_nt + lidk_layernorm_bwd; returns LIDK_ERR_UNSUPPORTED as lidk_ffn_fwd does. */
 int lidk_ffn_bwd_partial_rows(int M);
+/* lidk_ffn_bwd with a SECOND LayerNorm backward behind the PreNorm's: the pair post_norm (input rows x1, mean1, rstd1, gamma1)
+ * -> this module's PreNorm (lid/conformer.py:252-259 followed by :153-171 of the next block): dv = LN'(dh; x, mean, rstd, gamma) +
+ * dres, dx = LN1'(dv; x1, mean1, rstd1, gamma1), dxT = dxT_scale * dx; partial / partial1: the two LayerNorms' (dgamma | dbeta) rows.
+ * What lidk_ffn_bwd(dh form) + lidk_layernorm2_bwd compute in two launches. */
+int lidk_ffn_bwd_ln2(const void* dyT, const void* a, const void* W2T, int ldw2t, const void* W1T, int ldw1t, void* da, const float* x,
+                     const float* mean, const float* rstd, const float* gamma, const float* dres, const float* x1, const float* mean1,
+                     const float* rstd1, const float* gamma1, float* dx, void* dxT, float dxT_scale, float* partial, float* partial1,
+                     int M, int d, int ff, int dtype, void* stream);
+
 int lidk_ffn_bwd(const void* dyT, const void* a, const void* W2T, int ldw2t, const void* W1T, int ldw1t, void* da, const float* x,
                  const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx, void* dxT, float dxT_scale,
                  float* partial, void* dh, int M, int d, int ff, int dtype, void* stream);

@@ -465,6 +465,9 @@ struct FfnBwd {
   const float* x; const float* mean; const float* rstd; const float* gamma; const float* dres;
   float* dx; bf16* dxT; float dxT_scale; float* partial; bf16* dh;
   int M; int FF; int rot; int dbg;
+  // optional SECOND LayerNorm backward in the epilogue (the pair post_norm -> this PreNorm): the gradient the first one yields
+  // (+ dres) is the upstream gradient of LN1 whose input rows are x1: dx = LN1'(dv; x1, mean1, rstd1, gamma1); partial1 its rows
+  const float* x1; const float* mean1; const float* rstd1; const float* gamma1; float* partial1;
 };
 
 // GEMM = true: only the second product - dh = A . W with A = p.a [M][K = p.FF] (T) and p.W1T = W^T [256][K] - followed by the same
@@ -655,77 +658,96 @@ ffn_bwd_kernel(FfnBwd p) {
     return;
   }
 
-  // ---- LayerNorm backward of the complete rows
-  float4 xh[8], g[8];
-  float s1 = 0.f, s2 = 0.f;
+  // ---- LayerNorm backward of the complete rows (once, or twice for the pair post_norm -> this PreNorm)
+  float4 xin[8], x1v[8], g1v[8];
+  float mu1 = 0.f, rs1 = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float4 xv = *reinterpret_cast<const float4*>(xrow + (((32 * half + 4 * i + fq) ^ fr) << 4)), gm = gmv[i];
-    xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
-    g[i].x = dhv[i].x * gm.x; g[i].y = dhv[i].y * gm.y; g[i].z = dhv[i].z * gm.z; g[i].w = dhv[i].w * gm.w;
-    s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
-    s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+  for (int i = 0; i < 8; ++i) xin[i] = *reinterpret_cast<const float4*>(xrow + (((32 * half + 4 * i + fq) ^ fr) << 4));
+  if (p.x1) {                                        // kernel-uniform; requested now, used after the first LayerNorm's backward
+    mu1 = p.mean1[m]; rs1 = p.rstd1[m];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      x1v[i] = load4(p.x1 + (size_t)m * FFN_D + col0 + 16 * i);
+      g1v[i] = load4(p.gamma1 + col0 + 16 * i);
+    }
   }
-  s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-  s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-  __syncthreads();                                   // everybody has read the exchanged tiles: the area is free again
-  float2* rsum = reinterpret_cast<float2*>(ffn_smem);                 // [wave][16 rows]
-  if (fq == 0) rsum[wid * 16 + fr] = make_float2(s1, s2);
-  // per-column (dgamma | dbeta) terms of this workgroup's 64 rows: [row][256] each, behind the row sums
-  float* dgs = reinterpret_cast<float*>(ffn_smem + 1024);
+  __syncthreads();                                   // everybody has read the exchanged tiles and its rows of x: the area is free
+  float2* rsum = reinterpret_cast<float2*>(ffn_smem);                 // [2 rounds][wave][16 rows]
+  float* dgs = reinterpret_cast<float*>(ffn_smem + 2048);             // per-column (dgamma | dbeta) terms: [row][256] each
   float* dbs = dgs + FFN_BM * FFN_D;
   const int lrow = 16 * rw + fr;
+  // dy: upstream gradient at the LayerNorm's output (this lane's 8 x 4 columns); xin: its input rows; -> gradient at its input,
+  // and this workgroup's partial (dgamma | dbeta) row
+  auto ln_bwd = [&](float4 (&dy)[8], const float4 (&xin)[8], const float4 (&gm)[8], float mu_, float rs_, float* part, int round)
+      __attribute__((always_inline)) {
+    float4 xh[8];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float4 tg = make_float4(0.f, 0.f, 0.f, 0.f), tb = tg;
-    if (m_ok) {
-      tg = make_float4(dhv[i].x * xh[i].x, dhv[i].y * xh[i].y, dhv[i].z * xh[i].z, dhv[i].w * xh[i].w);
-      tb = dhv[i];
+    for (int i = 0; i < 8; ++i) {
+      xh[i].x = (xin[i].x - mu_) * rs_; xh[i].y = (xin[i].y - mu_) * rs_; xh[i].z = (xin[i].z - mu_) * rs_; xh[i].w = (xin[i].w - mu_) * rs_;
+      float4 tg = make_float4(0.f, 0.f, 0.f, 0.f), tb = tg;
+      if (m_ok) {
+        tg = make_float4(dy[i].x * xh[i].x, dy[i].y * xh[i].y, dy[i].z * xh[i].z, dy[i].w * xh[i].w);
+        tb = dy[i];
+      }
+      *reinterpret_cast<float4*>(dgs + lrow * FFN_D + col0 + 16 * i) = tg;
+      *reinterpret_cast<float4*>(dbs + lrow * FFN_D + col0 + 16 * i) = tb;
+      dy[i].x *= gm[i].x; dy[i].y *= gm[i].y; dy[i].z *= gm[i].z; dy[i].w *= gm[i].w;       // g = dy * gamma
+      s1 += (dy[i].x + dy[i].y) + (dy[i].z + dy[i].w);
+      s2 += (dy[i].x * xh[i].x + dy[i].y * xh[i].y) + (dy[i].z * xh[i].z + dy[i].w * xh[i].w);
     }
-    *reinterpret_cast<float4*>(dgs + lrow * FFN_D + col0 + 16 * i) = tg;
-    *reinterpret_cast<float4*>(dbs + lrow * FFN_D + col0 + 16 * i) = tb;
-  }
-  __syncthreads();
-  {
-    const float2 o = rsum[pw * 16 + fr];
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (fq == 0) rsum[(round * 8 + wid) * 16 + fr] = make_float2(s1, s2);
+    __syncthreads();
+    const float2 o = rsum[(round * 8 + pw) * 16 + fr];
     const float m1 = (s1 + o.x) * (1.0f / FFN_D), m2 = (s2 + o.y) * (1.0f / FFN_D);
-    if (m_ok) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float4 o4;
-        o4.x = rs * (g[i].x - m1 - xh[i].x * m2); o4.y = rs * (g[i].y - m1 - xh[i].y * m2);
-        o4.z = rs * (g[i].z - m1 - xh[i].z * m2); o4.w = rs * (g[i].w - m1 - xh[i].w * m2);
-        const size_t at = (size_t)m * FFN_D + col0 + 16 * i;
-        o4.x += rv[i].x; o4.y += rv[i].y; o4.z += rv[i].z; o4.w += rv[i].w;
-        if (p.dx) store4(p.dx + at, o4);
-        if (p.dxT) {
-          o4.x *= p.dxT_scale; o4.y *= p.dxT_scale; o4.z *= p.dxT_scale; o4.w *= p.dxT_scale;
-          store4(p.dxT + at, o4);
-        }
+    for (int i = 0; i < 8; ++i) {
+      dy[i].x = rs_ * (dy[i].x - m1 - xh[i].x * m2); dy[i].y = rs_ * (dy[i].y - m1 - xh[i].y * m2);
+      dy[i].z = rs_ * (dy[i].z - m1 - xh[i].z * m2); dy[i].w = rs_ * (dy[i].w - m1 - xh[i].w * m2);
+    }
+    {                                                // column sums over the 64 rows: thread t -> (which = t >> 8, column = t & 255)
+      const float* src = (tid >> 8) ? dbs : dgs;
+      const int col = tid & 255;
+      float t = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < FFN_BM; ++r) t += src[r * FFN_D + col];
+      part[(size_t)blockIdx.x * 2 * FFN_D + tid] = t;
+    }
+  };
+  ln_bwd(dhv, xin, gmv, mu, rs, p.partial, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { dhv[i].x += rv[i].x; dhv[i].y += rv[i].y; dhv[i].z += rv[i].z; dhv[i].w += rv[i].w; }
+  if (p.x1) {                                        // the gradient just formed is LN1's upstream gradient
+    __syncthreads();                                 // the column sums of the first round are done with dgs / dbs
+    ln_bwd(dhv, x1v, g1v, mu1, rs1, p.partial1, 1);
+  }
+  if (m_ok) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const size_t at = (size_t)m * FFN_D + col0 + 16 * i;
+      float4 o4 = dhv[i];
+      if (p.dx) store4(p.dx + at, o4);
+      if (p.dxT) {
+        o4.x *= p.dxT_scale; o4.y *= p.dxT_scale; o4.z *= p.dxT_scale; o4.w *= p.dxT_scale;
+        store4(p.dxT + at, o4);
       }
     }
-  }
-  // column sums over the 64 rows: thread t -> (which = t >> 8, column = t & 255)
-  {
-    const float* src = (tid >> 8) ? dbs : dgs;
-    const int col = tid & 255;
-    float t = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < FFN_BM; ++r) t += src[r * FFN_D + col];
-    p.partial[(size_t)blockIdx.x * 2 * FFN_D + tid] = t;
   }
 }
 
 extern "C" int lidk_ffn_bwd_partial_rows(int M) { return cdiv(M, FFN_BM); }
 
-extern "C" int lidk_ffn_bwd(const void* dyT, const void* a, const void* W2T, int ldw2t, const void* W1T, int ldw1t, void* da,
-                            const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
-                            void* dxT, float dxT_scale, float* partial, void* dh, int M, int d, int ff, int dtype, void* stream) {
+static int ffn_bwd_launch(const float* x1, const float* mean1, const float* rstd1, const float* gamma1, float* partial1,
+                          const void* dyT, const void* a, const void* W2T, int ldw2t, const void* W1T, int ldw1t, void* da,
+                          const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
+                          void* dxT, float dxT_scale, float* partial, void* dh, int M, int d, int ff, int dtype, void* stream) {
   if (!dyT || !a || !W2T || !W1T || !da) return LIDK_ERR_ARG;
   if (!dh && (!x || !mean || !rstd || !gamma || !partial || (!dx && !dxT))) return LIDK_ERR_ARG;
   if (!lidk_ffn_fwd_supported(M, d, ff, dtype) || ldw2t != FFN_D || ldw1t != ff) return LIDK_ERR_UNSUPPORTED;
   FfnBwd p{(const bf16*)dyT, (const bf16*)a, (const bf16*)W2T, (const bf16*)W1T, (bf16*)da, x, mean, rstd, gamma, dres, dx, (bf16*)dxT,
-           dxT_scale, partial, (bf16*)dh, M, ff, ffn_rot(), ffn_dbg()};
+           dxT_scale, partial, (bf16*)dh, M, ff, ffn_rot(), ffn_dbg(), x1, mean1, rstd1, gamma1, partial1};
   const int lds = 2 * FFN_BUF + 2 * FFN_ATILE;
   static bool attr_set = false;
   if (!attr_set) {
@@ -739,6 +761,22 @@ extern "C" int lidk_ffn_bwd(const void* dyT, const void* a, const void* W2T, int
   return launch_status();
 }
 
+extern "C" int lidk_ffn_bwd(const void* dyT, const void* a, const void* W2T, int ldw2t, const void* W1T, int ldw1t, void* da,
+                            const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
+                            void* dxT, float dxT_scale, float* partial, void* dh, int M, int d, int ff, int dtype, void* stream) {
+  return ffn_bwd_launch(nullptr, nullptr, nullptr, nullptr, nullptr, dyT, a, W2T, ldw2t, W1T, ldw1t, da, x, mean, rstd, gamma, dres, dx,
+                        dxT, dxT_scale, partial, dh, M, d, ff, dtype, stream);
+}
+
+extern "C" int lidk_ffn_bwd_ln2(const void* dyT, const void* a, const void* W2T, int ldw2t, const void* W1T, int ldw1t, void* da,
+                                const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                                const float* x1, const float* mean1, const float* rstd1, const float* gamma1, float* dx, void* dxT,
+                                float dxT_scale, float* partial, float* partial1, int M, int d, int ff, int dtype, void* stream) {
+  if (!x1 || !mean1 || !rstd1 || !gamma1 || !partial1) return LIDK_ERR_ARG;
+  return ffn_bwd_launch(x1, mean1, rstd1, gamma1, partial1, dyT, a, W2T, ldw2t, W1T, ldw1t, da, x, mean, rstd, gamma, dres, dx, dxT,
+                        dxT_scale, partial, nullptr, M, d, ff, dtype, stream);
+}
+
 extern "C" int lidk_dgrad_ln_bwd_supported(int M, int N, int K, int dtype) {
   return dtype == LIDK_BF16 && N == FFN_D && M > 0 && K >= FFN_CH && K % FFN_CH == 0;
 }
@@ -749,7 +787,7 @@ extern "C" int lidk_dgrad_ln_bwd(const void* dy, const void* WT, int ldwt, const
   if (!dy || !WT || !x || !mean || !rstd || !gamma || !partial || (!dx && !dxT)) return LIDK_ERR_ARG;
   if (!lidk_dgrad_ln_bwd_supported(M, N, K, dtype) || ldwt != K) return LIDK_ERR_UNSUPPORTED;
   FfnBwd p{nullptr, (const bf16*)dy, nullptr, (const bf16*)WT, nullptr, x, mean, rstd, gamma, dres, dx, (bf16*)dxT, dxT_scale, partial,
-           nullptr, M, K, ffn_rot(), ffn_dbg()};
+           nullptr, M, K, ffn_rot(), ffn_dbg(), nullptr, nullptr, nullptr, nullptr, nullptr};
   const int lds = 2 * FFN_BUF + 2 * FFN_ATILE;
   static bool attr_set = false;
   if (!attr_set) {

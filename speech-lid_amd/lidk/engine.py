@@ -755,6 +755,7 @@ class Engine:
             self.k.layernorm_bwd(dy, x, mean, rstd, P["ln_w"], w.partial, dgamma=P["dln_w"], dbeta=P["dln_b"],
                                  dtype=self.act_dtype, **kw)
         else:
+            w.__dict__.setdefault("_lnp_rows", {})[id(lnp)] = 0        # lidk_layernorm_bwd's own partial-row layout
             self.k.layernorm_bwd(dy, x, mean, rstd, P["ln_w"], lnp, dtype=self.act_dtype, **kw)
 
     def _dgrad_ln_bwd(self, w: _Work, dy, WT, K: int, x, mean, rstd, P, lnp, wg: bool, dres, dx, dxT, dxT_scale):
@@ -797,7 +798,24 @@ class Engine:
             # both data-gradient products (and, unless this PreNorm's backward is paired with the next block's post_norm, the
             # LayerNorm backward too) in one launch; the partial (dgamma | dbeta) rows are one per 64-row workgroup
             rows = self.k.ffn_bwd_partial_rows(M)
-            lnp_rows[id(lnp)] = rows if fuse is None else 0
+            # LIDK_FFN_LN_PAIR=1: both LayerNorm backwards of the block boundary in the kernel's epilogue (lidk_ffn_bwd_ln2).  Correct
+            # (tests/test_gpu_ffn.py) but measured slower end to end - 7.44 / 7.44 vs 7.38 / 7.38 ms per step: the long epilogue of 151
+            # lock-step workgroups costs more than the 11 us streaming launch it removes - so the dh form + lidk_layernorm2_bwd stay.
+            pair_fused = fuse is not None and _os_env("LIDK_FFN_LN_PAIR", "0") == "1"
+            lnp_rows[id(lnp)] = rows if (fuse is None or pair_fused) else 0
+            if pair_fused:
+                # this PreNorm's backward AND the following block's post_norm backward in the kernel's epilogue (was: dh out +
+                # lidk_layernorm2_bwd): dx (f32) -> w.dxa, 0.5 * dx (T) -> S_prev.dyTs[0], partial rows of both LayerNorms
+                pbb, post, Sp, forked = fuse
+                if forked:          # S_prev's buffers are still read by the weight gradients running on the second stream
+                    self._join()
+                lnp_rows[id(Sp.lnp[0])] = rows
+                self.k.ffn_bwd(dyT, a, P["w1"][1], P["w2"][1], da, x=x_in, mean=mean, rstd=rstd, gamma=P["ln_w"], dres=dx_res,
+                               dx=w.dxa, dxT=Sp.dyTs[0], dxT_scale=0.5, partial=lnp,
+                               pair=dict(x1=pbb.x4, mean1=pbb.mean[4], rstd1=pbb.rstd[4], gamma1=post["w"], partial1=Sp.lnp[0]))
+                if wg:
+                    self._wgrad(w, da, h, P["dw1"], ff, d, P["db1"])
+                return
             if fuse is None:
                 self.k.ffn_bwd(dyT, a, P["w1"][1], P["w2"][1], da, x=x_in, mean=mean, rstd=rstd, gamma=P["ln_w"], dres=dx_res,
                                dx=dx_out, dxT=dxT_out, dxT_scale=dxT_scale, partial=lnp)

@@ -350,11 +350,17 @@ def ffn_bwd_partial_rows(M):
 
 
 def ffn_bwd(dyT, a, W1T, W2T, da, x=None, mean=None, rstd=None, gamma=None, dres=None, dx=None, dxT=None, dxT_scale=1.0,
-            partial=None, dh=None):
+            partial=None, dh=None, pair=None):
     """da = (dyT W2) * swish'(a); dh = da W1; then the PreNorm backward (dx / dxT / partial dgamma-dbeta rows), or dh itself when
     ``dh`` is given; see lidk_ffn_bwd.  W1T [256, ff], W2T [ff, 256]: the transposed operand copies."""
     M, d = dyT.shape
     ff = a.shape[1]
+    if pair is not None:            # dict(x1, mean1, rstd1, gamma1, partial1): the LayerNorm in FRONT of this PreNorm (post_norm)
+        check(lib().lidk_ffn_bwd_ln2(_p(dyT), _p(a), _pv(W2T), W2T.stride(0), _pv(W1T), W1T.stride(0), _p(da), _p(x), _p(mean), _p(rstd),
+                                     _p(gamma), _p(dres), _p(pair["x1"]), _p(pair["mean1"]), _p(pair["rstd1"]), _p(pair["gamma1"]),
+                                     _p(dx), _p(dxT), dxT_scale, _p(partial), _p(pair["partial1"]), M, d, ff, _code(dyT), _stream()),
+              "ffn_bwd_ln2")
+        return
     check(lib().lidk_ffn_bwd(_p(dyT), _p(a), _pv(W2T), W2T.stride(0), _pv(W1T), W1T.stride(0), _p(da), _p(x), _p(mean), _p(rstd),
                              _p(gamma), _p(dres), _p(dx), _p(dxT), dxT_scale, _p(partial), _p(dh), M, d, ff, _code(dyT), _stream()),
           "ffn_bwd")

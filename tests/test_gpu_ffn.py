@@ -264,3 +264,47 @@ def test_ffn_fwd_applies_the_consuming_layernorms_in_its_epilogue(M, ff, pair):
         assert float((meanB.cpu() - yA.mean(1)).abs().max()) <= 2e-6
     else:
         assert bool(torch.isnan(yBT.float()).all())
+
+
+def test_ffn_bwd_with_the_layernorm_pair_equals_dh_plus_layernorm2_bwd():
+    """lidk_ffn_bwd_ln2 (this PreNorm's backward + the preceding post_norm's backward in the epilogue) against the two launches it
+    replaces: lidk_ffn_bwd (dh form) + lidk_layernorm2_bwd; the two paths differ only by dh's bf16 rounding."""
+    M, ff = 9664, 1024
+    x, gamma, beta, W1, b1, W2, b2 = _case(M, ff, seed=21)
+    g = torch.Generator().manual_seed(9)
+    dyT = (0.5 * torch.randn(M, 256, generator=g)).to(DEV, BF)
+    a = (torch.randn(M, ff, generator=g) * 1.5).to(DEV, BF)
+    dres = torch.randn(M, 256, generator=g).to(DEV)
+    x1 = (torch.randn(M, 256, generator=g) * 1.3 - 0.1).to(DEV)               # post_norm's input rows (the previous block's x4)
+    g1 = (1 + 0.1 * torch.randn(256, generator=g)).to(DEV)
+    b1n = (0.1 * torch.randn(256, generator=g)).to(DEV)
+    mean1, rstd1 = x1.mean(1), (x1.var(1, unbiased=False) + 1e-5).rsqrt()
+    y1 = F.layer_norm(x1, (256,), g1, b1n, 1e-5)                              # = this module's input x
+    mean2, rstd2 = y1.mean(1), (y1.var(1, unbiased=False) + 1e-5).rsqrt()
+    gd = gamma.to(DEV)
+    W1T, W2T = W1.t().contiguous().to(DEV, BF), W2.t().contiguous().to(DEV, BF)
+    e = lambda *s, dt=BF: torch.empty(s, device=DEV, dtype=dt)
+    # reference sequence
+    da0, dh0, dx0, dxT0 = e(M, ff), e(M, 256), e(M, 256, dt=torch.float32), e(M, 256)
+    pa0, pb0 = e(L.LN_BWD_BLOCKS * 512, dt=torch.float32), e(L.LN_BWD_BLOCKS * 512, dt=torch.float32)
+    ops.ffn_bwd(dyT, a, W1T, W2T, da0, dh=dh0)
+    ops.layernorm2_bwd(dh0, dres, y1, mean2, rstd2, gd, x1, mean1, rstd1, g1, dx0, dxT0, 0.5, pa0, pb0)
+    dg1_0, db1_0, dg2_0, db2_0 = (torch.zeros(256, device=DEV) for _ in range(4))
+    ops.layernorm_param_grads(pa0, M, 256, dg1_0, db1_0)
+    ops.layernorm_param_grads(pb0, M, 256, dg2_0, db2_0)
+    # fused
+    rows = ops.ffn_bwd_partial_rows(M)
+    da1, dx1, dxT1 = e(M, ff), e(M, 256, dt=torch.float32), e(M, 256)
+    p2, p1 = e(rows * 512, dt=torch.float32), e(rows * 512, dt=torch.float32)
+    ops.ffn_bwd(dyT, a, W1T, W2T, da1, x=y1, mean=mean2, rstd=rstd2, gamma=gd, dres=dres, dx=dx1, dxT=dxT1, dxT_scale=0.5, partial=p2,
+                pair=dict(x1=x1, mean1=mean1, rstd1=rstd1, gamma1=g1, partial1=p1))
+    dg1_1, db1_1, dg2_1, db2_1 = (torch.zeros(256, device=DEV) for _ in range(4))
+    ops.layernorm_param_grads_rows(p1, rows, 256, dg1_1, db1_1)
+    ops.layernorm_param_grads_rows(p2, rows, 256, dg2_1, db2_1)
+    torch.cuda.synchronize()
+    assert torch.equal(da0, da1)
+    scale = float(dx0.abs().max())
+    assert float((dx0 - dx1).abs().max()) <= 1e-2 * scale and float((dx0 - dx1).abs().mean()) <= 5e-4 * scale
+    assert float((dxT0.float() - dxT1.float()).abs().max()) <= 1e-2 * scale
+    for name, r0, r1 in (("dg1", dg1_0, dg1_1), ("db1", db1_0, db1_1), ("dg2", dg2_0, dg2_1), ("db2", db2_0, db2_1)):
+        assert float((r0 - r1).abs().max()) <= 5e-3 * float(r0.abs().max()) + 1e-3, name
