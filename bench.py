@@ -387,6 +387,9 @@ def roofline(trainer, batches, step_fn):
         m, d, ff = x.shape[0], x.shape[1], W1.shape[0]
         # x (f32) in, xo (f32) out, W1 + W2 + biases, a and u out (T), h out - or in, when the LayerNorm pair produced it
         nbytes = 2 * m * d * 4 + 2 * ff * d * 2 + (ff + d) * 4 + 2 * m * ff * 2 + m * d * 2 + (0 if kw.get("h_in") is not None else 8 * m)
+        nl = kw.get("next_ln") or {}                  # the consuming LayerNorm(s) applied in the epilogue: their outputs + statistics
+        nbytes += sum(m * d * t.element_size() for key, t in nl.items() if key in ("yA32", "yAT", "yBT") and t is not None)
+        nbytes += 8 * m * (("gA" in nl) + (nl.get("gB") is not None))
         rec["ffn"].append((lambda: orig["ffn_fwd"](x, W1, b1, W2, b2, xo, **kw), 4.0 * m * d * ff, nbytes))
         return orig["ffn_fwd"](x, W1, b1, W2, b2, xo, **kw)
 
