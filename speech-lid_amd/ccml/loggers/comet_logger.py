@@ -1,6 +1,6 @@
-"""CometLogger: the reference logs to an external service/package that is not part of the hot path.  This placeholder keeps
-launch scripts importable: it forwards to the local JSONL logger unless the real client library is importable AND the user
-opts in with LIDK_ENABLE_REMOTE_LOGGERS=1 (no credentials are ever shipped in this repository)."""
+"""CometLogger: the reference logs to an external service / package (ccml/loggers/comet_logger.py:18-22 (comet_ml client)) that is outside the hot path (out of
+scope).  This class keeps launch scripts and YAML `logger:` blocks importable: it ALWAYS writes to the local JSONL logger - there
+is no remote client, no opt-in switch and no credential handling in this repository."""
 from ccml.loggers.jsonl_logger import JsonlLogger
 
 
