@@ -462,7 +462,7 @@ def roofline(trainer, batches, step_fn):
     label = {"nt": ("gemm_nt (gemm_nt_bf16_pipe_kernel + gemm_nt_bf16_direct_kernel, 64x64 tiles)", ("gemm_nt_bf16_",)),
              "ffn": ("fused FeedForward (ffn_fwd_kernel + ffn_bwd_kernel, csrc/ffn.hip: 64-row workgroups, weights by LDS-DMA)",
                      ("ffn_fwd_kernel", "ffn_bwd_kernel")),
-             "tng": ("grouped weight-gradient GEMM (gemm_tn_grouped_kernel, 64x64 tiles, 4-way row split)", ("gemm_tn_grouped",)),
+             "tng": ("grouped weight-gradient GEMM (gemm_tn_grouped_dma_kernel: 128x128 tiles, 2 row chunks, operands by LDS-DMA ring)", ("gemm_tn_grouped",)),
              "tn": ("gemm_tn_bf16_kernel<64,64>", ("gemm_tn_bf16_kernel",))}
 
     def describe(kind):

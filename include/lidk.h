@@ -245,6 +245,9 @@ int lidk_gemm_tn_desc_bytes(void);
 int lidk_gemm_tn_grouped(const void* descs, int n_desc, int total_items, int full, void* stream);
 /* The grouped launch on 128x128 output tiles: item0 / total_items count 128-tiles; N1 % 128 == N2 % 128 == M % 64 == 0 in every record. */
 int lidk_gemm_tn_grouped128(const void* descs, int n_desc, int total_items, void* stream);
+/* The same on 256x256 output tiles (8 waves, both operand tiles by LDS-DMA, two 64 KB stages): item0 / total_items count 256-tiles;
+ * N1 % 256 == N2 % 256 == M % 64 == 0 in every record.  Half the operand bytes per FLOP of the 128-tile through L2. */
+int lidk_gemm_tn_grouped256(const void* descs, int n_desc, int total_items, void* stream);
 
 /* ------------------------------------------------------------------ Attention core with Shaw relative positions (lid/conformer.py:117-148)
  * qkv [B*T][3*heads*dh] (T): q | k | v column blocks, head h at columns h*dh.. within each.  rel_emb [2*max_pos+1][dh] f32.

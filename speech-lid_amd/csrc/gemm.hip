@@ -1081,6 +1081,343 @@ gemm_tn_grouped_kernel(const TnDesc* __restrict__ descs, int n_desc, int total_i
   }
 }
 
+// ------------------------------------------------------------------------------------ grouped TN, 128x128 tiles, LDS-DMA ring
+// The register-staged tile above keeps two 64-row tiles of global loads in flight per workgroup and pays a ds_write pass and
+// two barriers per 64 rows; with one item per CU (~200 items of ~4 800 rows at cfg2) it runs at ~13 % of the MFMA rate.  Here
+// both operand tiles of a stage (64 rows x 128 columns each, 256 B per row) arrive by global_load_lds_dwordx4 into a ring of
+// NST stages (NST - 1 stages = (NST - 1) x 32 KB in flight per CU, no staging registers, no ds_write pass, ONE barrier per
+// stage).  A wave instruction carries 4 rows (lane-linear image), the 16-byte chunks of row r are XOR-permuted on the SOURCE
+// address by sw(r) = 2 (r & 3) | 8 ((r >> 3) & 1): the 16 row segments one ds_read_b64_tr_b16 gathers (rows 8 fq + q) then
+// fall on 8 different bank groups per half wave.  The bias gradient (column sums of X) is taken by the matrix cores too:
+// X^T . 1 with a fragment of ones, two extra MFMAs per wave and K step on the tiles that own it.
+constexpr int TN_STG = 32768;       // one stage: X rows [64][256 B] | Y rows [64][256 B]
+
+__device__ __forceinline__ bf16x8 tr_pair256(const unsigned char* p) {      // rows k .. k+3 | k+4 .. k+7 of a 256-byte-row image
+  union { struct { s16x4_t lo, hi; } h; bf16x8 v; } u;
+  u.h.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)p);
+  u.h.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p + 1024));
+  return u.v;
+}
+
+__device__ __forceinline__ bf16x8 tr_pair512(const unsigned char* p) {      // the same for a 512-byte-row image
+  union { struct { s16x4_t lo, hi; } h; bf16x8 v; } u;
+  u.h.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)p);
+  u.h.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p + 2048));
+  return u.v;
+}
+
+// ABL (ablation builds, -DLIDK_TN_ABLATION, wrong results): 1 no DMA in the loop, 2 no fragment reads / MFMAs, 4 no output stores,
+// 8 fragment reads without MFMAs, 16 MFMAs without fragment reads
+template <int NST, bool CS, int ABL = 0>
+__device__ __forceinline__ void gemm_tn_dma_item(const TnDesc d, int tile, unsigned char* smem, unsigned smem0) {
+  const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
+  const int t1 = d.N1 / 128, t2 = d.N2 / 128;
+  const int bz = tile / (t1 * t2), by = (tile / t2) % t1, bx = tile % t2;
+  const int n1_0 = by * 128, n2_0 = bx * 128;
+  const int mbeg = bz * d.mchunk, mend = min(d.M, mbeg + d.mchunk), nt = (mend - mbeg) / 64;       // >= 1
+  const bool atomic = d.nsplit > 1;
+
+  // per-lane source offsets of this wave's 4 + 4 wave instructions per stage (stage rows 16 wid + 4 i + lane / 16)
+  unsigned xoff[4], yoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 16 * wid + 4 * i + (lane >> 4), c = (lane & 15) ^ (((r & 3) << 1) | (((r >> 3) & 1) << 3));
+    xoff[i] = (unsigned)((r * d.ldx + 8 * c) * 2);
+    yoff[i] = (unsigned)((r * d.ldy + 8 * c) * 2);
+  }
+  const bf16* xb = d.X + (size_t)mbeg * d.ldx + n1_0;
+  const bf16* yb = d.Y + (size_t)mbeg * d.ldy + n2_0;
+  const size_t xstep = (size_t)64 * d.ldx, ystep = (size_t)64 * d.ldy;
+  auto issue = [&](int ti, int slot) __attribute__((always_inline)) {
+    ti = min(ti, nt - 1);                              // past the end: the last tile again, into a slot nobody reads any more
+    const bf16* xs = xb + ti * xstep;
+    const bf16* ys = yb + ti * ystep;
+    const unsigned dst = smem0 + slot * TN_STG + wid * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gemm_glds16s(xs, xoff[i], dst + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gemm_glds16s(ys, yoff[i], dst + 16384 + i * 1024);
+  };
+
+  // per-lane fragment offsets inside a stage: row 8 fq + fr / 4, 16-byte chunk (tile chunk ^ sw(row)), 8-byte half fr & 1
+  const int swl = (((fr >> 2) & 3) << 1) | ((fq & 1) << 3);
+  const int rowb = (8 * fq + (fr >> 2)) * 256 + (((fr & 3) >> 1) << 4) + (fr & 1) * 8;
+  int aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    aoff[i] = rowb + (((wm * 8 + 2 * i) ^ swl) << 4);
+    boff[i] = 16384 + rowb + (((wn * 8 + 2 * i) ^ swl) << 4);
+  }
+
+  f32x4 acc[4][4], accs[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  accs[0] = accs[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ones[q] = (bf16)1.0f;
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) issue(s, s);
+  int slot = 0, islot = NST - 1;
+  for (int t = 0; t < nt; ++t) {
+    if (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 8) : "memory");      // this wave's pieces of stage t have landed
+    __syncthreads();                                  // everybody's have; and every wave is done reading the slot refilled next
+    if (!(ABL & 1)) issue(t + NST - 1, islot);
+    const unsigned char* sb = smem + slot * TN_STG;
+    slot = slot + 1 == NST ? 0 : slot + 1;
+    islot = islot + 1 == NST ? 0 : islot + 1;
+    if (ABL & 2) continue;
+    bf16x8 a0[4], b0[4], a1[4], b1[4];
+    if (ABL & 16) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a0[i] = b0[i] = a1[i] = b1[i] = ones;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a0[i] = tr_pair256(sb + aoff[i]); b0[i] = tr_pair256(sb + boff[i]); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a1[i] = tr_pair256(sb + aoff[i] + 8192); b1[i] = tr_pair256(sb + boff[i] + 8192); }
+    }
+    if (ABL & 8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(a0[i]), "v"(b0[i]), "v"(a1[i]), "v"(b1[i]));
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+    if (CS) {
+      if (wn == 0) { accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[0], ones, accs[0], 0, 0, 0);
+                     accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[1], ones, accs[1], 0, 0, 0); }
+      else         { accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[2], ones, accs[0], 0, 0, 0);
+                     accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[3], ones, accs[1], 0, 0, 0); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    if (CS) {
+      if (wn == 0) { accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0], ones, accs[0], 0, 0, 0);
+                     accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[1], ones, accs[1], 0, 0, 0); }
+      else         { accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[2], ones, accs[0], 0, 0, 0);
+                     accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[3], ones, accs[1], 0, 0, 0); }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the clamped refills of the tail still write LDS
+  __syncthreads();
+  if (ABL & 4) return;
+
+  if (CS && fr == 0) {                               // every column of X^T . 1 is the column sum; lanes fr == 0 hold rows 4 fq + r
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* dst = d.colsum + n1_0 + wm * 64 + (2 * wn + ii) * 16 + 4 * fq + r;
+        if (atomic) atomicAdd(dst, accs[ii][r] * d.alpha);
+        else *dst += accs[ii][r] * d.alpha;
+      }
+  }
+  constexpr int CST = 64 + 4;
+  float* Cw = reinterpret_cast<float*>(smem) + wid * 64 * CST;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cw[(i * 16 + fq * 4 + r) * CST + j * 16 + fr] = acc[i][j][r];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+  for (int row = 0; row < 64; ++row) {
+    float* dst = d.C + (size_t)(n1_0 + wm * 64 + row) * d.ldc + n2_0 + wn * 64 + lane;
+    const float v = Cw[row * CST + lane] * d.alpha;
+    if (atomic) atomicAdd(dst, v);
+    else *dst += v;
+  }
+}
+
+template <int NST, int ABL = 0>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gemm_tn_grouped_dma_kernel(const TnDesc* __restrict__ descs, int n_desc, int total_items) {
+  typedef __attribute__((address_space(3))) void lds_v;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_dma_smem[];
+  const unsigned smem0 = (unsigned)(size_t)(lds_v*)tn_dma_smem;
+  const int item = xcd_tile(blockIdx.x, total_items);
+  int g = 0;
+  while (g + 1 < n_desc && item >= descs[g + 1].item0) ++g;
+  const TnDesc d = descs[g];
+  const int tile = item - d.item0;
+  if (d.colsum != nullptr && tile % (d.N2 / 128) == 0) gemm_tn_dma_item<NST, true, ABL>(d, tile, tn_dma_smem, smem0);
+  else gemm_tn_dma_item<NST, false, ABL>(d, tile, tn_dma_smem, smem0);
+}
+
+// one weight gradient per launch: the record travels as a kernel argument
+template <int NST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gemm_tn_dma_single_kernel(const TnDesc d, int total_items) {
+  typedef __attribute__((address_space(3))) void lds_v;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_dma1_smem[];
+  const unsigned smem0 = (unsigned)(size_t)(lds_v*)tn_dma1_smem;
+  const int tile = xcd_tile(blockIdx.x, total_items);
+  if (d.colsum != nullptr && tile % (d.N2 / 128) == 0) gemm_tn_dma_item<NST, true>(d, tile, tn_dma1_smem, smem0);
+  else gemm_tn_dma_item<NST, false>(d, tile, tn_dma1_smem, smem0);
+}
+
+template <int NST>
+static void tn_dma_single_launch(const TnDesc& d, int total_items, hipStream_t s) {
+  constexpr int lds = NST * TN_STG > 4 * 64 * 68 * 4 ? NST * TN_STG : 4 * 64 * 68 * 4;
+  (void)hipFuncSetAttribute((const void*)gemm_tn_dma_single_kernel<NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  gemm_tn_dma_single_kernel<NST><<<total_items, 256, lds, s>>>(d, total_items);
+}
+
+template <int NST, int ABL = 0>
+static void tn_dma_launch(const void* descs, int n_desc, int total_items, hipStream_t s) {
+  constexpr int lds = NST * TN_STG > 4 * 64 * 68 * 4 ? NST * TN_STG : 4 * 64 * 68 * 4;
+  (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_dma_kernel<NST, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  gemm_tn_grouped_dma_kernel<NST, ABL><<<total_items, 256, lds, s>>>((const TnDesc*)descs, n_desc, total_items);
+}
+
+// ------------------------------------------------------------------------------------ grouped TN, 256x256 tiles, LDS-DMA
+// The 128-tile ring above is bound by the L2 -> LDS fill rate, not by HBM or the matrix cores: a 128x128 tile moves one operand
+// byte per 64 FLOP, ~510 MB per launch at cfg2, and the fabric delivers ~16-20 B/clk per CU when every CU pulls (the ring depth
+// makes no difference: 63.5 / 65.4 us with 3 / 4 stages, tools/wgrad_bench.py).  A 256x256 tile halves the bytes per FLOP.
+// 8 waves (2 x 4), each 128 x 64 outputs = 32 accumulator tiles; a stage is 64 rows of X [256 cols] and Y [256 cols] = 64 KB,
+// two stages = 128 KB per workgroup.  A wave instruction carries 2 rows of 512 B; chunk permutation as above (low 4 bits).
+constexpr int TN256_STG = 65536;
+
+template <bool CS>
+__device__ __forceinline__ void gemm_tn_dma256_item(const TnDesc d, int tile, unsigned char* smem, unsigned smem0) {
+  const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 2, wn = wid & 3;
+  const int t1 = d.N1 / 256, t2 = d.N2 / 256;
+  const int bz = tile / (t1 * t2), by = (tile / t2) % t1, bx = tile % t2;
+  const int n1_0 = by * 256, n2_0 = bx * 256;
+  const int mbeg = bz * d.mchunk, mend = min(d.M, mbeg + d.mchunk), nt = (mend - mbeg) / 64;       // >= 1
+  const bool atomic = d.nsplit > 1;
+
+  unsigned xoff[4], yoff[4];                       // stage rows 8 wid + 2 i + lane / 32, chunk (lane % 32) ^ sw(row)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 8 * wid + 2 * i + (lane >> 5), c = (lane & 31) ^ (((r & 3) << 1) | (((r >> 3) & 1) << 3));
+    xoff[i] = (unsigned)((r * d.ldx + 8 * c) * 2);
+    yoff[i] = (unsigned)((r * d.ldy + 8 * c) * 2);
+  }
+  const bf16* xb = d.X + (size_t)mbeg * d.ldx + n1_0;
+  const bf16* yb = d.Y + (size_t)mbeg * d.ldy + n2_0;
+  const size_t xstep = (size_t)64 * d.ldx, ystep = (size_t)64 * d.ldy;
+  auto issue = [&](int ti, int slot) __attribute__((always_inline)) {
+    const bf16* xs = xb + ti * xstep;
+    const bf16* ys = yb + ti * ystep;
+    const unsigned dst = smem0 + slot * TN256_STG + wid * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gemm_glds16s(xs, xoff[i], dst + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gemm_glds16s(ys, yoff[i], dst + 32768 + i * 1024);
+  };
+
+  const int swl = (((fr >> 2) & 3) << 1) | ((fq & 1) << 3);
+  const int rowb = (8 * fq + (fr >> 2)) * 512 + (((fr & 3) >> 1) << 4) + (fr & 1) * 8;
+  const int a_base = rowb + (((wm * 16) ^ swl) << 4);              // fragment i: a_base ^ (i << 5)  (bits 5-7: 2 i ^ swl)
+  const int b_base = 32768 + rowb + (((wn * 8) ^ swl) << 4);       // fragment j: b_base ^ (j << 5)
+
+  f32x4 acc[8][4], accs[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  accs[0] = accs[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ones[q] = (bf16)1.0f;
+
+  issue(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage t have landed
+    __syncthreads();                                      // everybody's have; every wave is done reading the other slot
+    if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+    const unsigned char* sb = smem + (t & 1) * TN256_STG;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a[8], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = tr_pair512(sb + (b_base ^ (j << 5)) + kk * 16384);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = tr_pair512(sb + (a_base ^ (i << 5)) + kk * 16384);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      if (CS) {
+        if (wn == 0)      { accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], ones, accs[0], 0, 0, 0);
+                            accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], ones, accs[1], 0, 0, 0); }
+        else if (wn == 1) { accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], ones, accs[0], 0, 0, 0);
+                            accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[3], ones, accs[1], 0, 0, 0); }
+        else if (wn == 2) { accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[4], ones, accs[0], 0, 0, 0);
+                            accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[5], ones, accs[1], 0, 0, 0); }
+        else              { accs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[6], ones, accs[0], 0, 0, 0);
+                            accs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[7], ones, accs[1], 0, 0, 0); }
+      }
+    }
+  }
+  __syncthreads();                                     // the last stage's slot becomes the output staging area
+
+  if (CS && fr == 0) {                                // every column of X^T . 1 is the column sum; lanes fr == 0 hold rows 4 fq + r
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* dst = d.colsum + n1_0 + wm * 128 + (2 * wn + ii) * 16 + 4 * fq + r;
+        if (atomic) atomicAdd(dst, accs[ii][r] * d.alpha);
+        else *dst += accs[ii][r] * d.alpha;
+      }
+  }
+  constexpr int CST = 64 + 4;
+  float* Cw = reinterpret_cast<float*>(smem) + wid * 32 * CST;       // 32 output rows of the wave at a time
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cw[(i * 16 + fq * 4 + r) * CST + j * 16 + fr] = acc[2 * h + i][j][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (int row = 0; row < 32; ++row) {
+      float* dst = d.C + (size_t)(n1_0 + wm * 128 + h * 32 + row) * d.ldc + n2_0 + wn * 64 + lane;
+      const float v = Cw[row * CST + lane] * d.alpha;
+      if (atomic) atomicAdd(dst, v);
+      else *dst += v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ void __launch_bounds__(512)
+gemm_tn_grouped_dma256_kernel(const TnDesc* __restrict__ descs, int n_desc, int total_items) {
+  typedef __attribute__((address_space(3))) void lds_v;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_dma256_smem[];
+  const unsigned smem0 = (unsigned)(size_t)(lds_v*)tn_dma256_smem;
+  const int item = xcd_tile(blockIdx.x, total_items);
+  int g = 0;
+  while (g + 1 < n_desc && item >= descs[g + 1].item0) ++g;
+  const TnDesc d = descs[g];
+  const int tile = item - d.item0;
+  if (d.colsum != nullptr && tile % (d.N2 / 256) == 0) gemm_tn_dma256_item<true>(d, tile, tn_dma256_smem, smem0);
+  else gemm_tn_dma256_item<false>(d, tile, tn_dma256_smem, smem0);
+}
+
+// 256x256 output tiles (item0 / total_items counted in 256-tiles; every record needs N1 % 256 == N2 % 256 == M % 64 == 0)
+extern "C" int lidk_gemm_tn_grouped256(const void* descs, int n_desc, int total_items, void* stream) {
+  if (!descs || n_desc <= 0 || total_items <= 0) return LIDK_ERR_ARG;
+  (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_dma256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN256_STG);
+  gemm_tn_grouped_dma256_kernel<<<total_items, 512, 2 * TN256_STG, as_stream(stream)>>>((const TnDesc*)descs, n_desc, total_items);
+  return launch_status();
+}
+
 extern "C" int lidk_gemm_tn_desc_bytes(void) { return (int)sizeof(TnDesc); }
 
 // descs: n_desc TnDesc records on the DEVICE (layout: lidk_gemm_tn_desc_bytes(), built by the host binding); total_items =
@@ -1100,7 +1437,32 @@ extern "C" int lidk_gemm_tn_grouped(const void* descs, int n_desc, int total_ite
 // M % 64 == 0): twice the MFMA work per operand byte staged through LDS.
 extern "C" int lidk_gemm_tn_grouped128(const void* descs, int n_desc, int total_items, void* stream) {
   if (!descs || n_desc <= 0 || total_items <= 0) return LIDK_ERR_ARG;
-  gemm_tn_grouped_kernel<true, 128><<<total_items, 256, 0, as_stream(stream)>>>((const TnDesc*)descs, n_desc, total_items);
+  // LIDK_TN_DMA (read per call): ring depth of the LDS-DMA kernel (2 / 3 / 4), 0: the register-staged tiles.  Default: 3 stages
+  // (96 KB, one workgroup per CU) while every item finds a CU of its own, 2 stages (64 KB, two per CU) beyond that.  Measured on
+  // a cfg2 block (tools/wgrad_bench.py, us per launch): register-staged 102 (208 items) / 108 (416); ring of 2: 75 / 62,
+  // of 3: 63.5 / 70.5, of 4: 65 / 72.
+  const char* env = getenv("LIDK_TN_DMA");
+  const int nst = env ? atoi(env) : (total_items > 256 ? 2 : 3);
+#ifdef LIDK_TN_ABLATION
+  const int abl = getenv("LIDK_TN_ABL") ? atoi(getenv("LIDK_TN_ABL")) : 0;
+  hipStream_t as = as_stream(stream);
+  switch (abl) {
+    case 1: tn_dma_launch<3, 1>(descs, n_desc, total_items, as); return launch_status();
+    case 2: tn_dma_launch<3, 2>(descs, n_desc, total_items, as); return launch_status();
+    case 4: tn_dma_launch<3, 4>(descs, n_desc, total_items, as); return launch_status();
+    case 5: tn_dma_launch<3, 5>(descs, n_desc, total_items, as); return launch_status();
+    case 6: tn_dma_launch<3, 6>(descs, n_desc, total_items, as); return launch_status();
+    case 8: tn_dma_launch<3, 8>(descs, n_desc, total_items, as); return launch_status();
+    case 9: tn_dma_launch<3, 9>(descs, n_desc, total_items, as); return launch_status();
+    case 16: tn_dma_launch<3, 16>(descs, n_desc, total_items, as); return launch_status();
+    case 17: tn_dma_launch<3, 17>(descs, n_desc, total_items, as); return launch_status();
+    default: break;
+  }
+#endif
+  if (nst == 2) tn_dma_launch<2>(descs, n_desc, total_items, as_stream(stream));
+  else if (nst == 3) tn_dma_launch<3>(descs, n_desc, total_items, as_stream(stream));
+  else if (nst >= 4) tn_dma_launch<4>(descs, n_desc, total_items, as_stream(stream));
+  else gemm_tn_grouped_kernel<true, 128><<<total_items, 256, 0, as_stream(stream)>>>((const TnDesc*)descs, n_desc, total_items);
   return launch_status();
 }
 
@@ -1162,6 +1524,23 @@ extern "C" int lidk_gemm_tn(const void* X, int ldx, const void* Y, int ldy, floa
   if (dtype == LIDK_BF16) {
     int mchunk = cdiv(cdiv(M, splitk), BKM) * BKM;
     splitk = cdiv(M, mchunk);
+    // Full 128-tile shapes with enough tiles: the LDS-DMA ring (gemm_tn_dma_item).  It chooses its own row split - as many
+    // chunks (<= 8) as keep the launch within 512 items, two 64 KB workgroups per CU - because every extra chunk is another
+    // pass of float atomics over the output.  LIDK_TN_DMA=0 turns it off (read per call).
+    {
+      const char* env = getenv("LIDK_TN_DMA");
+      const long tiles = (long)(N1 / 128) * (N2 / 128);
+      if (!(env && atoi(env) == 0) && !(N1 % 128) && !(N2 % 128) && !(M % 64) && tiles >= 16) {
+        int split = (int)std::min<long>(8, std::max<long>(1, 512 / tiles));
+        const int mc = cdiv(cdiv(M, split), 64) * 64;
+        split = cdiv(M, mc);
+        TnDesc d{(const bf16*)X, (const bf16*)Y, C, colsum, ldx, ldy, ldc, M, N1, N2, mc, 0, split, 0, alpha, 0};
+        const int items = (int)tiles * split;
+        if (items > 256) tn_dma_single_launch<2>(d, items, s);
+        else tn_dma_single_launch<3>(d, items, s);
+        return launch_status();
+      }
+    }
     static const int tn_tile = getenv("LIDK_TN_TILE") ? atoi(getenv("LIDK_TN_TILE")) : 0;
     const bool big = tn_tile == 128 || (tn_tile != 64 && N1 >= 128 && N2 >= 128 && (long)cdiv(N1, 128) * cdiv(N2, 128) * splitk >= 256);
     const int bn = big ? 128 : 64;

@@ -72,6 +72,7 @@ SIGNATURES = {
     "lidk_gemm_tn_desc_bytes": (_I, []),
     "lidk_gemm_tn_grouped": (_I, [_P, _I, _I, _I, _P]),
     "lidk_gemm_tn_grouped128": (_I, [_P, _I, _I, _P]),
+    "lidk_gemm_tn_grouped256": (_I, [_P, _I, _I, _P]),
     "lidk_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "lidk_attn_bwd_relpos_supported": (_I, [_I, _I, _I]),
     "lidk_attn_recompute_supported": (_I, [_I, _I, _I]),

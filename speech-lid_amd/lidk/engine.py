@@ -246,6 +246,11 @@ _WGRAD_WGS = int(__import__("os").environ.get("LIDK_WGRAD_WGS", "512"))      # w
 # each, ms per step): 64-tiles x 4 chunks 7.73 (x 8: 7.86); 128-tiles x 1 / 2 / 3 / 4 / 6 / 8 chunks 7.93 / 7.45 / 7.61 / 7.57 /
 # 7.70 / 7.70 - twice the MFMA work per operand byte fetched from L2 (the 64-tiles pull ~1 GB through L2 per launch) and ~190
 # long items instead of ~1 700 short ones beside the data-gradient chain.
+# Whole-chain backward capture: record the fork point before a block's data-gradient chain but capture the forked weight-gradient work
+# AFTER it (same dependencies).  The chain's first kernel is then the first child of the previous block's last kernel in the
+# hipGraph and the chain stays on one hardware queue (before: the last LayerNorm backward of every block ran on the side queue,
+# a cross-queue hand-over of ~10 us on either side of it).  7.20 -> 7.14 ms per step at cfg2 (two rounds, same box).
+_FORK_LATE = __import__("os").environ.get("LIDK_FORK_LATE", "1") == "1"
 _WGRAD_TILE = int(__import__("os").environ.get("LIDK_WGRAD_TILE", "128"))
 _WGRAD_SPLIT = int(__import__("os").environ.get("LIDK_WGRAD_SPLIT", "2" if _WGRAD_TILE == 128 else "4"))
 
@@ -1079,7 +1084,11 @@ class Engine:
                     if fuse_ok and n + 1 < len(blocks):
                         nxt = blocks[n + 1]
                         fuse = (nxt[3], nxt[2].post, w.sets[(n + 1) % ns], prv is not None and ns < 3)
-                    if prv is not None:
+                    late = prv is not None and _FORK_LATE
+                    if late:
+                        fork_at = torch.cuda.Event()
+                        fork_at.record()
+                    elif prv is not None:
                         with self._fork():
                             self._block_wgrads(w, prv[1], prv[2], prv[3], prv[0][0] == "enc")
                     if kind == "head":
@@ -1087,6 +1096,12 @@ class Engine:
                     else:
                         self._enc_block_bwd(dfeat, x_in, tag, w, dfeat, "all", S, not defer, post_done=post_done, fuse=fuse)
                     post_done = fuse is not None
+                    if late:
+                        # same dependencies as the fork above, captured AFTER the block's own chain: the chain's first kernel is
+                        # then the first child of the previous block's last kernel in the hipGraph
+                        self.side.wait_event(fork_at)
+                        with torch.cuda.stream(self.side):
+                            self._block_wgrads(w, prv[1], prv[2], prv[3], prv[0][0] == "enc")
                     if prv is not None:
                         self._join()
                     if defer:

@@ -427,12 +427,15 @@ class _TnDesc(C.Structure):
 
 def build_tn_group(entries, split=4, tile=64):
     """Descriptor table of a grouped weight-gradient launch.  entries: list of (X (M, N1) bf16, Y (M, N2) bf16, C (N1, N2) f32,
-    colsum (N1,) f32 or None, M, N1, N2): C += X[:M, :N1]^T @ Y[:M, :N2].  -> (device uint8 tensor, n, total_items, full); the
-    table holds raw pointers: rebuild it when any buffer is reallocated."""
+    colsum (N1,) f32 or None, M, N1, N2): C += X[:M, :N1]^T @ Y[:M, :N2].  split: row chunks per output tile (one int, or one per
+    entry); tile: 64, 128 or 256 (output tile edge; 128 / 256 need full shapes).  -> (device uint8 tensor, n, total_items, full or
+    tile); the table holds raw pointers: rebuild it when any buffer is reallocated."""
     if lib().lidk_gemm_tn_desc_bytes() != C.sizeof(_TnDesc):
         raise LidkError("TnDesc layout mismatch between ops.py and liblidk.so")
     arr, item, full, dev = (_TnDesc * len(entries))(), 0, True, None
+    splits = list(split) if isinstance(split, (list, tuple)) else [split] * len(entries)       # row chunks per entry
     for i, (X, Y, Cm, cs, M, N1, N2) in enumerate(entries):
+        split = splits[i]
         if X.dtype != torch.bfloat16 or Y.dtype != torch.bfloat16 or Cm.dtype != torch.float32:
             raise LidkError("build_tn_group: bf16 operands, f32 output")
         if X.stride(-1) != 1 or Y.stride(-1) != 1 or Cm.stride(-1) != 1 or (X.stride(0) & 7) or (Y.stride(0) & 7):
@@ -448,14 +451,17 @@ def build_tn_group(entries, split=4, tile=64):
         dev = X.device
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     if tile != 64 and not full:
-        raise LidkError("build_tn_group: 128-tiles need N1 % 128 == N2 % 128 == M % 64 == 0")
-    return host.to(dev), len(entries), item, (full if tile == 64 else 128)
+        raise LidkError(f"build_tn_group: {tile}-tiles need N1 % {tile} == N2 % {tile} == M % 64 == 0")
+    return host.to(dev), len(entries), item, (full if tile == 64 else tile)
 
 
 def gemm_tn_grouped(group):
     table, n, items, full = group
     if full == 128:
         check(lib().lidk_gemm_tn_grouped128(_p(table), n, items, _stream()), "gemm_tn_grouped128")
+        return
+    if full == 256:
+        check(lib().lidk_gemm_tn_grouped256(_p(table), n, items, _stream()), "gemm_tn_grouped256")
         return
     check(lib().lidk_gemm_tn_grouped(_p(table), n, items, int(full), _stream()), "gemm_tn_grouped")
 

@@ -221,9 +221,12 @@ def test_gemm_pipelined_tiles(M, N):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N1,N2,splitk", [(9664, 1024, 256, 8), (9664, 256, 1024, 8), (204, 256, 64, 4), (1000, 41, 256, 16),
-                                            (333, 80, 240, 3), (4100, 768, 256, 5), (130, 64, 64, 1), (2048, 256, 256, 16)])
+                                            (333, 80, 240, 3), (4100, 768, 256, 5), (130, 64, 64, 1), (2048, 256, 256, 16),
+                                            (9536, 768, 3072, 4), (9536, 2304, 768, 4), (9536, 768, 768, 4), (1088, 512, 1536, 2)])
 def test_gemm_tn_wgrad(dt, M, N1, N2, splitk):
-    """dW = dY^T . X from the row-major activations (no transposes), bias gradient fused as a column sum."""
+    """dW = dY^T . X from the row-major activations (no transposes), bias gradient fused as a column sum.  bf16 shapes with
+    N1 % 128 == N2 % 128 == M % 64 == 0 and >= 16 128-tiles run the LDS-DMA ring (one, several and > 256 items per launch:
+    the transformer backbones' d = 768 / ffn 3072 gradients and the conv extractor's)."""
     N1p = (N1 + 7) // 8 * 8
     X = torch.zeros(M, N1p)
     X[:, :N1] = torch.randn(M, N1, generator=g(90)) * (0.5 + torch.arange(N1) / N1)
@@ -989,7 +992,7 @@ def test_speed_perturb_matches_the_float64_restatement():
 
 
 @pytest.mark.parametrize("M", [9664, 1000])
-def test_grouped_weight_gradients_equal_the_separate_launches(M):
+def test_grouped_weight_gradients_equal_the_separate_launches(M, monkeypatch):
     """lidk_gemm_tn_grouped (one launch for a block's weight gradients) against lidk_gemm_tn per site and against torch:
     full-tile shapes (M = 9664 = 151 * 64) and a ragged M with a narrow, non-multiple-of-64 site."""
     torch.manual_seed(M)
@@ -1017,13 +1020,30 @@ def test_grouped_weight_gradients_equal_the_separate_launches(M):
         with pytest.raises(LidkError):
             ops.build_tn_group(ents, split=2, tile=128)
         return
-    for split in (1, 2, 3):                      # the training default is 128-tiles x 2 row chunks (lidk_gemm_tn_grouped128)
+    # the training default is 128-tiles x 2 row chunks (lidk_gemm_tn_grouped128); LIDK_TN_DMA picks the register-staged tile (0)
+    # or the LDS-DMA ring of 2 / 3 / 4 stages (read per call); split 7 leaves chunks of 22 / 19 row tiles, 151 a single one
+    for dma, split in ((None, 2), (None, 4), ("0", 1), ("0", 2), ("0", 3), ("2", 2), ("3", 1), ("3", 2), ("4", 2), ("4", 7), ("3", 151)):
+        if dma is None:
+            monkeypatch.delenv("LIDK_TN_DMA", raising=False)          # the default: ring of 3 (<= 256 items) or 2
+        else:
+            monkeypatch.setenv("LIDK_TN_DMA", dma)
         ents2 = [(X, Y, torch.zeros_like(Cg), torch.zeros_like(csg), M, n1, n2) for X, Y, Cg, csg, _, n1, n2 in ents]
         grp = ops.build_tn_group(ents2, split=split, tile=128)
         assert grp[3] == 128
         ops.gemm_tn_grouped(grp)
         torch.cuda.synchronize()
         for (X, Y, Cg, csg, *_), (Cr, csr) in zip(ents2, refs):
+            ref, refc = X.float().t() @ Y.float(), X.float().sum(0)
+            assert float((Cg - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+            assert float((csg - refc).abs().max()) <= 2e-3 * float(refc.abs().max())
+    # 256x256 output tiles (lidk_gemm_tn_grouped256, 8 waves, two 64 KB LDS-DMA stages), uniform and per-entry row splits
+    for split in (1, 8, 151, [10, 9, 3, 1, 2]):
+        ents3 = [(X, Y, torch.zeros_like(Cg), torch.zeros_like(csg), M, n1, n2) for X, Y, Cg, csg, _, n1, n2 in ents]
+        grp = ops.build_tn_group(ents3, split=split, tile=256)
+        assert grp[3] == 256
+        ops.gemm_tn_grouped(grp)
+        torch.cuda.synchronize()
+        for (X, Y, Cg, csg, *_), (Cr, csr) in zip(ents3, refs):
             ref, refc = X.float().t() @ Y.float(), X.float().sum(0)
             assert float((Cg - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
             assert float((csg - refc).abs().max()) <= 2e-3 * float(refc.abs().max())
