@@ -755,6 +755,142 @@ gemm_nt_bf16_pipe_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
 #undef PIPE_STAGE
 }
 
+// The same stage machinery for K = 64 KS (KS even, 8 ... 16: the K = 512 / 768 / 1024 data gradients of the QKV projection and the
+// first pointwise convolution).  gemm_nt_bf16_direct_kernel reads every operand fragment twice from L2 (its 2 x 2 waves share rows
+// and columns but not registers): at K = 768, N = 256 that is 232 MB through the texture path of 256 CUs, ~30 us for 3.8 GFLOP;
+// staged through LDS each operand byte enters the CU once.  TPB = 1: one tile per workgroup (no cross-tile overlap).
+template <int MODE, int KS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
+gemm_nt_bf16_pipek_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int lda, int ldb, int tiles,
+                         int G, int TPB, Epi e) {
+  __shared__ __attribute__((aligned(16))) bf16 As[64 * BK];
+  __shared__ __attribute__((aligned(16))) bf16 Bs[64 * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int n_tiles = N / 64, span = G * TPB;
+
+  auto coords = [&](int j, int& m0, int& n0) __attribute__((always_inline)) {
+    int t = xcd_tile(blockIdx.x + j * G, span);          // G % 8 == 0: the XCD of launch index b + j*G is that of b
+    t = min(t, tiles - 1);
+    m0 = (t / n_tiles) * 64; n0 = (t % n_tiles) * 64;
+  };
+  u32x4 ra0[2], rb0[2], ra1[2], rb1[2];
+  auto gload = [&](u32x4 (&ra)[2], u32x4 (&rb)[2], int m0, int n0, int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int c = tid + i * 256, row = c >> 3, kc = (c & 7) * 8;
+      ra[i] = *reinterpret_cast<const u32x4*>(A + (size_t)(m0 + row) * lda + k0 + kc);
+      rb[i] = *reinterpret_cast<const u32x4*>(B + (size_t)(n0 + row) * ldb + k0 + kc);
+    }
+  };
+  auto lstore = [&](const u32x4 (&ra)[2], const u32x4 (&rb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int c = tid + i * 256, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<u32x4*>(&As[row * BK + ((ch ^ (row & 7)) << 3)]) = ra[i];
+      int rho = (row & ~31) + (((row >> 2) & 1) << 4) + (((row >> 3) & 3) << 2) + (row & 3);     // bf16 outputs: pair layout
+      *reinterpret_cast<u32x4*>(&Bs[rho * BK + ((ch ^ (rho & 7)) << 3)]) = rb[i];
+    }
+  };
+  f32x4 acc[2][2], prv[2][2];
+  auto mma = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; kk += 4) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * 32 + i * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * 32 + j * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+  // rows i*16 + fr of this wave's 32x32 block of the tile at (m0, n0): 8 consecutive columns per lane
+  auto epi = [&](const f32x4 (&a)[2][2], int i, int m0, int n0) __attribute__((always_inline)) {
+    const int m = m0 + wm * 32 + i * 16 + fr, n = n0 + wn * 32 + 8 * fq;
+    float4 v0 = make_float4(a[i][0][0], a[i][0][1], a[i][0][2], a[i][0][3]);
+    float4 v1 = make_float4(a[i][1][0], a[i][1][1], a[i][1][2], a[i][1][3]);
+    if (MODE == PIPE_BIAS || MODE == PIPE_BIAS_SWISH_PRE) {
+      float4 b0 = load4(e.bias + n), b1 = load4(e.bias + n + 4);
+      v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w; v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
+    }
+    if (MODE == PIPE_BIAS_SWISH_PRE) {
+      *reinterpret_cast<uint4*>((bf16*)e.out2 + (size_t)m * e.ldo2 + n) = pack8(v0, v1);
+      v0.x *= sigmoidf_(v0.x); v0.y *= sigmoidf_(v0.y); v0.z *= sigmoidf_(v0.z); v0.w *= sigmoidf_(v0.w);
+      v1.x *= sigmoidf_(v1.x); v1.y *= sigmoidf_(v1.y); v1.z *= sigmoidf_(v1.z); v1.w *= sigmoidf_(v1.w);
+    }
+    if (MODE == PIPE_SWISH_GRAD) {
+      const bf16* ap = (const bf16*)e.aux + (size_t)m * e.ldaux + n;
+      float4 a0 = load4(ap), a1 = load4(ap + 4);
+      float s;
+      s = sigmoidf_(a0.x); v0.x *= s * (1.f + a0.x * (1.f - s)); s = sigmoidf_(a0.y); v0.y *= s * (1.f + a0.y * (1.f - s));
+      s = sigmoidf_(a0.z); v0.z *= s * (1.f + a0.z * (1.f - s)); s = sigmoidf_(a0.w); v0.w *= s * (1.f + a0.w * (1.f - s));
+      s = sigmoidf_(a1.x); v1.x *= s * (1.f + a1.x * (1.f - s)); s = sigmoidf_(a1.y); v1.y *= s * (1.f + a1.y * (1.f - s));
+      s = sigmoidf_(a1.z); v1.z *= s * (1.f + a1.z * (1.f - s)); s = sigmoidf_(a1.w); v1.w *= s * (1.f + a1.w * (1.f - s));
+    }
+    *reinterpret_cast<uint4*>((bf16*)e.out + (size_t)m * e.ldo + n) = pack8(v0, v1);
+  };
+  auto zero = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto keep = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) prv[i][j] = acc[i][j];
+  };
+  int m0, n0, mn = 0, nn = 0, mp = 0, np = 0;
+  // one tile = KS stages in two alternating register sets; stage s refills its set with stage s + 2 of the same tile or, in the
+  // last two stages, with the first two stages of the next tile; the previous tile's epilogue rides in stages 0 and 1.  After
+  // full unrolling every condition below is a compile-time constant (no refill sits behind a runtime branch).
+  auto stage = [&](u32x4 (&ra)[2], u32x4 (&rb)[2], int s_, auto first, auto last) __attribute__((always_inline)) {
+    lstore(ra, rb);
+    __syncthreads();
+    if (s_ + 2 < KS) gload(ra, rb, m0, n0, (s_ + 2) * BK);
+    else if constexpr (!decltype(last)::value) gload(ra, rb, mn, nn, (s_ + 2 - KS) * BK);
+    mma();
+    if constexpr (!decltype(first)::value) { if (s_ < 2) epi(prv, s_, mp, np); }
+    __syncthreads();
+  };
+  auto tile = [&](auto first, auto last) __attribute__((always_inline)) {
+    zero();
+#pragma unroll
+    for (int sp = 0; sp < KS; sp += 2) {
+      stage(ra0, rb0, sp, first, last);
+      stage(ra1, rb1, sp + 1, first, last);
+    }
+  };
+  constexpr std::true_type YES{};
+  constexpr std::false_type NO{};
+  coords(0, m0, n0);
+  gload(ra0, rb0, m0, n0, 0);
+  gload(ra1, rb1, m0, n0, BK);
+  if (TPB == 1) {                 // block-uniform
+    tile(YES, YES);
+    epi(acc, 0, m0, n0);
+    epi(acc, 1, m0, n0);
+    return;
+  }
+  coords(1, mn, nn);
+  tile(YES, NO);
+  keep(); mp = m0; np = n0; m0 = mn; n0 = nn;
+  for (int j = 1; j + 1 < TPB; ++j) {
+    coords(j + 1, mn, nn);
+    tile(NO, NO);
+    keep(); mp = m0; np = n0; m0 = mn; n0 = nn;
+  }
+  tile(NO, YES);
+  epi(acc, 0, m0, n0);
+  epi(acc, 1, m0, n0);
+}
+
 // ------------------------------------------------------------------------------------ f32 kernel (parity mode)
 __global__ void __launch_bounds__(256)
 gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, int M, int N, int K, int lda, int ldb,
@@ -834,18 +970,46 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
         return launch_status();
       }
     }
+    // K = 512 / 768 / 1024 with plain / bias epilogues: the K-generic pipelined kernel (LIDK_GEMM_PIPEK = tiles per workgroup, default 1,
+    // 0 = off).  tools/gemm_longk_bench.py, us per launch, direct kernel / 1 / 2 / 3 tiles per workgroup: M 9664 N 256 K 768: 12.2 /
+    // 11.2 / 13.6 / 13.0; K 1024: 14.2 / 12.8 / 16.5 / 16.0; K 512: 9.0 / 8.1 / 10.1 / 9.9; M 9536 N 768 K 768: 23.1 / 21.2 / 23.4 /
+    // 24.8.  End to end at cfg2 it is neutral (7.13 / 7.21 against 7.13 / 7.17 ms per step): beside the weight-gradient stream these
+    // launches take 2-3 x their isolated time whichever kernel runs.
+    {
+      const char* pk_env = getenv("LIDK_GEMM_PIPEK");            // read per call (a test flips it inside one process)
+      const int pk = pk_env ? atoi(pk_env) : 1;
+      if (pk > 0 && splitk == 1 && !dbg && (g->K == 512 || g->K == 768 || g->K == 1024) && !(g->M & 63) && !(g->N & 63) && !g->out_f32 &&
+          !g->res && g->alpha == 1.0f && !(g->ldo & 7) && g->act == LIDK_ACT_NONE && !g->out2) {
+        const int tiles = (g->M / 64) * (g->N / 64);
+        const int tpb = tiles >= 16 * pk ? pk : 1;
+        const int G = tpb == 1 ? tiles : cdiv(cdiv(tiles, tpb), 8) * 8;
+#define LIDK_PIPEK_LAUNCH(MODE_, KS_)                                                                                          \
+  gemm_nt_bf16_pipek_kernel<MODE_, KS_><<<G, 256, 0, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->lda, g->ldb,   \
+                                                          tiles, G, tpb, e)
+        if (g->bias) {
+          if (g->K == 512) LIDK_PIPEK_LAUNCH(PIPE_BIAS, 8); else if (g->K == 768) LIDK_PIPEK_LAUNCH(PIPE_BIAS, 12); else LIDK_PIPEK_LAUNCH(PIPE_BIAS, 16);
+        } else {
+          if (g->K == 512) LIDK_PIPEK_LAUNCH(PIPE_PLAIN, 8); else if (g->K == 768) LIDK_PIPEK_LAUNCH(PIPE_PLAIN, 12); else LIDK_PIPEK_LAUNCH(PIPE_PLAIN, 16);
+        }
+#undef LIDK_PIPEK_LAUNCH
+        return launch_status();
+      }
+    }
     // LDS-DMA 128x128 kernel: opt-in, K >= LIDK_GEMM_DMA (e.g. 512; default 0 = never), N % 128 == 0, >= 384 tiles.  Faster per launch
     // on the backbones' big-K shapes (below) but NOT end to end: WavLM frozen / fine-tune 25.05 / 31.65 ms per step with it against
     // 24.68 / 31.30 without, wav2vec2 on 1-10 s batches 49.2 / 48.8 against 48.2 / 48.7 (two 64 KB workgroups per CU leave the
-    // weight-gradient stream less room beside it), so it stays off.
+    // weight-gradient stream less room beside it), so it stays off.  LIDK_GEMM_DMA_TILES lowers the tile-count floor (default 384): with
+    // it at 100 the cfg2 data gradients of K >= 512 (152 tiles of 128 x 128) take this kernel and the step goes 7.16 -> 7.68 ms.
     const char* dma_env = getenv("LIDK_GEMM_DMA");                 // read per call (a test flips it inside one process)
     const int dma_min_k = dma_env ? atoi(dma_env) : 0;
     // Measured against the 64x64 / register-staged 128x128 kernels on the backbone shapes (tools/gemm_bench_wavlm.py): K = 3072
     // +36 % (798 TFLOP/s), conv stack K = 1536 +7...20 %, K = 768 single output +0...7 %; it LOSES with the two-output GELU
     // epilogue at K = 768 (store-bound) and when the tile count leaves a mostly empty second round (512 < tiles < 1024).
     const long dma_tiles = (long)cdiv(g->M, 128) * (g->N / 128);
+    const char* dma_tiles_env = getenv("LIDK_GEMM_DMA_TILES");
+    const long dma_min_tiles = dma_tiles_env ? atol(dma_tiles_env) : 384;
     if (direct && splitk == 1 && dma_min_k > 0 && g->K >= dma_min_k && (g->K & 63) == 0 && !(g->N & 127) &&
-        (g->K >= 1024 || !g->out2) && dma_tiles >= 384 && (dma_tiles <= 512 || dma_tiles >= 1024) &&
+        (g->K >= 1024 || !g->out2) && dma_tiles >= dma_min_tiles && (dma_tiles <= 512 || dma_tiles >= 1024) &&
         (size_t)128 * g->lda * 2 < (1ull << 31) && (size_t)128 * g->ldb * 2 < (1ull << 31)) {
       const int grid = (g->N / 128) * cdiv(g->M, 128);
       static bool dma_attr = false;

@@ -259,6 +259,7 @@ class Engine:
     def __init__(self, cfg: ConformerCfg, act_dtype=torch.bfloat16, backend=None):
         self.cfg = cfg
         self.act_dtype = act_dtype
+        self._after_first = None
         # kernel backend: the real lidk.ops (HIP; refuses CPU tensors).  tests/ may inject a torch-CPU fake to check
         # the orchestration on a GPU-less machine; nothing in the product constructs an Engine with another backend.
         self.k = backend if backend is not None else ops
@@ -861,6 +862,9 @@ class Engine:
         if part in ("all", "a"):
             # ---- ff2: y = x3 + 0.5*ff(x3)
             self._ff_bwd(w, dx4, t0, bb.x3, bp.ff2, bb.h4, bb.a4, bb.u4, bb.mean[3], bb.rstd[3], a, t1, 1.0, S.da[0], wg, S.lnp[1])
+            if self._after_first is not None:           # whole-chain capture: the previous block's weight gradients fork here
+                cb, self._after_first = self._after_first, None
+                cb()
             # ---- conv module: y = x2 + conv(x2)
             if wg:
                 self._wgrad(w, t1, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
@@ -1086,8 +1090,17 @@ class Engine:
                         fuse = (nxt[3], nxt[2].post, w.sets[(n + 1) % ns], prv is not None and ns < 3)
                     late = prv is not None and _FORK_LATE
                     if late:
+                        # same dependencies as the fork below, but captured AFTER the block's first data-gradient launch: that
+                        # kernel is then the first child of the previous block's last kernel in the hipGraph (and BEFORE the
+                        # rest of the chain, whose fused LayerNorm pair joins the second stream ahead of overwriting S_prev)
                         fork_at = torch.cuda.Event()
                         fork_at.record()
+
+                        def side_work(prv=prv, fork_at=fork_at):
+                            self.side.wait_event(fork_at)
+                            with torch.cuda.stream(self.side):
+                                self._block_wgrads(w, prv[1], prv[2], prv[3], prv[0][0] == "enc")
+                        self._after_first = side_work
                     elif prv is not None:
                         with self._fork():
                             self._block_wgrads(w, prv[1], prv[2], prv[3], prv[0][0] == "enc")
@@ -1096,12 +1109,9 @@ class Engine:
                     else:
                         self._enc_block_bwd(dfeat, x_in, tag, w, dfeat, "all", S, not defer, post_done=post_done, fuse=fuse)
                     post_done = fuse is not None
-                    if late:
-                        # same dependencies as the fork above, captured AFTER the block's own chain: the chain's first kernel is
-                        # then the first child of the previous block's last kernel in the hipGraph
-                        self.side.wait_event(fork_at)
-                        with torch.cuda.stream(self.side):
-                            self._block_wgrads(w, prv[1], prv[2], prv[3], prv[0][0] == "enc")
+                    if late and self._after_first is not None:      # not consumed by the chain: issue it now
+                        cb, self._after_first = self._after_first, None
+                        cb()
                     if prv is not None:
                         self._join()
                     if defer:

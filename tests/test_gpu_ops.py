@@ -219,6 +219,30 @@ def test_gemm_pipelined_tiles(M, N):
     check("pipe_swish_grad", out, acc * s_ * (1 + rt(aux, dt) * (1 - s_)), 4e-2)
 
 
+@pytest.mark.parametrize("tpb", ["1", "2", "3"])
+@pytest.mark.parametrize("M,N,K", [(9664, 256, 768), (9664, 256, 1024), (9664, 256, 512), (128, 256, 768), (2112, 192, 512)])
+def test_gemm_pipelined_long_k(M, N, K, tpb, monkeypatch):
+    """K = 512 / 768 / 1024 through the K-generic pipelined kernel (LIDK_GEMM_PIPEK = tiles per workgroup): plain and bias
+    epilogues, one tile per workgroup when the launch is small, clamped duplicate tiles at the end of the range."""
+    monkeypatch.setenv("LIDK_GEMM_PIPEK", tpb)
+    dt = torch.bfloat16
+    A = torch.randn(M, K, generator=g(34)) * 0.3
+    B = torch.randn(N, K, generator=g(35)) * 0.3
+    bias = torch.randn(N, generator=g(36))
+    acc = _gemm_ref(A, B, dt).float()
+    Ad, Bd = dev(A, dt), dev(B, dt)
+    out = torch.full((M, N), 5.0, device=DEV, dtype=dt)
+    ops.gemm_nt(Ad, Bd, out)
+    check("pipek_plain", out, acc, 2e-2, rtol=1e-2)
+    out.fill_(5.0)
+    ops.gemm_nt(Ad, Bd, out, bias=dev(bias))
+    check("pipek_bias", out, acc + bias, 2e-2, rtol=1e-2)
+    monkeypatch.setenv("LIDK_GEMM_PIPEK", "0")
+    ref = torch.empty_like(out)
+    ops.gemm_nt(Ad, Bd, ref, bias=dev(bias))
+    assert float((out.float() - ref.float()).abs().max()) <= 2e-2 * float(ref.float().abs().max())
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N1,N2,splitk", [(9664, 1024, 256, 8), (9664, 256, 1024, 8), (204, 256, 64, 4), (1000, 41, 256, 16),
                                             (333, 80, 240, 3), (4100, 768, 256, 5), (130, 64, 64, 1), (2048, 256, 256, 16),
