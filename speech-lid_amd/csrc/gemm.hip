@@ -1409,13 +1409,19 @@ gemm_tn_grouped_dma_kernel(const TnDesc* __restrict__ descs, int n_desc, int tot
   typedef __attribute__((address_space(3))) void lds_v;
   extern __shared__ __attribute__((aligned(16))) unsigned char tn_dma_smem[];
   const unsigned smem0 = (unsigned)(size_t)(lds_v*)tn_dma_smem;
-  const int item = xcd_tile(blockIdx.x, total_items);
-  int g = 0;
-  while (g + 1 < n_desc && item >= descs[g + 1].item0) ++g;
-  const TnDesc d = descs[g];
-  const int tile = item - d.item0;
-  if (d.colsum != nullptr && tile % (d.N2 / 128) == 0) gemm_tn_dma_item<NST, true, ABL>(d, tile, tn_dma_smem, smem0);
-  else gemm_tn_dma_item<NST, false, ABL>(d, tile, tn_dma_smem, smem0);
+  // grid == total_items: one item per workgroup.  A smaller grid (LIDK_TN_GRID) walks the items with a stride: the launch then
+  // holds a bounded number of CUs for longer and leaves the others to the LDS-heavy kernels of the data-gradient chain.  Measured
+  // SLOWER at cfg2 (ms per step, two rounds): 0 (= 208 workgroups) 7.08 / 7.16, 152: 7.49 / 7.54, 104: 7.57 / 7.55, 70: 7.74 / 7.81.
+  for (int it = blockIdx.x; it < total_items; it += gridDim.x) {
+    const int item = xcd_tile(it, total_items);
+    int g = 0;
+    while (g + 1 < n_desc && item >= descs[g + 1].item0) ++g;
+    const TnDesc d = descs[g];
+    const int tile = item - d.item0;
+    if (d.colsum != nullptr && tile % (d.N2 / 128) == 0) gemm_tn_dma_item<NST, true, ABL>(d, tile, tn_dma_smem, smem0);
+    else gemm_tn_dma_item<NST, false, ABL>(d, tile, tn_dma_smem, smem0);
+    __syncthreads();                  // the ring doubles as the output staging area of the item just finished
+  }
 }
 
 // one weight gradient per launch: the record travels as a kernel argument
@@ -1441,7 +1447,9 @@ template <int NST, int ABL = 0>
 static void tn_dma_launch(const void* descs, int n_desc, int total_items, hipStream_t s) {
   constexpr int lds = NST * TN_STG > 4 * 64 * 68 * 4 ? NST * TN_STG : 4 * 64 * 68 * 4;
   (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_dma_kernel<NST, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  gemm_tn_grouped_dma_kernel<NST, ABL><<<total_items, 256, lds, s>>>((const TnDesc*)descs, n_desc, total_items);
+  static const int cap = getenv("LIDK_TN_GRID") ? atoi(getenv("LIDK_TN_GRID")) : 0;          // 0: one workgroup per item
+  const int grid = cap > 0 && cap < total_items ? cap : total_items;
+  gemm_tn_grouped_dma_kernel<NST, ABL><<<grid, 256, lds, s>>>((const TnDesc*)descs, n_desc, total_items);
 }
 
 // ------------------------------------------------------------------------------------ grouped TN, 256x256 tiles, LDS-DMA
