@@ -1324,13 +1324,34 @@ __device__ __forceinline__ void gemm_tn_dma_item(const TnDesc d, int tile, unsig
 #pragma unroll
   for (int q = 0; q < 8; ++q) ones[q] = (bf16)1.0f;
 
+  // ABL & 32 (experiment): the same LDS image filled through registers (global_load_dwordx4 + ds_write_b128) instead of LDS-DMA
+  u32x4 rg[8];
+  auto gload = [&](int ti) __attribute__((always_inline)) {
+    ti = min(ti, nt - 1);
+    const char* xs = reinterpret_cast<const char*>(xb + ti * xstep);
+    const char* ys = reinterpret_cast<const char*>(yb + ti * ystep);
 #pragma unroll
-  for (int s = 0; s < NST - 1; ++s) issue(s, s);
+    for (int i = 0; i < 4; ++i) { rg[i] = *reinterpret_cast<const u32x4*>(xs + xoff[i]); rg[4 + i] = *reinterpret_cast<const u32x4*>(ys + yoff[i]); }
+  };
+  auto lwrite = [&](int slot_) __attribute__((always_inline)) {
+    unsigned char* dst = smem + slot_ * TN_STG + wid * 4096 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { *reinterpret_cast<u32x4*>(dst + i * 1024) = rg[i]; *reinterpret_cast<u32x4*>(dst + 16384 + i * 1024) = rg[4 + i]; }
+  };
+  if (ABL & 32) {
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) { gload(s); lwrite(s); }
+    gload(NST - 1);
+  } else {
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue(s, s);
+  }
   int slot = 0, islot = NST - 1;
   for (int t = 0; t < nt; ++t) {
-    if (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 8) : "memory");      // this wave's pieces of stage t have landed
+    if (!(ABL & 33)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 8) : "memory");      // this wave's pieces of stage t have landed
     __syncthreads();                                  // everybody's have; and every wave is done reading the slot refilled next
-    if (!(ABL & 1)) issue(t + NST - 1, islot);
+    if (ABL & 32) { lwrite(islot); gload(t + NST); }
+    else if (!(ABL & 1)) issue(t + NST - 1, islot);
     const unsigned char* sb = smem + slot * TN_STG;
     slot = slot + 1 == NST ? 0 : slot + 1;
     islot = islot + 1 == NST ? 0 : islot + 1;
@@ -1628,6 +1649,9 @@ extern "C" int lidk_gemm_tn_grouped128(const void* descs, int n_desc, int total_
     case 9: tn_dma_launch<3, 9>(descs, n_desc, total_items, as); return launch_status();
     case 16: tn_dma_launch<3, 16>(descs, n_desc, total_items, as); return launch_status();
     case 17: tn_dma_launch<3, 17>(descs, n_desc, total_items, as); return launch_status();
+    case 32: tn_dma_launch<3, 32>(descs, n_desc, total_items, as); return launch_status();
+    case 34: tn_dma_launch<3, 34>(descs, n_desc, total_items, as); return launch_status();
+    case 38: tn_dma_launch<3, 38>(descs, n_desc, total_items, as); return launch_status();
     default: break;
   }
 #endif
