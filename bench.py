@@ -137,7 +137,11 @@ def resident_batches(ds, rank, world, device, batch, resident, ragged=False):
             b.append(sum(ds.n_samples_of(i) for i in idx) / 16000.0 if ragged else batch * SECONDS)
             b[0] = [w.to(device) for w in b[0]] if isinstance(b[0], list) else b[0].to(device)
             for j in (1, 2, 3, 5):
-                b[j] = b[j].to(device)
+                host = b[j]
+                b[j] = host.to(device)
+                if not host.is_floating_point():          # as Trainer.batch_to_device does: small integer metadata (the batch's
+                    b[j]._host = host                     # language id) stays readable on the host without a device sync
+
             out.append(b)
     return out
 

@@ -579,7 +579,12 @@ class Trainer:
     @register_cost_statistic(need_return=True)
     def batch_to_device(self, batch: List[Any]):
         def move(x):
-            return x.to(self.device, non_blocking=True) if isinstance(x, torch.Tensor) else x
+            if not isinstance(x, torch.Tensor):
+                return x
+            y = x.to(self.device, non_blocking=True)
+            if x.device.type == "cpu" and not x.is_floating_point() and x.numel() <= 4096:
+                y._host = x          # small integer metadata (language ids, ...): modules read it here instead of syncing on the copy
+            return y
         batch = list(batch)
         for i, item in enumerate(batch):
             if isinstance(item, torch.Tensor):

@@ -114,7 +114,9 @@ class LidModule(CCMLModule):
     # ------------------------------------------------------------------ shared forward + loss (reference :178-223)
     def common_loop(self, batch, train_stat: bool = True) -> Dict:
         wavs, texts, wav_percents, text_percents, langs = batch[0], batch[1], batch[2], batch[3], batch[5]
-        lang = self.index2lang_dict[int(langs[0])]
+        # single-language batches (Q7): the id comes from the host copy Trainer.batch_to_device keeps beside the device tensor -
+        # int(langs[0]) on the device tensor is a blocking read behind everything queued, i.e. one full host-device sync per step
+        lang = self.index2lang_dict[int(getattr(langs, "_host", langs)[0])]
         wavs = self._prepare_wavs(wavs, train_stat and self.model.training)
         out, _ = self.model(wavs, self.sr, lang)
         out = out[lang]

@@ -78,7 +78,7 @@ class LidSuperviseModule(CCMLModule):
     def common_loop(self, batch, with_text: bool = True) -> Dict:
         wavs, texts, wav_percents, text_percents, langs = batch[0], batch[1], batch[2], batch[3], batch[5]
         lang_id = getattr(wavs, "lang_id", None)                          # host-side metadata: no device sync
-        lang = self.index2lang_dict[int(langs[0]) if lang_id is None else lang_id]   # single-language batches (Q7)
+        lang = self.index2lang_dict[int(getattr(langs, "_host", langs)[0]) if lang_id is None else lang_id]   # single-language batches (Q7)
         out, _ = self.model(wavs, self.sr, lang)
         out = out[lang]
         in_len = (out.shape[1] * wav_percents).long()
