@@ -101,7 +101,8 @@ class LidModule(CCMLModule):
         normalisation, and in training wav_augment's dither + pre-emphasis), for the whole batch on the GPU."""
         lens = [int(w.shape[-1]) for w in wavs]
         x = torch.nn.utils.rnn.pad_sequence([w.reshape(-1).float() for w in wavs], batch_first=True).contiguous()
-        ns = torch.tensor(lens, dtype=torch.int32, device=x.device) if min(lens) != max(lens) else None
+        # (through pinned staging: torch.tensor(lens, device=cuda) blocks the host until the stream has drained - one sync per step)
+        ns = _ops.upload_async(lens, torch.int32, x.device, "prepare_wavs.ns") if min(lens) != max(lens) else None
         x = _ops.normalize_wav(x, n_samples=ns)
         if train:
             y = _ops.dither_preemph(x, coef=0.97, dither=1e-5, seed=int(torch.randint(0, 2 ** 31 - 1, (1,))))

@@ -44,6 +44,35 @@ def _code(t):
     return dtype_code(t.dtype)
 
 
+# ----------------------------------------------------------------------------------------------- small host -> device uploads
+_STAGE = {}
+
+
+def upload_async(values, dtype, device, key):
+    """A small host list / array (per-utterance lengths, table indices) -> a new device tensor WITHOUT stalling the host:
+    torch.tensor(list, device=cuda) copies from pageable memory, which blocks until everything queued on the stream has drained
+    (one full host-device sync per call: 20 ms per step on ragged wav2vec2 batches).  Here the values go through one of two pinned
+    staging buffers per ``key``; a buffer is reused two calls later, after its copy's event has passed."""
+    src = torch.as_tensor(values, dtype=dtype).reshape(-1)
+    n = src.numel()
+    k = (key, str(device), dtype)
+    st = _STAGE.get(k)
+    if st is None or st["cap"] < n:
+        cap = max(64, 1 << max(n - 1, 1).bit_length())
+        st = _STAGE[k] = dict(cap=cap, bufs=[torch.empty(cap, dtype=dtype).pin_memory() for _ in range(2)], events=[None, None], turn=0)
+    i = st["turn"]
+    st["turn"] = 1 - i
+    if st["events"][i] is not None:
+        st["events"][i].synchronize()
+    st["bufs"][i][:n].copy_(src)
+    out = torch.empty(n, dtype=dtype, device=device)
+    out.copy_(st["bufs"][i][:n], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    st["events"][i] = ev
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- features
 _TABLES = {}
 
@@ -151,9 +180,10 @@ def speed_perturb(wav, factors, n_samples=None):
             _RESAMPLE[key] = (torch.from_numpy(taps.astype(np.float32)).contiguous().to(dev), left)
         t, left = _RESAMPLE[key]
         recs.append([t.data_ptr(), (p & 0xFFFFFFFF) | (q << 32), (t.shape[1] & 0xFFFFFFFF) | (left << 32)])
-    tables = torch.tensor(recs, dtype=torch.int64, device=dev)          # {ptr; int p, q; int ntaps, left} = 24 bytes per record
-    table_of = torch.tensor([uniq.index(f) for f in factors], dtype=torch.int32, device=dev)
-    n_out = torch.tensor(out_lens, dtype=torch.int32, device=dev)
+    # {ptr; int p, q; int ntaps, left} = 24 bytes per record; all three through pinned staging (no host stall per augmented batch)
+    tables = upload_async(recs, torch.int64, dev, "speed.tables").view(len(recs), 3)
+    table_of = upload_async([uniq.index(f) for f in factors], torch.int32, dev, "speed.table_of")
+    n_out = upload_async(out_lens, torch.int32, dev, "speed.n_out")
     out = torch.empty(B, Lout, device=dev, dtype=torch.float32)
     check(lib().lidk_speed_perturb(_p(wav), B, Lin, _p(n_samples), _p(out), Lout, _p(n_out), _p(tables), len(uniq), _p(table_of),
                                    _stream()), "speed_perturb")
