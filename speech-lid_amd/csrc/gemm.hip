@@ -995,16 +995,17 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
         return launch_status();
       }
     }
-    // LDS-DMA 128x128 kernel: opt-in, K >= LIDK_GEMM_DMA (e.g. 512; default 0 = never), N % 128 == 0, >= 384 tiles.  Faster per launch
-    // on the backbones' big-K shapes (below) but NOT end to end: WavLM frozen / fine-tune 25.05 / 31.65 ms per step with it against
-    // 24.68 / 31.30 without, wav2vec2 on 1-10 s batches 49.2 / 48.8 against 48.2 / 48.7 (two 64 KB workgroups per CU leave the
-    // weight-gradient stream less room beside it), so it stays off.  LIDK_GEMM_DMA_TILES lowers the tile-count floor (default 384): with
-    // it at 100 the cfg2 data gradients of K >= 512 (152 tiles of 128 x 128) take this kernel and the step goes 7.16 -> 7.68 ms.
-    const char* dma_env = getenv("LIDK_GEMM_DMA");                 // read per call (a test flips it inside one process)
-    const int dma_min_k = dma_env ? atoi(dma_env) : 0;
-    // Measured against the 64x64 / register-staged 128x128 kernels on the backbone shapes (tools/gemm_bench_wavlm.py): K = 3072
+    // LDS-DMA 128x128 kernel: K >= LIDK_GEMM_DMA (default 1024; 0 = never), N % 128 == 0, >= LIDK_GEMM_DMA_TILES tiles (default 384).
+    // Per launch against the 64x64 / register-staged 128x128 kernels on the backbone shapes (tools/gemm_bench_wavlm.py): K = 3072
     // +36 % (798 TFLOP/s), conv stack K = 1536 +7...20 %, K = 768 single output +0...7 %; it LOSES with the two-output GELU
     // epilogue at K = 768 (store-bound) and when the tile count leaves a mostly empty second round (512 < tiles < 1024).
+    // End to end (tools/gpu_ab_finetune.sh, 3 alternating rounds of 60 steps, spread +-0.05 ms once the per-step host syncs of the
+    // backbone modules were gone - the A/B runs before that were noise): WavLM fine-tune 26.79 (off) / 26.76 (K >= 512) / 26.42
+    // (K >= 2048) / 26.12 (K >= 1024) ms per step; frozen regime 21.21 (off) / 20.64 (2048) / 20.38 (1536) / 20.38 (1024).  The
+    // cfg2 Conformer has no such shape (its K >= 1024 data gradients have 152 tiles: with the tile floor at 100 the step goes
+    // 7.16 -> 7.28 ms (K >= 1024) / 7.68 (K >= 512)).
+    const char* dma_env = getenv("LIDK_GEMM_DMA");                 // read per call (a test flips it inside one process)
+    const int dma_min_k = dma_env ? atoi(dma_env) : 1024;
     const long dma_tiles = (long)cdiv(g->M, 128) * (g->N / 128);
     const char* dma_tiles_env = getenv("LIDK_GEMM_DMA_TILES");
     const long dma_min_tiles = dma_tiles_env ? atol(dma_tiles_env) : 384;

@@ -145,7 +145,8 @@ class WavLMMutiLangModel(_EngineBoundModel):
             raise LidkError("WavLMMutiLangModel.forward: waveforms must be on the GPU (no CPU fallback)")
         grad_path = self.training and torch.is_grad_enabled() and lang is not None
         if self._bb_stale:
-            self.backbone.refresh()
+            params = dict(self.named_parameters())
+            self.backbone.refresh(changed=[n for n in self._bb_names if params[self.BB_PREFIX + n].requires_grad])
             self._bb_stale = False
         self._bb_shape = tuple(wav.shape)
         mix_w = self._mix_w()

@@ -243,6 +243,60 @@ class WavLMBackbone:
             self.graphs.clear()
         self._prepared = True
 
+    def _refresh_inplace(self):
+        """The operands of _prepare written straight into the existing buffers (same addresses: captured graphs and views stay
+        valid): one converting / transposing copy per operand instead of build-new + copy-over.  1-D parameters (biases, LayerNorm
+        weights, mask_emb) ARE the parameter tensors when those already live on the device, so they need nothing."""
+        p, W, bf = self.params, self.W, torch.bfloat16
+        fe = "feature_extractor.conv_layers."
+
+        def alias(dst, name):                                  # f32 operand kept as a copy only if _prepare had to make one
+            if dst.data_ptr() != p[name].data_ptr():
+                dst.copy_(p[name].reshape(dst.shape), non_blocking=True)
+
+        alias(W["conv0_w"], fe + "0.0.weight"); alias(W["gn_w"], fe + "0.2.weight"); alias(W["gn_b"], fe + "0.2.bias")
+        for i in range(1, len(self.layers_spec)):
+            w = p[f"{fe}{i}.0.weight"]                                           # [Co][Ci][kW] -> [Co][kW][Ci]
+            W["conv"][i - 1].view(w.shape[0], w.shape[2], w.shape[1]).copy_(w.permute(0, 2, 1))
+            W["convT"][i - 1].copy_(W["conv"][i - 1].t())
+        alias(W["ln0_w"], "layer_norm.weight"); alias(W["ln0_b"], "layer_norm.bias")
+        W["proj_w"].copy_(p["post_extract_proj.weight"]); alias(W["proj_b"], "post_extract_proj.bias")
+        W["proj_wT"].copy_(W["proj_w"].t())
+        w = torch._weight_norm(p["encoder.pos_conv.0.weight_v"], p["encoder.pos_conv.0.weight_g"], 2)
+        cg = self.d // self.gpos
+        for i in range(self.gpos):
+            blk = w[i * cg:(i + 1) * cg]                                           # [cg][cg][k]
+            W["pos_w"][i].view(cg, blk.shape[2], cg).copy_(blk.permute(0, 2, 1))
+            W["pos_wd"][i].view(cg, blk.shape[2], cg).copy_(blk.flip(2).permute(1, 2, 0))
+        alias(W["pos_b"], "encoder.pos_conv.0.bias")
+        alias(W["enc_ln_w"], "encoder.layer_norm.weight"); alias(W["enc_ln_b"], "encoder.layer_norm.bias")
+        if self.rel_pos:
+            emb = p["encoder.layers.0.self_attn.relative_attention_bias.weight"]
+            W["rb"].copy_(emb[W["rb_bucket"]].t())
+        alias(W["mask_emb"], "mask_emb")
+        d = self.d
+        for i, Lw_ in enumerate(W["layers"]):
+            q = f"encoder.layers.{i}."
+            a = q + "self_attn."
+            for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                Lw_["wqkv"][j * d:(j + 1) * d].copy_(p[a + n + ".weight"])
+                Lw_["bqkv"][j * d:(j + 1) * d].copy_(p[a + n + ".bias"])
+            Lw_["wo"].copy_(p[a + "out_proj.weight"]); alias(Lw_["bo"], a + "out_proj.bias")
+            if self.rel_pos:
+                alias(Lw_["wg"], a + "grep_linear.weight"); alias(Lw_["bg"], a + "grep_linear.bias"); alias(Lw_["grep_a"], a + "grep_a")
+            alias(Lw_["ln1_w"], q + "self_attn_layer_norm.weight"); alias(Lw_["ln1_b"], q + "self_attn_layer_norm.bias")
+            Lw_["w1"].copy_(p[q + "fc1.weight"]); alias(Lw_["b1"], q + "fc1.bias")
+            Lw_["w2"].copy_(p[q + "fc2.weight"]); alias(Lw_["b2"], q + "fc2.bias")
+            alias(Lw_["ln2_w"], q + "final_layer_norm.weight"); alias(Lw_["ln2_b"], q + "final_layer_norm.bias")
+            for n in ("wqkv", "wo", "w1", "w2"):
+                Lw_[n + "T"].copy_(Lw_[n].t())
+        self._prepared = True
+
+    @property
+    def _inplace_ok(self) -> bool:
+        """All parameters already live on the kernels' device (the in-place refresh reads them where they are)."""
+        return all(t.device == self.device for t in self.params.values())
+
     # ------------------------------------------------------------------ geometry
     def frame_counts(self, n_samples: int) -> List[int]:
         t, out = n_samples, []
@@ -770,8 +824,17 @@ class WavLMBackbone:
         self.grads["encoder.pos_conv.0.weight_g"] += dot / norm
         self.grads["encoder.pos_conv.0.weight_v"] += gg / norm * (dw - v * dot / norm.pow(2))
 
-    def refresh(self):
-        """Re-derive the bf16 operands after the optimizer changed the (encoder) parameters (in place)."""
+    def refresh(self, changed=None):
+        """Re-derive the kernels' operands after the optimizer changed parameters (in place).  ``changed``: names of the backbone
+        parameters that take gradients; when they are only the input LayerNorm and ``mask_emb`` (the frozen regime: everything else
+        is unchanged) just those three operands are refreshed - a full re-derivation re-casts / transposes / concatenates ~95 M
+        parameters and costs ~290 device copies, ~3 ms of GPU time and as much host time per step for nothing."""
+        W = getattr(self, "W", None)
+        if changed is not None and self._prepared and W is not None and set(changed) <= set(self.INPUT_SIDE):
+            for key, name in (("ln0_w", "layer_norm.weight"), ("ln0_b", "layer_norm.bias"), ("mask_emb", "mask_emb")):
+                if name in changed:
+                    W[key].copy_(self.params[name], non_blocking=True)
+            return
         self._prepared = False
 
     # ------------------------------------------------------------------ forward
@@ -787,7 +850,10 @@ class WavLMBackbone:
         if not wav.is_cuda or wav.dtype != torch.float32:
             raise LidkError("WavLMBackbone.forward needs a float32 GPU tensor (B, L)")
         if not self._prepared:
-            self._prepare()
+            if getattr(self, "W", None) is not None and self._inplace_ok:
+                self._refresh_inplace()
+            else:
+                self._prepare()
         wav = wav.contiguous()
         B, Lw = wav.shape
         ws = self._workspace(B, Lw)

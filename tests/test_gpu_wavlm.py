@@ -121,6 +121,54 @@ def test_backbone_forward_stages_against_the_reference():
     assert out2.shape == (1, 37, 768) and bool(torch.isfinite(out2).all())
 
 
+@pytest.mark.parametrize("rel_pos", [True, False])
+def test_operand_refresh_in_place_equals_a_fresh_derivation(rel_pos):
+    """After an optimizer step the kernels' operands (bf16 casts, transposes, the folded weight-norm, QKV concatenations, the bias
+    table) are rewritten in place (WavLMBackbone._refresh_inplace) - or, when only the input LayerNorm / mask_emb train, just those
+    (refresh(changed=...)): both must give exactly what a from-scratch _prepare derives from the same parameters."""
+    def flat(t, pre=""):
+        if isinstance(t, dict):
+            return {k2: v2 for k, v in t.items() for k2, v2 in flat(v, f"{pre}{k}.").items()}
+        if isinstance(t, list):
+            return {k2: v2 for i, v in enumerate(t) for k2, v2 in flat(v, f"{pre}{i}.").items()}
+        return {pre: t}
+    cfg = dict(wc.CFG) if rel_pos else dict(wc.W2V_CFG)          # WavLM (gated relative bias) / the wav2vec2 encoder
+    bb = WavLMBackbone(cfg)
+    # parameters on the device and shared, as WavLMMutiLangModel hands them over (its nn.Parameters)
+    bb.load_state_dict({k: v.to(DEV) for k, v in wc.backbone_weights(cfg["encoder_layers"], rel_pos=rel_pos).items()}, share=True)
+    bb.to(DEV)
+    wav = wc.waveforms().to(DEV)
+    bb.forward(wav)
+    assert bb._inplace_ok
+    before = {k: v.data_ptr() for k, v in flat(bb.W).items()}
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    with torch.no_grad():
+        for t in bb.params.values():
+            t.add_(0.02 * torch.randn(t.shape, device=DEV, generator=gen) * (t.abs().mean() + 1e-3))
+    bb.refresh()                                         # everything may have changed: the in-place path on the next forward
+    out_inplace = bb.forward(wav).clone()
+    got = {k: v.clone() for k, v in flat(bb.W).items()}
+    assert {k: v.data_ptr() for k, v in flat(bb.W).items()} == before, "operands moved: captured graphs would read stale memory"
+    bb.W, bb._prepared = None, False                     # from scratch
+    out_fresh = bb.forward(wav)
+    fresh = flat(bb.W)
+    assert got.keys() == fresh.keys()
+    for k in got:
+        assert torch.equal(got[k], fresh[k]), k
+    assert torch.equal(out_inplace, out_fresh)
+    # only the input LayerNorm / mask_emb changed: the partial refresh
+    with torch.no_grad():
+        for n in bb.INPUT_SIDE:
+            bb.params[n].mul_(1.05)
+    bb.refresh(changed=list(bb.INPUT_SIDE))
+    assert bb._prepared
+    part = {k: v.clone() for k, v in flat(bb.W).items()}
+    bb.W, bb._prepared = None, False
+    bb.forward(wav)
+    for k, v in flat(bb.W).items():
+        assert torch.equal(part[k], v), k
+
+
 def _model(dt=torch.bfloat16, dropout=0.0, cfg=wc.CFG, mask=False, **kw):
     from lid.WavLMMutiLangModel import WavLMMutiLangModel
     m = WavLMMutiLangModel(dropout=dropout, linear_dim=768, mask=mask, **kw, lang2vocab=wc.L2V, lang2index=wc.L2I,
