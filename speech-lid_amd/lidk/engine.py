@@ -1077,6 +1077,7 @@ class Engine:
             # the last block's weight gradients - as one captured sequence per (workspace, language)
             def bwd_all():
                 prv = None
+                self._after_first = None              # (a capture that raised half-way must not leave its callback behind)
                 fuse_ok = defer and self._ln2_ok()
                 post_done = False
                 for n, (kind, tag, bpk, bbk, x_in, stage) in enumerate(blocks):
