@@ -245,7 +245,8 @@ _WGRAD_WGS = int(__import__("os").environ.get("LIDK_WGRAD_WGS", "512"))      # w
 # Grouped weight-gradient launch: output tile and row chunks per weight gradient.  Measured end to end at cfg2 (same box, two rounds
 # each, ms per step): 64-tiles x 4 chunks 7.73 (x 8: 7.86); 128-tiles x 1 / 2 / 3 / 4 / 6 / 8 chunks 7.93 / 7.45 / 7.61 / 7.57 /
 # 7.70 / 7.70 - twice the MFMA work per operand byte fetched from L2 (the 64-tiles pull ~1 GB through L2 per launch) and ~190
-# long items instead of ~1 700 short ones beside the data-gradient chain.
+# long items instead of ~1 700 short ones beside the data-gradient chain.  With the LDS-DMA ring (csrc/gemm.hip) the split no longer matters:
+# 128-tiles x 2 / 3 / 4 chunks 7.17 / 7.16 / 7.20 (two rounds, same box).
 # Whole-chain backward capture: record the fork point before a block's data-gradient chain but capture the forked weight-gradient work
 # AFTER it (same dependencies).  The chain's first kernel is then the first child of the previous block's last kernel in the
 # hipGraph and the chain stays on one hardware queue (before: the last LayerNorm backward of every block ran on the side queue,
