@@ -807,7 +807,8 @@ class Engine:
             rows = self.k.ffn_bwd_partial_rows(M)
             # LIDK_FFN_LN_PAIR=1: both LayerNorm backwards of the block boundary in the kernel's epilogue (lidk_ffn_bwd_ln2).  Correct
             # (tests/test_gpu_ffn.py) but measured slower end to end - 7.44 / 7.44 vs 7.38 / 7.38 ms per step: the long epilogue of 151
-            # lock-step workgroups costs more than the 11 us streaming launch it removes - so the dh form + lidk_layernorm2_bwd stay.
+            # lock-step workgroups costs more than the 11 us streaming launch it removes - so the dh form + lidk_layernorm2_bwd stay
+            # (re-measured under the late-fork schedule: 7.19 / 7.19 vs 7.14 / 7.16).
             pair_fused = fuse is not None and _os_env("LIDK_FFN_LN_PAIR", "0") == "1"
             lnp_rows[id(lnp)] = rows if (fuse is None or pair_fused) else 0
             if pair_fused:
