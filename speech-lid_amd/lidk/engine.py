@@ -767,15 +767,15 @@ class Engine:
 
     def _dgrad_ln_bwd(self, w: _Work, dy, WT, K: int, x, mean, rstd, P, lnp, wg: bool, dres, dx, dxT, dxT_scale):
         """Data gradient of the projection behind a PreNorm (N = d) followed by that LayerNorm's backward: lidk_gemm_nt +
-        lidk_layernorm_bwd through w.dh, or (LIDK_DGRAD_LN=1) the one-launch form lidk_dgrad_ln_bwd (csrc/ffn.hip).  The fused form is
-        correct (tests/test_gpu_ffn.py) but measured no faster end to end - 7.43-7.46 vs 7.34-7.43 ms per step, same box, two rounds:
-        151 row-panel workgroups do not beat a 604-workgroup GEMM plus a streaming pass when only one intermediate ([M, 256] bf16)
-        is saved - so it is off by default and kept for the record."""
+        lidk_layernorm_bwd through w.dh (LIDK_DGRAD_LN=0), or the one-launch form lidk_dgrad_ln_bwd (csrc/ffn.hip; default).  Before
+        the data-gradient chain stayed on one hardware queue (late fork) the fused form measured no faster - 7.43-7.46 vs 7.34-7.43
+        ms per step: 151 row-panel workgroups against a 604-workgroup GEMM plus a streaming pass.  Under the late-fork schedule, with
+        the chain as the critical path, one launch fewer per site pays: 6.96 / 7.06 against 7.04 / 7.12 (same box, two rounds)."""
         M, d = w.M, self.cfg.d
         key = ("dln", M, K)
         ok = self._split_ok.get(key)
         if ok is None:
-            ok = self._split_ok[key] = bool(self._hip and hasattr(self.k, "dgrad_ln_bwd") and _os_env("LIDK_DGRAD_LN", "0") == "1"
+            ok = self._split_ok[key] = bool(self._hip and hasattr(self.k, "dgrad_ln_bwd") and _os_env("LIDK_DGRAD_LN", "1") == "1"
                                             and WT.stride(0) == K and self.k.dgrad_ln_bwd_supported(M, d, K, self.act_dtype)
                                             and self.k.ffn_bwd_partial_rows(M) <= L.LN_BWD_BLOCKS)
         lnp_rows = w.__dict__.setdefault("_lnp_rows", {})
@@ -932,10 +932,11 @@ class Engine:
         if post_norm:
             sites.append((0, dict(dln_w=bp.post["dw"], dln_b=bp.post["db"])))
         lnp_rows = w.__dict__.get("_lnp_rows", {})
-        # LIDK_LN_GROUPED=1: the block's five finalisers as one launch.  Measured SLOWER end to end (7.78-7.84 vs 7.68-7.69 ms per
-        # step, same box, two rounds): the weight-gradient stream then reaches its big grouped GEMM earlier and takes more of the
-        # chip from the data-gradient chain at the start of the block.  Off by default, kept for the record.
-        if hasattr(self.k, "layernorm_param_grads_grouped") and _os_env("LIDK_LN_GROUPED", "0") == "1":
+        # The block's five finalisers as one launch (LIDK_LN_GROUPED=0: five launches).  With the register-staged weight gradients
+        # this measured SLOWER (7.78-7.84 vs 7.68-7.69 ms per step: the weight-gradient stream reached its big grouped GEMM earlier
+        # and took more of the chip from the data-gradient chain at the start of the block); with the LDS-DMA weight gradients and
+        # the late fork it is the faster form: 7.00 / 7.08 against 7.07 / 7.15 (same box, two rounds).
+        if hasattr(self.k, "layernorm_param_grads_grouped") and _os_env("LIDK_LN_GROUPED", "1") == "1":
             rows_of = [lnp_rows.get(id(S.lnp[i]), 0) or self.k.layernorm_bwd_partial_rows(M) for i, _ in sites]
             cache = w.__dict__.setdefault("_ln_groups", {})
             key = (id(bp), id(S), post_norm, tuple(rows_of))
