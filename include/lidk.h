@@ -433,7 +433,7 @@ int lidk_wavlm_attn_bias_grads(const void* ds, const float* gate, const float* r
 /* ------------------------------------------------------------------ backward of the conv feature extractor
  * (lid/wavlm/WavLM.py:409-531, un-frozen by lid/WavLMMutiLangModel.py:86-94).  Layers 1-6 are the forward's strided-view GEMMs
  * run backwards (lidk_gemm_tn / lidk_gemm_nt) plus these layout kernels; layer 0 is recomputed from the waveform.
- *   conv_dlast : dpre [B*P][C] bf16 = dsrc [B*T][C] f32 * gelu'(pre) for t < T, zero in the pitch padding rows
+ *   conv_dlast : dpre [B*P][C] bf16 = dsrc [B*T][C] f32 * gelu'(pre) for t < T (pre NULL: no factor), zero in the pitch padding rows
  *   conv_col2im: dprev [B*2P][C] bf16, row (b, t < Tprev) = (window terms of dcol [B*P][kW*C] bf16 that touch input row t:
  *                k2 s2 one term, k3 s2 two on even rows) * gelu'(pre [B*2P][C]) (pre NULL: no factor), zero for t >= Tprev
  *   conv0_bwd  : dy0 [B*P0][C] bf16 at layer 0's output, stats [B][C][2] (mean, rstd) from lidk_wavlm_conv0's workspace
@@ -443,6 +443,32 @@ int lidk_wavlm_conv_col2im(const void* dcol, const void* pre, void* dprev, int B
                            void* stream);
 int lidk_wavlm_conv0_bwd(const float* wav, int B, int L, const float* w, const float* gamma, const float* beta, const float* stats,
                          const void* dy0, float* sums, float* dw, float* dgamma, float* dbeta, int T0, int P0, int C, void* stream);
+
+/* ------------------------------------------------------------------ wav2vec2 Large / XLS-R and WavLM Large: the "layer_norm" feature
+ * extractor and waveform normalisation (the checkpoints the reference's wav2vec confs load: lid/conf/xf_asr_wav2vec.yaml:12,
+ * lid/conf/xf_asr_extra_finetune.yaml:12).
+ * lidk_wav_layernorm: task.normalize, F.layer_norm(wav, wav.shape) per utterance (lid/s3prl_updream/wav2vec/wav2vec2_expert.py:71-72):
+ *   (x - mean) / sqrt(var_biased + eps) over the utterance's own n_samples[b] samples (NULL: all L), zeros behind them.
+ * ConvFeatureExtractionModel(mode="layer_norm", conv_bias) (lid/wavlm/WavLM.py:415-477 = wav2vec2.py:769-848): every layer is
+ * Conv1d(+bias) -> LayerNorm over the C channels of a time step -> GELU.  Channel-last activations make that a row LayerNorm:
+ *   lidk_conv0_ln_fwd : layer 0 (k10 s5 on the raw waveform) with its LayerNorm + GELU, wav [B][L] f32 -> out [B*P0][C] bf16
+ *                       (rows T0..P0-1 of an utterance zero); bias may be NULL (conv_bias=False).  C = 512.
+ *   lidk_ln_gelu_fwd  : layers 1..: out = gelu(LayerNorm(pre)) on rows of C = 512 (pre = lidk_gemm_nt over the strided view, bias in
+ *                       its epilogue); pre / out [rows][C] of `dtype`.
+ *   lidk_ln_gelu_bwd  : dy at the GELU output -> dpre (rows t >= Tv of each utterance's P rows: zero); dgamma / dbeta ACCUMULATED.
+ *   lidk_conv0_ln_bwd : layer 0 backward, recomputed from the waveform; dw [C][10], dbias [C] (NULL without conv bias), dgamma,
+ *                       dbeta ACCUMULATED.
+ * LIDK_ERR_UNSUPPORTED for C != 512. */
+int lidk_wav_layernorm(const float* wav, float* out, int B, int L, const int32_t* n_samples, float eps, void* stream);
+int lidk_conv0_ln_fwd(const float* wav, int B, int L, const float* w, const float* bias, const float* gamma, const float* beta,
+                      float eps, void* out, int T0, int P0, int C, void* stream);
+int lidk_ln_gelu_fwd(const void* pre, const float* gamma, const float* beta, void* out, long rows, int C, float eps, int dtype,
+                     void* stream);
+int lidk_ln_gelu_bwd(const void* dy, const void* pre, const float* gamma, const float* beta, void* dpre, float* dgamma, float* dbeta,
+                     int B, int P, int Tv, int C, float eps, int dtype, void* stream);
+int lidk_conv0_ln_bwd(const float* wav, int B, int L, const float* w, const float* bias, const float* gamma, const float* beta,
+                      float eps, const void* dy0, float* dw, float* dbias, float* dgamma, float* dbeta, int T0, int P0, int C,
+                      void* stream);
 
 /* ------------------------------------------------------------------ wav2vec2 pieces
  * lidk_zero_padded_rows: x [B][T][C] f32, rows t >= klen[b] become zero - TransformerEncoder.extract_features zeroes padded frames

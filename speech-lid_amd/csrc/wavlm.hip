@@ -838,12 +838,12 @@ __global__ void wavlm_conv_dlast_kernel(const float* __restrict__ dsrc, const bf
     const long row = i / C;
     const int b = (int)(row / P), t = (int)(row % P);
     float v = 0.f;
-    if (t < T_) v = dsrc[((size_t)b * T_ + t) * C + c] * gelu_grad_((float)pre[i]);
+    if (t < T_) v = dsrc[((size_t)b * T_ + t) * C + c] * (pre ? gelu_grad_((float)pre[i]) : 1.0f);
     dpre[i] = (bf16)v;
   }
 }
 extern "C" int lidk_wavlm_conv_dlast(const float* dsrc, const void* pre, void* dpre, int B, int T_, int P, int C, void* stream) {
-  if (!dsrc || !pre || !dpre || B <= 0 || T_ <= 0 || P < T_ || C <= 0) return LIDK_ERR_ARG;
+  if (!dsrc || !dpre || B <= 0 || T_ <= 0 || P < T_ || C <= 0) return LIDK_ERR_ARG;
   const long n = (long)B * P * C;
   int blocks = (int)((n + 255) / 256); if (blocks > 16384) blocks = 16384;
   wavlm_conv_dlast_kernel<<<blocks, 256, 0, as_stream(stream)>>>(dsrc, (const bf16*)pre, (bf16*)dpre, B, T_, P, C);

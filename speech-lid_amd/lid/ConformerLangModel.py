@@ -169,7 +169,8 @@ class _EngineBoundModel(nn.Module):
         for tid in eng.active_tensor_ids(lang, keep):
             s = eng.specs[tid]
             mod, leaf = self._owner[s.name]
-            mod._parameters[leaf].grad = eng.gview(s.name)
+            if mod._parameters[leaf].requires_grad:             # a frozen head (keep_last_lang_model_train): .grad stays None
+                mod._parameters[leaf].grad = eng.gview(s.name)
 
     def lang_discriminator_forward(self, logits: Dict[str, torch.Tensor]):
         """LangDiscriminator.forward (lid/ConformerLangModel.py:383-395): per-language CTC-path confidence, then the MLP."""

@@ -71,11 +71,8 @@ class LidModule(CCMLModule):
     # ------------------------------------------------------------------ optimizer / schedule (reference :140-176)
     def config_optim(self, *args, **kwargs):
         # all parameters, like the reference (:140-150): frozen ones carry no gradient, so the optimizer skips them (and
-        # allocates no state) until freeze_tranformer_epoch has passed; the never-trained conv extractor is left out
-        pre = self.model.BB_PREFIX
-        never = {id(p) for n, p in self.model.named_parameters()
-                 if n.startswith((pre + "feature_extractor.", pre + "post_extract_proj."))}
-        params = [p for p in self.model.parameters() if id(p) not in never]
+        # allocates no state) until freeze_tranformer_epoch / freeze_encoder_epoch have passed
+        params = list(self.model.parameters())
         name = self.optimizer_name
         if name == "sgd":
             optimizer = torch.optim.SGD(params, **self.optimizer_param)

@@ -21,9 +21,12 @@ of such a state dict (quantizer, project_q, final_proj) are carried but unused.
 
 Parity: the transformer arithmetic is pinned through the reference's own lid/wavlm/WavLM.py encoder with the relative-position
 bias off and a padding mask on (tests/golden/w2v2_*.npz); what lives only in the un-vendored fairseq (its compute_mask_indices
-draw order, MultiheadAttention internals) is restated and UNPINNED.  Built: extractor_mode=default,
-conv_bias=False, layer_norm_first=False, normalize=False (wav2vec2 Base); the Large / XLSR variant (layer-norm extractor,
-pre-LN layers, waveform normalisation) raises."""
+draw order, MultiheadAttention internals) is restated and UNPINNED.  Built: wav2vec2 Base (extractor_mode=default,
+conv_bias=False, layer_norm_first=False, normalize=False) and the Large / XLS-R variant every wav2vec conf of the reference loads
+(lid/conf/xf_asr_wav2vec.yaml:12 ``xlsr2_300m.pt``: extractor_mode=layer_norm with conv bias, layer_norm_first, ``task.normalize``
+= per-utterance layer-norm of the waveform, d = 1024 / 16 heads / ffn 4096 / 24 layers), pinned by tests/golden/xlsr_step.npz - a
+run of the reference's own lid/wavlm/WavLM.py classes with those flags (oracle/gen_golden_xlsr.py).  ``normalize`` is read from
+the checkpoint cfg, flat (``cfg["normalize"]``) or in fairseq's nesting (``cfg["task"]["normalize"]`` beside ``cfg["model"]``)."""
 from typing import Dict, Optional
 
 import torch
@@ -36,6 +39,7 @@ from lid.WavLMMutiLangModel import WavLMMutiLangModel
 class Wav2vecMutiLangModel(WavLMMutiLangModel):
     BB_PREFIX = "model.featurizer.upstream.model."
     MIX_NAME = "model.featurizer.weights"
+    APPLY_NORMALIZE = True
 
     def __init__(self, pt_path: str = None, feature_selection: str = "hidden_states", dropout: float = 0.0, linear_dim: int = 768,
                  mask: bool = True, num_layers: int = 1, lang2vocab: Dict = None, lang2index: Dict = None, hidden_dim: int = 128,
@@ -51,8 +55,9 @@ class Wav2vecMutiLangModel(WavLMMutiLangModel):
             cfg, weights = dict(wav2vec_cfg), None
         else:
             raise ValueError("Wav2vecMutiLangModel needs pt_path or wav2vec_cfg")
-        if cfg.get("normalize", False):
-            raise NotImplementedError("wav2vec2 with task.normalize (Large / XLSR: per-utterance layer_norm of the waveform) is not built")
+        if isinstance(cfg.get("model"), dict):             # the nested fairseq form {"model": {...}, "task": {"normalize": ...}}
+            task = cfg.get("task") or {}
+            cfg = dict(cfg["model"], normalize=bool(task.get("normalize", cfg["model"].get("normalize", False))))
         if cfg.get("relative_position_embedding", False) or cfg.get("gru_rel_pos", False):
             raise ValueError("a wav2vec2 config has no relative position embedding")
         cfg["encoder_padding_mask"] = True

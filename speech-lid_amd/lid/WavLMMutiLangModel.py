@@ -34,6 +34,7 @@ from lidk._lib import LidkError
 class WavLMMutiLangModel(_EngineBoundModel):
     BB_PREFIX = "model.featurizer.model."         # where the backbone's parameters sit in the reference state_dict
     MIX_NAME = None                               # wav2vec2: the s3prl Featurizer's layer-mixing logits
+    APPLY_NORMALIZE = False                       # whether the checkpoint cfg's ``normalize`` is applied to the waveforms
 
     def __init__(self, pt_path: str = None, feature_selection: str = "hidden_states", dropout: float = 0.0, linear_dim: int = 768,
                  mask: bool = True, num_layers: int = 1, lang2vocab: Dict = None, lang2index: Dict = None, hidden_dim: int = 128,
@@ -53,6 +54,10 @@ class WavLMMutiLangModel(_EngineBoundModel):
             cfg, weights = dict(wavlm_cfg), _weights
         else:
             raise ValueError("WavLMMutiLangModel needs pt_path (a WavLM checkpoint with 'cfg' and 'model') or wavlm_cfg")
+        # WavLMModel.forward (lid/WavLMMutiLangModel.py:160-182) hands the raw padded batch to WavLM.extract_features: the
+        # checkpoint's ``normalize`` flag (WavLM Large: True) is never acted on by the reference, so it is not here either;
+        # the wav2vec2 wrapper (s3prl UpstreamExpert, wav2vec2_expert.py:71-72) does normalise.
+        cfg["normalize"] = bool(cfg.get("normalize", False)) and self.APPLY_NORMALIZE
         cfg["mask_prob"] = mask_prob if mask else 0.0
         cfg["mask_channel_prob"] = mask_channel_prob if mask else 0.0
         self.backbone = WavLMBackbone(cfg)
@@ -96,7 +101,7 @@ class WavLMMutiLangModel(_EngineBoundModel):
         g = torch.Generator().manual_seed(0)
         out = {}
         for name, shape in shapes.items():
-            if name.endswith(("norm.weight", "conv_layers.0.2.weight", "grep_a", "weight_g")):
+            if name.endswith(("norm.weight", "conv_layers.0.2.weight", ".2.1.weight", "grep_a", "weight_g")):
                 out[name] = torch.ones(shape)
             elif len(shape) >= 2:
                 fan_in = 1
@@ -247,7 +252,17 @@ class WavLMMutiLangModel(_EngineBoundModel):
         self._bb_stale = True                                      # an optimizer step follows
 
     def keep_last_lang_model_train(self, lang):
-        raise NotImplementedError("keep_train_lang (freezing all heads but one) is not built")
+        """lid/WavLMMutiLangModel.py:114-123 (``module.keep_train_lang``, lid/conf/xf_asr_extra_finetune.yaml:43): every head
+        but ``lang``'s stops training.  A batch of a frozen language still runs through its head and back-propagates into
+        the backbone; the head's own parameters get no ``.grad`` (``_publish_grads`` leaves them out), so the optimizer skips them
+        and allocates no state for them - what ``requires_grad = False`` does in the reference."""
+        for item_lang in self.cfg.lang2vocab:
+            if item_lang == lang:
+                continue
+            logging.info(f"freeze lang model: {item_lang}")
+            for p in self.model.last_projects[item_lang].parameters():
+                p.requires_grad = False
+                p.grad = None
 
     def reset_param(self):
         logging.info("reset parameters...")

@@ -102,6 +102,11 @@ SIGNATURES = {
     "lidk_ctc_workspace_bytes": (_L, [_I, _I, _I, _I]),
     "lidk_ctc_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "lidk_lid_score": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "lidk_wav_layernorm": (_I, [_P, _P, _I, _I, _P, _F, _P]),
+    "lidk_conv0_ln_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _F, _P, _I, _I, _I, _P]),
+    "lidk_ln_gelu_fwd": (_I, [_P, _P, _P, _P, _L, _I, _F, _I, _P]),
+    "lidk_ln_gelu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "lidk_conv0_ln_bwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_wavlm_conv0_workspace": (_L, [_I, _I, _I]),
     "lidk_wavlm_conv0": (_I, [_P, _I, _I, _P, _P, _P, _F, _P, _I, _I, _I, _P, _P]),
     "lidk_wavlm_posconv_prep": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _L, _P]),

@@ -704,6 +704,42 @@ def wavlm_conv0(wav, w, gamma, beta, out, T0, P0, eps=1e-5, workspace=None):
     return out
 
 
+# ----------------------------------------------------------------------------------------------- layer_norm feature extractor
+def wav_layernorm(wav, out=None, n_samples=None, eps=1e-5):
+    """task.normalize of wav2vec2 Large / XLS-R: F.layer_norm(wav, wav.shape) per utterance (biased variance, eps inside the
+    root) over the utterance's own samples; n_samples: optional int32 (B,) true lengths of a zero-padded batch."""
+    out = torch.empty_like(wav) if out is None else out
+    B, Lw = wav.shape
+    check(lib().lidk_wav_layernorm(_p(wav), _p(out), B, Lw, _p(n_samples), eps, _stream()), "wav_layernorm")
+    return out
+
+
+def conv0_ln_fwd(wav, w, bias, gamma, beta, out, T0, P0, eps=1e-5):
+    """wav (B, L) f32 -> out (B*P0 [+slack], 512) bf16: Conv1d(1, C, k10, s5, bias) + LayerNorm(C) + GELU, channel-last."""
+    B, Lw = wav.shape
+    check(lib().lidk_conv0_ln_fwd(_p(wav), B, Lw, _p(w), _p(bias), _p(gamma), _p(beta), eps, _p(out), T0, P0, w.shape[0],
+                                  _stream()), "conv0_ln_fwd")
+    return out
+
+
+def ln_gelu_fwd(pre, gamma, beta, out, eps=1e-5):
+    rows, Cc = pre.shape
+    check(lib().lidk_ln_gelu_fwd(_p(pre), _p(gamma), _p(beta), _p(out), rows, Cc, eps, _code(pre), _stream()), "ln_gelu_fwd")
+    return out
+
+
+def ln_gelu_bwd(dy, pre, gamma, beta, dpre, dgamma, dbeta, B, P, Tv, eps=1e-5):
+    check(lib().lidk_ln_gelu_bwd(_p(dy), _p(pre), _p(gamma), _p(beta), _p(dpre), _p(dgamma), _p(dbeta), B, P, Tv, pre.shape[-1], eps,
+                                 _code(pre), _stream()), "ln_gelu_bwd")
+    return dpre
+
+
+def conv0_ln_bwd(wav, w, bias, gamma, beta, dy0, dw, dbias, dgamma, dbeta, T0, P0, eps=1e-5):
+    B, Lw = wav.shape
+    check(lib().lidk_conv0_ln_bwd(_p(wav), B, Lw, _p(w), _p(bias), _p(gamma), _p(beta), eps, _p(dy0), _p(dw), _p(dbias), _p(dgamma),
+                                  _p(dbeta), T0, P0, w.shape[0], _stream()), "conv0_ln_bwd")
+
+
 def wavlm_posconv_prep(x, xg, B, T, G, Pp, pad_left):
     """x (B*T, C) f32 -> xg (G, rows_total, C/G) bf16 zero-padded group-major copy."""
     check(lib().lidk_wavlm_posconv_prep(_p(x), _p(xg), B, T, x.shape[1], G, Pp, pad_left, xg.shape[1], _stream()),

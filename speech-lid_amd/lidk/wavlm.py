@@ -82,6 +82,8 @@ def span_mask(shape, padding_mask, mask_prob: float, mask_length: int, min_masks
 
 
 def _same_tree(a, b):
+    if a is None or b is None:
+        return a is None and b is None
     if isinstance(a, dict):
         return isinstance(b, dict) and a.keys() == b.keys() and all(_same_tree(a[k], b[k]) for k in a)
     if isinstance(a, list):
@@ -96,7 +98,7 @@ def _copy_tree(dst, src):
     elif isinstance(dst, list):
         for x, y in zip(dst, src):
             _copy_tree(x, y)
-    else:
+    elif dst is not None:
         dst.copy_(src)
 
 
@@ -113,8 +115,22 @@ class WavLMBackbone:
         self.C = self.layers_spec[0][0]
         if any(c != self.C for c, _, _ in self.layers_spec) or self.layers_spec[0][1:] != (10, 5):
             raise NotImplementedError("lidk WavLM: conv feature extractor of the (C,10,5) + (C,k,s)* form with one width")
-        if cfg.get("extractor_mode", "default") != "default" or cfg.get("conv_bias", False) or cfg.get("layer_norm_first", False):
-            raise NotImplementedError("lidk WavLM: extractor_mode=default, conv_bias=False, layer_norm_first=False (WavLM-Base/Base+)")
+        # Base models: extractor_mode "default" (GroupNorm on conv layer 0 only, no conv bias), post-LN transformer layers.
+        # Large models (wav2vec2 Large / XLS-R 300M - xlsr2_300m.pt of lid/conf/xf_asr_wav2vec*.yaml - and WavLM Large of
+        # lid/conf/xf_asr_extra_finetune.yaml): extractor_mode "layer_norm" (Conv1d(+bias) -> LayerNorm(C) -> GELU in EVERY conv
+        # layer, WavLM.py:415-477), layer_norm_first (pre-LN layers + the encoder's final LayerNorm, WavLM.py:596-612,727-755),
+        # ``normalize``: the task-level per-utterance layer-norm of the waveform (wav2vec2_expert.py:49,71-72).
+        mode = cfg.get("extractor_mode", "default")
+        if mode not in ("default", "layer_norm"):
+            raise ValueError(f"extractor_mode {mode!r}: 'default' or 'layer_norm' (WavLM.py:420)")
+        self.ln_extractor = mode == "layer_norm"
+        self.conv_bias = bool(cfg.get("conv_bias", False))
+        if self.conv_bias and not self.ln_extractor:
+            raise NotImplementedError("lidk backbone: conv_bias with extractor_mode=default (no released checkpoint has it)")
+        self.pre_ln = bool(cfg.get("layer_norm_first", False))
+        self.normalize = bool(cfg.get("normalize", False))
+        if self.ln_extractor and self.C != 512:
+            raise NotImplementedError("lidk backbone: the layer_norm feature extractor is built for 512 channels")
         # WavLM: bucketed relative-position bias with GRU gating (every released WavLM checkpoint).  wav2vec2 (SURVEY 8f N2:
         # lid/s3prl_updream/wav2vec/wav2vec2.py): neither, but the encoder receives the key padding mask
         # (``encoder_padding_mask``; the reference's WavLM call leaves it out, WavLM.py:390-394).
@@ -145,16 +161,23 @@ class WavLMBackbone:
     # ------------------------------------------------------------------ parameters
     @staticmethod
     def param_shapes(cfg: Dict) -> Dict[str, tuple]:
-        """Names and shapes of lid/wavlm/WavLM.py's ``state_dict()`` for a config (conv_bias=False, extractor_mode=default,
-        relative position embedding owned by layer 0)."""
+        """Names and shapes of lid/wavlm/WavLM.py's ``state_dict()`` for a config (either extractor mode, with or without conv
+        bias; the relative position embedding is owned by layer 0)."""
         spec = eval(cfg.get("conv_feature_layers", "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"))
         C, d = spec[0][0], cfg.get("encoder_embed_dim", 768)
         ffn, H = cfg.get("encoder_ffn_embed_dim", 3072), cfg.get("encoder_attention_heads", 12)
         kpos, gpos = cfg.get("conv_pos", 128), cfg.get("conv_pos_groups", 16)
-        s = {"mask_emb": (d,), "feature_extractor.conv_layers.0.0.weight": (C, 1, spec[0][1]),
-             "feature_extractor.conv_layers.0.2.weight": (C,), "feature_extractor.conv_layers.0.2.bias": (C,)}
-        for i in range(1, len(spec)):
-            s[f"feature_extractor.conv_layers.{i}.0.weight"] = (C, C, spec[i][1])
+        ln_mode, bias = cfg.get("extractor_mode", "default") == "layer_norm", bool(cfg.get("conv_bias", False))
+        s = {"mask_emb": (d,)}
+        for i in range(len(spec)):
+            fe = f"feature_extractor.conv_layers.{i}."
+            s[fe + "0.weight"] = (C, 1 if i == 0 else C, spec[i][1])
+            if bias:
+                s[fe + "0.bias"] = (C,)
+            if ln_mode:                              # Sequential(conv, Dropout, Sequential(TransposeLast, LayerNorm, TransposeLast), GELU)
+                s[fe + "2.1.weight"], s[fe + "2.1.bias"] = (C,), (C,)
+            elif i == 0:                             # Sequential(conv, Dropout, GroupNorm, GELU)
+                s[fe + "2.weight"], s[fe + "2.bias"] = (C,), (C,)
         s.update({"post_extract_proj.weight": (d, C), "post_extract_proj.bias": (d,), "encoder.pos_conv.0.bias": (d,),
                   "encoder.pos_conv.0.weight_g": (1, 1, kpos), "encoder.pos_conv.0.weight_v": (d, d // gpos, kpos)})
         for i in range(cfg.get("encoder_layers", 12)):
@@ -196,7 +219,14 @@ class WavLMBackbone:
         p, dev, bf = self.params, self.device, torch.bfloat16
         g = lambda n: p[n].to(dev).contiguous()
         fe = "feature_extractor.conv_layers."
-        W = {"conv0_w": g(fe + "0.0.weight").reshape(self.C, 10), "gn_w": g(fe + "0.2.weight"), "gn_b": g(fe + "0.2.bias"), "conv": []}
+        W = {"conv0_w": g(fe + "0.0.weight").reshape(self.C, 10), "conv": []}
+        n_conv = len(self.layers_spec)
+        if self.ln_extractor:
+            W["xln_w"] = [g(f"{fe}{i}.2.1.weight") for i in range(n_conv)]
+            W["xln_b"] = [g(f"{fe}{i}.2.1.bias") for i in range(n_conv)]
+            W["conv_b"] = [g(f"{fe}{i}.0.bias") if self.conv_bias else None for i in range(n_conv)]
+        else:
+            W["gn_w"], W["gn_b"] = g(fe + "0.2.weight"), g(fe + "0.2.bias")
         for i in range(1, len(self.layers_spec)):
             w = g(f"{fe}{i}.0.weight")                                        # [Co][Ci][kW] -> [Co][kW*Ci], k-major
             W["conv"].append(w.permute(0, 2, 1).reshape(w.shape[0], -1).to(bf).contiguous())
@@ -254,7 +284,14 @@ class WavLMBackbone:
             if dst.data_ptr() != p[name].data_ptr():
                 dst.copy_(p[name].reshape(dst.shape), non_blocking=True)
 
-        alias(W["conv0_w"], fe + "0.0.weight"); alias(W["gn_w"], fe + "0.2.weight"); alias(W["gn_b"], fe + "0.2.bias")
+        alias(W["conv0_w"], fe + "0.0.weight")
+        if self.ln_extractor:
+            for i in range(len(self.layers_spec)):
+                alias(W["xln_w"][i], f"{fe}{i}.2.1.weight"); alias(W["xln_b"][i], f"{fe}{i}.2.1.bias")
+                if self.conv_bias:
+                    alias(W["conv_b"][i], f"{fe}{i}.0.bias")
+        else:
+            alias(W["gn_w"], fe + "0.2.weight"); alias(W["gn_b"], fe + "0.2.bias")
         for i in range(1, len(self.layers_spec)):
             w = p[f"{fe}{i}.0.weight"]                                           # [Co][Ci][kW] -> [Co][kW][Ci]
             W["conv"][i - 1].view(w.shape[0], w.shape[2], w.shape[1]).copy_(w.permute(0, 2, 1))
@@ -325,11 +362,19 @@ class WavLMBackbone:
         P_last = max(-(-T[l] // mult[l]) for l in range(n))
         P = [P_last * m for m in mult]
         dev, bf = self.device, torch.bfloat16
-        bufs = [torch.zeros(B * P[l] + 8, self.C, device=dev, dtype=(bf if l < n - 1 else torch.float32)) for l in range(n)]
+        # layer_norm extractor: every layer's output is bf16 (the row LayerNorm + GELU kernel keeps the operand type); default
+        # mode: the last layer's GEMM writes f32 straight away
+        bufs = [torch.zeros(B * P[l] + 8, self.C, device=dev, dtype=(bf if l < n - 1 or self.ln_extractor else torch.float32))
+                for l in range(n)]
         Tn, M, d = T[-1], B * T[-1], self.d
         Pp = Tn + self.kpos
         ws = dict(T=T, P=P, bufs=bufs, M=M, Tn=Tn, Pp=Pp, wav=torch.empty(B, Lw, device=dev),
-                  c0ws=torch.empty(ops.wavlm_conv0_workspace(B, T[0], self.C), device=dev),
+                  c0ws=None if self.ln_extractor else torch.empty(ops.wavlm_conv0_workspace(B, T[0], self.C), device=dev),
+                  # layer_norm extractor: a conv layer's pre-norm GEMM output (one scratch for all layers while the extractor is
+                  # frozen; per-layer buffers when it trains, _extractor_buffers)
+                  xpre=torch.zeros(B * P[1] + 8, self.C, device=dev, dtype=bf) if self.ln_extractor and n > 1 else None,
+                  nsamp=torch.full((B,), Lw, device=dev, dtype=torch.int32),
+                  xf=torch.empty(M, d, device=dev) if self.pre_ln else None,
                   tmask=torch.zeros(B, Tn, device=dev, dtype=torch.uint8), cmask=torch.zeros(B, d, device=dev, dtype=torch.uint8),
                   xc=torch.empty(M, self.C, device=dev), mean_in=torch.empty(M, device=dev), rstd_in=torch.empty(M, device=dev), h0=torch.empty(M, self.C, device=dev, dtype=bf),
                   x=torch.empty(M, d, device=dev), xb=torch.empty(M, d, device=dev, dtype=bf),
@@ -355,11 +400,15 @@ class WavLMBackbone:
         f = lambda *sh: torch.empty(*sh, device=dev)
         layers = []
         for _ in range(self.n_layers):
+            # post-LN: xin / xinb = the layer input (a LayerNorm output), y1 / y2 = the sums in front of the two LayerNorms, x1 /
+            # x1b = LN1's output.  pre-LN (layer_norm_first): xin = the residual stream, xinb = LN1(xin), y1 = xin + attention,
+            # x1b = LN2(y1); x1 (LN1's f32 output) is only the relative-bias gate's input, y2 is the next layer's xin.
             layers.append(dict(xin=f(M, d), xinb=e(M, d), qkv=e(M, 3 * d), gate=f(B, H, Tn), lse=f(B, H, Tn), o=e(M, d),
-                               y1=f(M, d), mean1=f(M), rstd1=f(M), x1=f(M, d), x1b=e(M, d), pre=e(M, self.ffn), hm=e(M, self.ffn),
-                               y2=f(M, d), mean2=f(M), rstd2=f(M)))
+                               y1=f(M, d), mean1=f(M), rstd1=f(M), x1=f(M, d) if (not self.pre_ln or self.rel_pos) else None,
+                               x1b=e(M, d), pre=e(M, self.ffn), hm=e(M, self.ffn),
+                               y2=None if self.pre_ln else f(M, d), mean2=f(M), rstd2=f(M)))
         Pp = ws["Pp"]
-        sv = dict(layers=layers, y0=f(M, d), mean0=f(M), rstd0=f(M), pcp=e(B * Pp, d),
+        sv = dict(layers=layers, y0=f(M, d), mean0=f(M), rstd0=f(M), pcp=e(B * Pp, d), meanF=f(M), rstdF=f(M),
                   dxa=f(M, d), dxb=f(M, d), da=f(M, d), dab=e(M, d), dpre=e(M, self.ffn), dx1=f(M, d), db=f(M, d), dbb=e(M, d),
                   do=e(M, d), dqkv=e(M, 3 * d), dgate=f(B, H, Tn), delta=f(B, H, Tn), partial=f(L.LN_BWD_BLOCKS * 2 * d),
                   dpc=torch.zeros(B * Pp + self.kpos, d, device=dev, dtype=bf), dy0=f(M, d),
@@ -431,7 +480,7 @@ class WavLMBackbone:
                 pre=[None] + [torch.zeros(B * P[l] + 8, C, device=dev, dtype=bf) for l in range(1, n)],
                 d=[torch.zeros(B * P[l] + 8, C, device=dev, dtype=bf) for l in range(n)],
                 dcol=torch.empty(B * P[1], kmax * C, device=dev, dtype=bf),
-                sums=torch.empty(B * C * 2, device=dev),
+                sums=None if self.ln_extractor else torch.empty(B * C * 2, device=dev),
                 gconv=[None] + [torch.zeros(C, self.layers_spec[l][1] * C, device=dev) for l in range(1, n)],
                 gconv0=torch.zeros(C, self.layers_spec[0][1], device=dev))
         return ex
@@ -442,11 +491,23 @@ class WavLMBackbone:
         W, k, wav = self.W, ops, ws["wav"]
         T, P, bufs, C, d = ws["T"], ws["P"], ws["bufs"], self.C, self.d
         ex = self._extractor_buffers(ws, B) if keep_pre else None
-        k.wavlm_conv0(wav, W["conv0_w"], W["gn_w"], W["gn_b"], bufs[0], T[0], P[0], workspace=ws["c0ws"])
-        for l in range(1, len(T)):
-            _, kw, st = self.layers_spec[l]
-            A = bufs[l - 1].as_strided((B * P[l], kw * C), (st * C, 1))          # strided view: the convolution is this GEMM
-            k.gemm_nt(A, W["conv"][l - 1], bufs[l][:B * P[l]], act=L.ACT_GELU, out2=ex["pre"][l][:B * P[l]] if ex else None)
+        if self.ln_extractor:
+            # every layer: Conv1d(+bias) -> LayerNorm over channels -> GELU (WavLM.py:438-450).  Layer 0 in one kernel; layers 1..:
+            # the strided-view GEMM (bias in its epilogue) writes the pre-norm rows, lidk_ln_gelu_fwd the layer output
+            k.conv0_ln_fwd(wav, W["conv0_w"], W["conv_b"][0], W["xln_w"][0], W["xln_b"][0], bufs[0], T[0], P[0])
+            for l in range(1, len(T)):
+                _, kw, st = self.layers_spec[l]
+                rows = B * P[l]
+                A = bufs[l - 1].as_strided((rows, kw * C), (st * C, 1))
+                pre = (ex["pre"][l] if ex else ws["xpre"])[:rows]
+                k.gemm_nt(A, W["conv"][l - 1], pre, bias=W["conv_b"][l])
+                k.ln_gelu_fwd(pre, W["xln_w"][l], W["xln_b"][l], bufs[l][:rows])
+        else:
+            k.wavlm_conv0(wav, W["conv0_w"], W["gn_w"], W["gn_b"], bufs[0], T[0], P[0], workspace=ws["c0ws"])
+            for l in range(1, len(T)):
+                _, kw, st = self.layers_spec[l]
+                A = bufs[l - 1].as_strided((B * P[l], kw * C), (st * C, 1))          # strided view: the convolution is this GEMM
+                k.gemm_nt(A, W["conv"][l - 1], bufs[l][:B * P[l]], act=L.ACT_GELU, out2=ex["pre"][l][:B * P[l]] if ex else None)
         Tn, M, Pp = ws["Tn"], ws["M"], ws["Pp"]
         last = bufs[-1][:B * P[-1]]
         k.scale_cast_2d(last.view(B, P[-1] * C), ws["xc"].view(B, Tn * C), B, Tn * C)       # drop the pitch padding rows
@@ -482,6 +543,8 @@ class WavLMBackbone:
             A = ws["xg"][g].as_strided((B * Pp, self.kpos * cg), (cg, 1))
             k.gemm_nt(A, W["pos_w"][g], ws["pc"][:, g * cg:(g + 1) * cg], bias=W["pos_b"][g * cg:(g + 1) * cg].contiguous(),
                       act=L.ACT_GELU)
+        if self.pre_ln:
+            return self._fwd_post_preln(ws, B, taps, klen, mix_w)
         k.wavlm_add_rows(ws["x"], ws["pc"], ws["y"], B, Tn, Pp)
         k.layernorm_fwd(ws["y"], W["enc_ln_w"], W["enc_ln_b"], yT=ws["xb"], y32=ws["x"])
         if taps is not None:
@@ -507,6 +570,38 @@ class WavLMBackbone:
                 taps[f"layer{i}"] = ws["x"].view(B, Tn, d).clone()
         if mix_w is not None:
             k.hidden_mix_axpy(ws["x"], mix_w, nL, ws["feat"], overwrite=(nL == 0))
+
+    def _fwd_post_preln(self, ws, B, taps, klen, mix_w):
+        """The inference encoder with layer_norm_first (WavLM.py:596-612,727-755 = wav2vec2.py:898-957,1037-1056): no LayerNorm
+        behind the positional convolution; a layer is x += attn(LN1(x)); x += ffn(LN2(x)); the encoder's LayerNorm closes the
+        stack.  Hidden states (s3prl hooks, wav2vec2_expert.py:58-66): the residual stream entering every layer + the final
+        LayerNorm's output.  Called after the positional convolution has filled ws["pc"]."""
+        W, k = self.W, ops
+        Tn, Pp, d = ws["Tn"], ws["Pp"], self.d
+        k.wavlm_add_rows(ws["x"], ws["pc"], ws["y"], B, Tn, Pp)
+        x, y = ws["y"], ws["x"]                                        # the residual stream ping-pongs between the two buffers
+        if taps is not None:
+            taps["enc_in"] = x.view(B, Tn, d).clone()
+        nL = len(W["layers"])
+        for i, Lw_ in enumerate(W["layers"]):
+            if mix_w is not None:
+                k.hidden_mix_axpy(x, mix_w, i, ws["feat"], overwrite=(i == 0))
+            k.layernorm_fwd(x, Lw_["ln1_w"], Lw_["ln1_b"], yT=ws["xb"], y32=ws["x1"] if self.rel_pos else None)
+            k.gemm_nt(ws["xb"], Lw_["wqkv"], ws["qkv"], bias=Lw_["bqkv"])
+            gate = None
+            if self.rel_pos:                                           # the gate reads the attention's query = LN1(x)
+                gate = k.wavlm_gate(ws["x1"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], ws["gate"], B, Tn, self.H, self.dh)
+            gate, rb = self._attn_bias(gate)
+            k.xattn_fwd(ws["qkv"], ws["o"], ws["lse"], B, Tn, self.H, self.dh, gate=gate, rb=rb, klen=klen)
+            k.gemm_nt(ws["o"], Lw_["wo"], y, bias=Lw_["bo"], res=x)
+            k.layernorm_fwd(y, Lw_["ln2_w"], Lw_["ln2_b"], yT=ws["x1b"])
+            k.gemm_nt(ws["x1b"], Lw_["w1"], ws["hm"], bias=Lw_["b1"], act=L.ACT_GELU)
+            k.gemm_nt(ws["hm"], Lw_["w2"], x, bias=Lw_["b2"], res=y)
+            if taps is not None:
+                taps[f"layer{i}"] = x.view(B, Tn, d).clone()
+        k.layernorm_fwd(x, W["enc_ln_w"], W["enc_ln_b"], y32=ws["xf"])
+        if mix_w is not None:
+            k.hidden_mix_axpy(ws["xf"], mix_w, nL, ws["feat"], overwrite=(nL == 0))
 
     # ------------------------------------------------------------------ training: forward with saved activations, backward
     # dropout sites of one step: seed = base + 16 * (layer + 1) + site  (site 0 = encoder input / input features)
@@ -543,6 +638,8 @@ class WavLMBackbone:
         if mix_w is not None and len(active) != self.n_layers:
             raise LidkError("hidden_states weighted sum with LayerDrop: the number of hidden states changes from step to step "
                             "(the reference's Featurizer asserts on this too, interfaces.py:228): set encoder_layerdrop to 0")
+        if self.pre_ln:
+            return self._layers_train_preln(ws, B, sv, klen, mix_w, active, (p_drop, p_att, p_act))
         first = sv["layers"][active[0]] if active else None
         o32, ob = (first["xin"], first["xinb"]) if first is not None else (ws["x"], ws["xb"])
         k.layernorm_fwd(sv["y0"], W["enc_ln_w"], W["enc_ln_b"], yT=ob, y32=o32, mean=sv["mean0"], rstd=sv["rstd0"])
@@ -579,6 +676,52 @@ class WavLMBackbone:
             for n, i in enumerate(active):
                 k.hidden_mix_axpy(sv["layers"][i]["xin"], mix_w, n, ws["feat"], overwrite=(n == 0))
             k.hidden_mix_axpy(ws["x"], mix_w, len(active), ws["feat"], overwrite=(len(active) == 0))
+
+    def _layers_train_preln(self, ws, B, sv, klen, mix_w, active, drops):
+        """Training-mode layers with layer_norm_first (WavLM.py:727-755): residual = x; x = residual + dropout1(attn(LN1(x)));
+        x = x + dropout3(fc2(dropout2(gelu(fc1(LN2(x)))))), the encoder's LayerNorm behind the last layer (WavLM.py:596-600).  The
+        residual stream of layer i lives in its ``xin`` buffer (f32) and is hidden state i of the s3prl mix; sv["y0"] (positional
+        convolution + residual, no LayerNorm in front of the layers here) is copied / dropped out into the first one."""
+        W, k = self.W, ops
+        Tn, d = ws["Tn"], self.d
+        p_drop, p_att, p_act = drops
+        fk = self.forced_keep
+        first = sv["layers"][active[0]]["xin"] if active else ws["x"]
+        if p_drop > 0:                                                    # F.dropout(x, p=self.dropout) in front of the layers
+            k.dropout(sv["y0"], first, p_drop, seed=self._site(sv, -1, 0), keep_in=fk.get("enc"))
+        else:
+            k.scale_cast(sv["y0"], first, 1.0)
+        for n, i in enumerate(active):
+            Lw_, S = W["layers"][i], sv["layers"][i]
+            xo = sv["layers"][active[n + 1]]["xin"] if n + 1 < len(active) else ws["x"]
+            k.layernorm_fwd(S["xin"], Lw_["ln1_w"], Lw_["ln1_b"], yT=S["xinb"], y32=S["x1"] if self.rel_pos else None,
+                            mean=S["mean1"], rstd=S["rstd1"])
+            k.gemm_nt(S["xinb"], Lw_["wqkv"], S["qkv"], bias=Lw_["bqkv"])
+            gate = None
+            if self.rel_pos and 0 in active:
+                gate = k.wavlm_gate(S["x1"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], S["gate"], B, Tn, self.H, self.dh)
+            gate, rb = self._attn_bias(gate, active)
+            k.xattn_fwd(S["qkv"], S["o"], S["lse"], B, Tn, self.H, self.dh, gate=gate, rb=rb, klen=klen, drop_p=p_att,
+                        seed=self._site(sv, i, self._ATT), keep=fk.get(("att", i)))
+            if p_drop > 0:
+                k.gemm_nt(S["o"], Lw_["wo"], ws["tmp"], bias=Lw_["bo"])
+                k.dropout_add(ws["tmp"], S["xin"], S["y1"], p_drop, seed=self._site(sv, i, self._D1), keep_in=fk.get(("d1", i)))
+            else:
+                k.gemm_nt(S["o"], Lw_["wo"], S["y1"], bias=Lw_["bo"], res=S["xin"])
+            k.layernorm_fwd(S["y1"], Lw_["ln2_w"], Lw_["ln2_b"], yT=S["x1b"], mean=S["mean2"], rstd=S["rstd2"])
+            k.gemm_nt(S["x1b"], Lw_["w1"], S["hm"], bias=Lw_["b1"], act=L.ACT_GELU, out2=S["pre"])
+            if p_act > 0:
+                k.dropout(S["hm"], S["hm"], p_act, seed=self._site(sv, i, self._D2), keep_in=fk.get(("d2", i)))
+            if p_drop > 0:
+                k.gemm_nt(S["hm"], Lw_["w2"], ws["tmp"], bias=Lw_["b2"])
+                k.dropout_add(ws["tmp"], S["y1"], xo, p_drop, seed=self._site(sv, i, self._D3), keep_in=fk.get(("d3", i)))
+            else:
+                k.gemm_nt(S["hm"], Lw_["w2"], xo, bias=Lw_["b2"], res=S["y1"])
+        k.layernorm_fwd(ws["x"], W["enc_ln_w"], W["enc_ln_b"], y32=ws["xf"], mean=sv["meanF"], rstd=sv["rstdF"])
+        if mix_w is not None:
+            for n, i in enumerate(active):
+                k.hidden_mix_axpy(sv["layers"][i]["xin"], mix_w, n, ws["feat"], overwrite=(n == 0))
+            k.hidden_mix_axpy(ws["xf"], mix_w, len(active), ws["feat"], overwrite=(len(active) == 0))
 
     TRAINABLE_PREFIX = "encoder."
     INPUT_SIDE = ("layer_norm.weight", "layer_norm.bias", "mask_emb")      # never frozen by the reference's freeze_* helpers
@@ -657,12 +800,13 @@ class WavLMBackbone:
             self._drb.zero_()
         dx = sv["dxa"]
         dfe = dfeat.reshape(M, d).contiguous()
+        last = ws["xf"] if self.pre_ln else ws["x"]                          # the last hidden state = the encoder output
         if not data_grads:
             if sv["mix"] and mix_dw is not None:
                 sv["dots"].zero_()
                 for n, i in enumerate(active):
                     k.hidden_mix_dot(dfe, sv["layers"][i]["xin"], sv["dots"][n:n + 1])
-                k.hidden_mix_dot(dfe, ws["x"], sv["dots"][len(active):len(active) + 1])
+                k.hidden_mix_dot(dfe, last, sv["dots"][len(active):len(active) + 1])
                 k.hidden_mix_wgrad(mix_w, sv["dots"], mix_dw)
             return
         if sv["mix"]:
@@ -670,11 +814,66 @@ class WavLMBackbone:
                 raise LidkError("backward: the forward mixed hidden states; pass the same mix_w")
             sv["dots"].zero_()
             nL = len(active)
-            k.hidden_mix_dot(dfe, ws["x"], sv["dots"][nL:nL + 1])
+            k.hidden_mix_dot(dfe, last, sv["dots"][nL:nL + 1])
             k.hidden_mix_axpy(dfe, mix_w, nL, dx, overwrite=True)
         else:
             k.scale_cast(dfe, dx, 1.0)
+        if self.pre_ln:                                                      # the encoder's closing LayerNorm (WavLM.py:598-599)
+            k.layernorm_bwd(dx, ws["x"], sv["meanF"], sv["rstdF"], W["enc_ln_w"], sv["partial"], dx=sv["dxb"],
+                            dgamma=G("encoder.layer_norm.weight"), dbeta=G("encoder.layer_norm.bias"), dtype=bf)
+            dx = sv["dxb"]
         for n, i in reversed(list(enumerate(active))):
+            if not self.pre_ln:
+                break
+            # x_out = y1 + dropout3(fc2(dropout2(gelu(fc1(LN2(y1)))))),  y1 = xin + dropout1(out_proj(attn(LN1(xin))))
+            S, Lw_ = sv["layers"][i], W["layers"][i]
+            q = f"encoder.layers.{i}."
+            a = q + "self_attn."
+            other = sv["dxb"] if dx is sv["dxa"] else sv["dxa"]
+            if p_drop > 0:                                                 # dropout3 masks the fc2 branch only
+                k.dropout(dx, sv["dm"], p_drop, seed=self._site(sv, i, self._D3), keep_in=fk.get(("d3", i)))
+            else:
+                k.scale_cast(dx, sv["dm"], 1.0)
+            dy2 = sv["dm"]
+            if wgrads:
+                self._wgrad(dy2, S["hm"], g[q + "fc2.weight"], g[q + "fc2.bias"])
+            k.gemm_nt(dy2, Lw_["w2T"], sv["dpre"], act=L.ACT_GELU_GRAD, aux=S["pre"])
+            if p_act > 0:
+                k.dropout(sv["dpre"], sv["dpre"], p_act, seed=self._site(sv, i, self._D2), keep_in=fk.get(("d2", i)))
+            if wgrads:
+                self._wgrad(sv["dpre"], S["x1b"], g[q + "fc1.weight"], g[q + "fc1.bias"])
+            k.gemm_nt(sv["dpre"], Lw_["w1T"], sv["dx1"])                   # d LN2(y1)
+            k.layernorm_bwd(sv["dx1"], S["y1"], S["mean2"], S["rstd2"], Lw_["ln2_w"], sv["partial"], dres=dx, dx=sv["da"],
+                            dgamma=G(q + "final_layer_norm.weight"), dbeta=G(q + "final_layer_norm.bias"), dtype=bf)
+            if p_drop > 0:                                                 # dropout1 masks the attention branch only
+                k.dropout(sv["da"], sv["dab"], p_drop, seed=self._site(sv, i, self._D1), keep_in=fk.get(("d1", i)))
+            else:
+                k.scale_cast(sv["da"], sv["dab"], 1.0)
+            dy1 = sv["dab"]
+            if wgrads:
+                self._wgrad(dy1, S["o"], g[a + "out_proj.weight"], g[a + "out_proj.bias"])
+            k.gemm_nt(dy1, Lw_["woT"], sv["do"])
+            gate, rb = self._attn_bias(S["gate"], active)
+            k.xattn_bwd(S["qkv"], S["o"], sv["do"], S["lse"], sv["dqkv"], sv["delta"], B, Tn, H, self.dh, gate=gate, rb=rb,
+                        klen=klen, drop_p=p_att, seed=self._site(sv, i, self._ATT), keep=fk.get(("att", i)),
+                        dgate=sv["dgate"] if gate is not None else None, drb=self._drb if gate is not None else None)
+            if wgrads:
+                gw, gb = self._gqkv[i]
+                self._wgrad(sv["dqkv"], S["xinb"], gw, gb)
+            k.gemm_nt(sv["dqkv"], Lw_["wqkvT"], sv["db"])                  # d LN1(xin)
+            if gate is not None:                                           # the gate read LN1's output too
+                gp = g if wgrads else self._gate_scratch()
+                k.wavlm_gate_bwd(S["x1"], Lw_["wg"], Lw_["bg"], Lw_["grep_a"], sv["dgate"], sv["db"], gp[a + "grep_linear.weight"],
+                                 gp[a + "grep_linear.bias"], gp[a + "grep_a"].view(-1), B, Tn, H, self.dh)
+            k.layernorm_bwd(sv["db"], S["xin"], S["mean1"], S["rstd1"], Lw_["ln1_w"], sv["partial"], dres=sv["da"], dx=other,
+                            dgamma=G(q + "self_attn_layer_norm.weight"), dbeta=G(q + "self_attn_layer_norm.bias"), dtype=bf)
+            if sv["mix"]:                                                  # this layer's residual input is hidden state n
+                k.hidden_mix_dot(dfe, S["xin"], sv["dots"][n:n + 1])
+                k.hidden_mix_axpy(dfe, mix_w, n, other)
+            dx = other
+        for n, i in reversed(list(enumerate(active))):
+            if self.pre_ln:
+                break
             S, Lw_ = sv["layers"][i], W["layers"][i]
             q = f"encoder.layers.{i}."
             a = q + "self_attn."
@@ -721,9 +920,12 @@ class WavLMBackbone:
             k.hidden_mix_wgrad(mix_w, sv["dots"], mix_dw)
         if p_drop > 0:                                                     # the encoder-input dropout
             k.dropout(dx, dx, p_drop, seed=self._site(sv, -1, 0), keep_in=fk.get("enc"))
-        # encoder.layer_norm, then y0 = x + gelu(pos_conv(x))
-        k.layernorm_bwd(dx, sv["y0"], sv["mean0"], sv["rstd0"], W["enc_ln_w"], sv["partial"], dx=sv["dy0"],
-                        dgamma=G("encoder.layer_norm.weight"), dbeta=G("encoder.layer_norm.bias"), dtype=bf)
+        # encoder.layer_norm (post-LN models: it sits in front of the layers), then y0 = x + gelu(pos_conv(x))
+        if self.pre_ln:
+            k.scale_cast(dx, sv["dy0"], 1.0)
+        else:
+            k.layernorm_bwd(dx, sv["y0"], sv["mean0"], sv["rstd0"], W["enc_ln_w"], sv["partial"], dx=sv["dy0"],
+                            dgamma=G("encoder.layer_norm.weight"), dbeta=G("encoder.layer_norm.bias"), dtype=bf)
         k.wavlm_posconv_dprep(sv["dy0"], sv["pcp"], sv["dpc"], B, Tn, Pp, dpg=sv["dpg"], goff=self.kpos - 1 - self.kpos // 2)
         cg = d // self.gpos
         if wgrads:
@@ -781,6 +983,8 @@ class WavLMBackbone:
             return                                                # the reference runs the extractor under no_grad then
         if fgm != 1.0:
             k.scale_cast(dconv, dconv, fgm)
+        if self.ln_extractor:
+            return self._backward_extractor_ln(ws, B, dconv)
         k.wavlm_conv_dlast(dconv, ex["pre"][n - 1][:B * P[n - 1]], ex["d"][n - 1][:B * P[n - 1]], B, T[n - 1], P[n - 1])
         for l in range(n - 1, 0, -1):
             _, kw, st = self.layers_spec[l]
@@ -799,6 +1003,35 @@ class WavLMBackbone:
         ex["gconv0"].zero_()
         k.wavlm_conv0_bwd(ws["wav"], W["conv0_w"], W["gn_w"], W["gn_b"], ws["c0ws"][off:off + B * C * 2], ex["d"][0][:B * P[0]],
                           ex["sums"], ex["gconv0"], g[fe + "0.2.weight"], g[fe + "0.2.bias"], T[0], P[0])
+        g[fe + "0.0.weight"] += ex["gconv0"].view(C, 1, -1)
+
+    def _backward_extractor_ln(self, ws, B, dconv):
+        """The layer_norm extractor's backward (WavLM.py:438-450 per layer: conv(+bias) -> LayerNorm(C) -> GELU): the gradient at a
+        layer's output goes through lidk_ln_gelu_bwd (in place: -> gradient at the conv output, + the LayerNorm's parameter
+        gradients), the convolution's weight / bias gradient is the TN GEMM on the forward's strided view (bias = column sums),
+        its data gradient the NT GEMM to window space + col2im; layer 0 is recomputed from the waveform."""
+        ex, W, k, g = ws["ex"], self.W, ops, self.grads
+        T, P, bufs, C = ws["T"], ws["P"], ws["bufs"], self.C
+        n = len(T)
+        fe = "feature_extractor.conv_layers."
+        k.wavlm_conv_dlast(dconv, None, ex["d"][n - 1][:B * P[n - 1]], B, T[n - 1], P[n - 1])
+        for l in range(n - 1, 0, -1):
+            _, kw, st = self.layers_spec[l]
+            rows = B * P[l]
+            d = ex["d"][l][:rows]
+            k.ln_gelu_bwd(d, ex["pre"][l][:rows], W["xln_w"][l], W["xln_b"][l], d, g[f"{fe}{l}.2.1.weight"], g[f"{fe}{l}.2.1.bias"],
+                          B, P[l], T[l])
+            A = bufs[l - 1].as_strided((rows, kw * C), (st * C, 1))
+            gw = ex["gconv"][l]
+            gw.zero_()
+            k.gemm_tn(d, A, gw, colsum=g[f"{fe}{l}.0.bias"] if self.conv_bias else None, splitk=16)
+            g[f"{fe}{l}.0.weight"] += gw.view(C, kw, C).permute(0, 2, 1)
+            dcol = ex["dcol"].view(-1)[:rows * kw * C].view(rows, kw * C)
+            k.gemm_nt(d, W["convT"][l - 1], dcol)
+            k.wavlm_conv_col2im(dcol, None, ex["d"][l - 1][:B * P[l - 1]], B, P[l], T[l], T[l - 1], kw, C)
+        ex["gconv0"].zero_()
+        k.conv0_ln_bwd(ws["wav"], W["conv0_w"], W["conv_b"][0], W["xln_w"][0], W["xln_b"][0], ex["d"][0][:B * P[0]], ex["gconv0"],
+                       g[fe + "0.0.bias"] if self.conv_bias else None, g[fe + "0.2.1.weight"], g[fe + "0.2.1.bias"], T[0], P[0])
         g[fe + "0.0.weight"] += ex["gconv0"].view(C, 1, -1)
 
     def _gate_scratch(self):
@@ -858,7 +1091,12 @@ class WavLMBackbone:
         B, Lw = wav.shape
         ws = self._workspace(B, Lw)
         Tn, d = ws["Tn"], self.d
-        ws["wav"].copy_(wav)                                  # static input buffer: captured launches see one address
+        if self.normalize:                                    # task.normalize: F.layer_norm(wav, wav.shape) per utterance
+            ragged = n_samples is not None and any(int(n) < Lw for n in n_samples)
+            ns = self._upload_mask(ws, "nsamp", np.asarray([min(int(n), Lw) for n in n_samples], dtype=np.int32)) if ragged else None
+            ops.wav_layernorm(wav, out=ws["wav"], n_samples=ns)
+        else:
+            ws["wav"].copy_(wav)                              # static input buffer: captured launches see one address
         masking = mask and (self.cfg.get("mask_prob", 0.0) > 0 or self.cfg.get("mask_channel_prob", 0.0) > 0)
         ws["masked"] = None
         klen = self._key_lengths(ws, B, Tn, Lw, n_samples)
@@ -887,4 +1125,4 @@ class WavLMBackbone:
                 self._apply_mask(ws, B, Tn, Lw, n_samples)     # host-drawn spans -> two small H2D copies + one launch
             self.graphs.run(("post", B, Lw, klen is not None, None if mix_w is None else mix_w.data_ptr()),
                             lambda: self._fwd_post(ws, B, None, klen=klen, mix_w=mix_w))
-        return (ws["feat"] if mix_w is not None else ws["x"]).view(B, Tn, d)
+        return (ws["feat"] if mix_w is not None else ws["xf"] if self.pre_ln else ws["x"]).view(B, Tn, d)

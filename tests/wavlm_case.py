@@ -20,6 +20,24 @@ W2V_CFG = dict(encoder_layers=2, encoder_embed_dim=768, encoder_ffn_embed_dim=30
                conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2", conv_pos=128, conv_pos_groups=16,
                layer_norm_first=False, extractor_mode="default", conv_bias=False, dropout=0.0, attention_dropout=0.0,
                activation_dropout=0.0, dropout_input=0.0, dropout_features=0.0, encoder_layerdrop=0.0)
+# wav2vec2 Large / XLS-R 300M architecture (what xlsr2_300m.pt of lid/conf/xf_asr_wav2vec*.yaml holds) at reduced depth:
+# layer-norm conv extractor with conv bias, pre-LN layers + the encoder's final LayerNorm, d = 1024, 16 heads, ffn 4096,
+# task.normalize (per-utterance layer-norm of the waveform)
+XLSR_CFG = dict(encoder_layers=2, encoder_embed_dim=1024, encoder_ffn_embed_dim=4096, encoder_attention_heads=16,
+                conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2", conv_pos=128, conv_pos_groups=16,
+                layer_norm_first=True, extractor_mode="layer_norm", conv_bias=True, normalize=True, dropout=0.0,
+                attention_dropout=0.0, activation_dropout=0.0, dropout_input=0.0, dropout_features=0.0, encoder_layerdrop=0.0,
+                feature_grad_mult=1.0)
+# WavLM Large architecture (WavLM-Large.pt of lid/conf/xf_asr_extra_finetune.yaml:12) at reduced depth: the same extractor without
+# conv bias, pre-LN layers, gated bucketed relative position bias; the reference's WavLM wrapper neither normalises the waveform
+# nor hands the encoder a padding mask
+WAVLM_LARGE_CFG = dict(encoder_layers=2, encoder_embed_dim=1024, encoder_ffn_embed_dim=4096, encoder_attention_heads=16,
+                       conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2", conv_pos=128, conv_pos_groups=16,
+                       relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True, layer_norm_first=True,
+                       extractor_mode="layer_norm", conv_bias=False, normalize=True, dropout=0.0, attention_dropout=0.0,
+                       activation_dropout=0.0, dropout_input=0.0, dropout_features=0.0, encoder_layerdrop=0.0, mask_prob=0.0,
+                       mask_channel_prob=0.0, feature_grad_mult=1.0)
+HEAD_LARGE = dict(dim_head=32, num_head=8, linear_dim=1024, hidden_dim=64)      # lid/conf/xf_asr_wav2vec.yaml:6,9,19-20
 MASK_PROB, MASK_CHANNEL_PROB, MASK_SEED = 0.3, 0.2, 5           # the span-masked frozen-regime fixture (numpy seed before the step)
 L2V = {"a": 30, "b": 40, "c": 50}
 L2I = {"a": 0, "b": 1, "c": 2}
@@ -79,6 +97,29 @@ def backbone_weights(layers: int = CFG["encoder_layers"], rel_pos: bool = True):
     return out
 
 
+def backbone_weights_cfg(cfg):
+    """The same recipe for any backbone config: names and shapes from ``WavLMBackbone.param_shapes`` (the reference's
+    ``load_state_dict(strict=True)`` in the fixture generators checks them against lid/wavlm/WavLM.py's own)."""
+    from lidk.wavlm import WavLMBackbone
+    out = {}
+    for name, shape in WavLMBackbone.param_shapes(cfg).items():
+        g = torch.Generator().manual_seed(_seed(name))
+        if name.endswith(("norm.weight", "conv_layers.0.2.weight", ".2.1.weight")):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith("grep_a"):
+            t = 1.0 + 0.2 * torch.randn(shape, generator=g)
+        elif name.endswith("weight_g"):
+            t = 0.5 + 0.5 * torch.rand(shape, generator=g)
+        elif name.endswith("relative_attention_bias.weight"):
+            t = 0.5 * torch.randn(shape, generator=g)
+        elif len(shape) >= 2:
+            t = torch.randn(shape, generator=g) * (1.6 / math.sqrt(math.prod(shape[1:])))
+        else:
+            t = 0.05 * torch.randn(shape, generator=g)
+        out[name] = t
+    return out
+
+
 def waveforms():
     g = torch.Generator().manual_seed(2024)
     t = torch.arange(SAMPLES) / 16000.0
@@ -97,12 +138,12 @@ def head_cfg(**kw):
     return ConformerCfg(**base)
 
 
-def head_weights():
+def head_weights(**kw):
     """name -> tensor for the per-language ConformerLinear heads + LangDiscriminator of WavLMMutiLangModel (reference state_dict
     names: model.last_projects.<lang>.block.*, .linear.*, lang_discriminator.linear.*), seeded per tensor name; BatchNorm
     running statistics non-trivial."""
     from lidk.layout import model_specs
-    specs, buffers, _, _ = model_specs(head_cfg())
+    specs, buffers, _, _ = model_specs(head_cfg(**kw))
     out = {}
     for s in specs:
         g = torch.Generator().manual_seed(_seed(s.name))
