@@ -289,6 +289,7 @@ class Trainer:
             model.set_compute_dtype(torch.bfloat16 if self.use_amp else torch.float32)
         model = model.to(self.device)
         self.engine = getattr(model, "lidk_engine", None)
+        self._seed_native_generators(model)
         swa_model = None
         if use_swa:
             swa_model = torch.optim.swa_utils.AveragedModel(
@@ -310,6 +311,29 @@ class Trainer:
                 model = torch.nn.parallel.DistributedDataParallel(
                     model, device_ids=[self.device.index] if self.device.type == "cuda" else None)
         return model, swa_model
+
+    def _seed_native_generators(self, model):
+        """The counter-based dropout / stochastic-depth generators of the native path are functions of (seed, step, site, element):
+        give them the run's seed - what ``seed_everything`` handed torch (ccml/train_helper.py:6-12) - so different seeds give
+        different masks.  ``seed`` stays EQUAL on all ranks (stochastic depth and LayerDrop must agree); the dropout masks
+        are salted with the rank so the ranks' noise is independent, as it is under DistributedDataParallel where every process
+        draws from its own generator state."""
+        seed = int(torch.initial_seed()) & 0x3FFFFFFF
+        salt = int(self.local_rank) if self.ddp and self.local_rank is not None and self.local_rank > 0 else 0
+        for obj in (self.engine, getattr(model, "backbone", None)):
+            if obj is not None and hasattr(obj, "seed"):
+                obj.seed, obj.rank_salt = seed, salt
+
+    def _resume_native_counters(self):
+        """After a resume the generators continue from the step the run had reached instead of replaying the masks of step 0
+        (the reference's torch generator state is not checkpointed either: a resumed run there draws a fresh sequence)."""
+        for obj in (self.engine, getattr(self.model, "backbone", None)):
+            if obj is None:
+                continue
+            if hasattr(obj, "step_count"):
+                obj.step_count = max(obj.step_count, int(self.current_step))
+            elif hasattr(obj, "step"):
+                obj.step = max(obj.step, int(self.current_step))
 
     def init_dataloader(self, ddp: bool = False, train_batch_size: int = 4, val_batch_size: int = 4, pin_memory: bool = True,
                         num_workers: int = 0, prefetch_factor: int = 2, train_sampler: Sampler = None,
@@ -366,6 +390,7 @@ class Trainer:
              self.logger) = self.resume_from_checkpoint(self.checkpoint_path, self.resume_train_states, self.gpu_id, self.model,
                                                         self.optimizer, self.scalar, self.lr_scheduler, self.logger)
         self.current_step = self.current_epoch * int(len(self.train_dataloader) / self.accumulate_grad)
+        self._resume_native_counters()
         self.logger.watch_model(model=self.model)
 
     # ------------------------------------------------------------------ module pass-throughs (reference names)

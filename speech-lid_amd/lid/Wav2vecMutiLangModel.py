@@ -61,8 +61,14 @@ class Wav2vecMutiLangModel(WavLMMutiLangModel):
         if cfg.get("relative_position_embedding", False) or cfg.get("gru_rel_pos", False):
             raise ValueError("a wav2vec2 config has no relative position embedding")
         cfg["encoder_padding_mask"] = True
-        # UpstreamExpert(mask=mask): spans are drawn with the checkpoint config's own probabilities (fairseq defaults 0.65 / 0)
-        mask_prob, mask_channel_prob = float(cfg.get("mask_prob", 0.65)), float(cfg.get("mask_channel_prob", 0.0))
+        # load_wav2vec2_for_finetune (wav2vec2_expert.py:196-215) overrides the checkpoint's masking with fixed values -
+        # mask_prob 0.2, mask_channel_prob 0.2, mask_channel_length 64 (the YAML's model.mask_prob / mask_channel_prob never reach
+        # the wav2vec2 model: lid/LidModule_ASR.py:95-110 does not pass them) - and switches LayerDrop off unless
+        # feature_selection == "last_hidden_state" (drop_layer, lid/Wav2vecMutiLangModel.py:186).
+        mask_prob, mask_channel_prob = 0.2, 0.2
+        cfg["mask_channel_length"] = 64
+        if feature_selection != "last_hidden_state":
+            cfg["encoder_layerdrop"] = -1.0
         super().__init__(pt_path=None, feature_selection=feature_selection, dropout=dropout, linear_dim=linear_dim, mask=mask,
                          num_layers=num_layers, lang2vocab=lang2vocab, lang2index=lang2index, hidden_dim=hidden_dim,
                          conformer_linear=conformer_linear, use_mask=use_mask, dim_head=dim_head, num_head=num_head,

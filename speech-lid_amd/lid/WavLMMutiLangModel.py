@@ -231,10 +231,9 @@ class WavLMMutiLangModel(_EngineBoundModel):
         if any(p.grad is None for n, p in live.items() if masked or n != "mask_emb"):
             bb.zero_grads()
         mix_dw = None
-        if mix_w is not None:
-            mp = params[self.MIX_NAME]
-            if getattr(self, "_mix_grad", None) is None or self._mix_grad.device != mix_w.device:
-                self._mix_grad = torch.zeros_like(mix_w)
+        if mix_w is not None:                      # the Featurizer's mixing logits: their gradient lives at the head of the
+            mp = params[self.MIX_NAME]             # backbone's flat arena, so data parallelism averages it with the rest
+            self._mix_grad = bb.mix_grad
             if mp.grad is None:
                 self._mix_grad.zero_()
             mix_dw = self._mix_grad if mp.requires_grad else None
@@ -247,8 +246,9 @@ class WavLMMutiLangModel(_EngineBoundModel):
             if n == "mask_emb" and not masked:                     # no span was replaced: the reference leaves .grad None
                 continue
             p.grad = bb.grads[n]
-        if self.on_backbone_grads_ready is not None:
-            self.on_backbone_grads_ready(bb.grad_flat)
+        if self.on_backbone_grads_ready is not None:          # only the prefix of the arena this regime writes
+            region = "extractor" if not self._backbone_frozen["extractor"] else "input" if frozen else "encoder"
+            self.on_backbone_grads_ready(bb.grad_flat[:bb.grad_regions[region]])
         self._bb_stale = True                                      # an optimizer step follows
 
     def keep_last_lang_model_train(self, lang):

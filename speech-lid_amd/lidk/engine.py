@@ -283,7 +283,8 @@ class Engine:
         self.stat_allreduce: Optional[Callable[[torch.Tensor], None]] = None
         self.on_stage_grads_ready: Optional[Callable[[str], None]] = None
         self.world_size = 1
-        self.seed = 0
+        self.seed = 0                      # the run's seed (Trainer._seed_native_generators): equal on every rank
+        self.rank_salt = 0                 # data parallelism: this rank's salt of the DROPOUT masks (stochastic depth uses seed only)
         self.step_count = 0
         self._split_ok: Dict[tuple, bool] = {}
         self._ln_gemm_ok: Dict[tuple, bool] = {}
@@ -692,7 +693,7 @@ class Engine:
         w = self.work(B, F_)
         self._forced_masks = masks or {}
         self.step_count += 1
-        seed = (self.seed * 1000003 + self.step_count) & 0x7FFFFFFFFFFF
+        seed = ((self.seed + 7919 * self.rank_salt) * 1000003 + self.step_count) & 0x7FFFFFFFFFFF
         x = self._front_fwd(w, mel, training, seed)
         keep = keep_layers if (training and keep_layers is not None) else [True] * self.cfg.n_blocks
         if self._whole_graphs(keep):

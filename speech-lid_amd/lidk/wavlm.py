@@ -140,7 +140,9 @@ class WavLMBackbone:
         self.rel_pos = bool(cfg.get("relative_position_embedding", False))
         self.pad_mask = bool(cfg.get("encoder_padding_mask", False))
         self.train_extractor = False              # un-frozen conv feature extractor: the forward keeps its pre-activations
-        self.seed, self.step = 0, 0               # dropout decisions are functions of (seed, step, site, element index)
+        # dropout decisions are functions of (seed, rank salt, step, site, element index); the Trainer sets seed (the run's seed,
+        # equal on all ranks) and rank_salt (_seed_native_generators) and moves ``step`` forward on a resume
+        self.seed, self.rank_salt, self.step = 0, 0, 0
         self.forced_keep: Dict = {}               # tests: site -> uint8 keep mask (reference-captured dropout masks)
         self.d = cfg.get("encoder_embed_dim", 768)
         self.ffn = cfg.get("encoder_ffn_embed_dim", 3072)
@@ -607,6 +609,9 @@ class WavLMBackbone:
     # dropout sites of one step: seed = base + 16 * (layer + 1) + site  (site 0 = encoder input / input features)
     _D1, _ATT, _D2, _D3 = 1, 2, 3, 4
 
+    def _drop_base(self):
+        return ((((self.seed + 7919 * self.rank_salt) * 1000003 + self.step) & 0x7FFFFFFF) << 12)
+
     def _site(self, sv, layer, site):
         return sv["drop"]["base"] + 16 * (layer + 1) + site
 
@@ -618,7 +623,7 @@ class WavLMBackbone:
         W, k, cfg = self.W, ops, self.cfg
         Tn, M, Pp, d = ws["Tn"], ws["M"], ws["Pp"], self.d
         p_drop, p_att, p_act = (float(cfg.get(n, 0.0)) for n in ("dropout", "attention_dropout", "activation_dropout"))
-        sv["drop"] = dict(p=p_drop, att=p_att, act=p_act, base=(((self.seed * 1000003 + self.step) & 0x7FFFFFFF) << 12))
+        sv["drop"] = dict(p=p_drop, att=p_att, act=p_act, base=self._drop_base())
         fk = self.forced_keep
         sv["klen"], sv["mix"] = klen, mix_w is not None
         if klen is not None:
@@ -748,17 +753,31 @@ class WavLMBackbone:
             plan.append((name, off, tuple(shape)))
             off += -(-n // 64) * 64
 
+        # Arena order = what trains in the reference's three regimes, so that under data parallelism only the live prefix is
+        # exchanged: [hidden-state mixing logits of the s3prl Featurizer (owned by the model above, averaged with the rest) |
+        # layer_norm, mask_emb: never frozen] [encoder.*: after freeze_tranformer_epoch] [extractor: after freeze_encoder_epoch]
         fused = (".q_proj.", ".k_proj.", ".v_proj.")
+        shapes = self.param_shapes(self.cfg)
+        self.grad_regions = {}
+        take("featurizer.weights", (self.n_layers + 1,))
+        for name in self.INPUT_SIDE:
+            take(name, self.params[name].shape)
+        self.grad_regions["input"] = off
         for name, t in self.params.items():
-            if (name.startswith((self.TRAINABLE_PREFIX,) + self.EXTRACTOR_PREFIXES) or name in self.INPUT_SIDE) \
-                    and not any(f in name for f in fused) and name in self.param_shapes(self.cfg):
+            if name.startswith(self.TRAINABLE_PREFIX) and not any(f in name for f in fused) and name in shapes:
                 take(name, t.shape)
         for i in range(self.n_layers):
             take(f"qkv_w.{i}", (3 * d, d))
             take(f"qkv_b.{i}", (3 * d,))
+        self.grad_regions["encoder"] = off
+        for name, t in self.params.items():
+            if name.startswith(self.EXTRACTOR_PREFIXES) and name in shapes:
+                take(name, t.shape)
+        self.grad_regions["extractor"] = off
         self.grad_flat = torch.zeros(off, device=dev)
         view = {name: self.grad_flat[o:o + math.prod(shape)].view(shape) for name, o, shape in plan}
-        g = {n: v for n, v in view.items() if not n.startswith("qkv_")}
+        g = {n: v for n, v in view.items() if not n.startswith("qkv_") and n != "featurizer.weights"}
+        self.mix_grad = view["featurizer.weights"]
         self._gqkv = []
         for i in range(self.n_layers):
             a = f"encoder.layers.{i}.self_attn."
@@ -1108,7 +1127,7 @@ class WavLMBackbone:
             sv = self._train_buffers(ws, B)
             p_in = float(self.cfg.get("dropout_input", 0.0))
             if p_in > 0:
-                sv["drop"] = dict(base=(((self.seed * 1000003 + self.step) & 0x7FFFFFFF) << 12))
+                sv["drop"] = dict(base=self._drop_base())
                 ops.dropout(ws["x"], ws["x"], p_in, seed=self._site(sv, -1, 1), keep_in=self.forced_keep.get("in"))
             if masking:
                 self._apply_mask(ws, B, Tn, Lw, n_samples)

@@ -102,3 +102,49 @@ def test_bench_two_ranks_rehearsal_at_cfg2_shape():
     print("[bench dp2 rehearsal]", line["ms_per_step"], comm)
     assert comm["ms_per_step_with_comm"] > 0 and comm["ms_per_step_comm_stubbed"] > 0 and "comm_exposed_ms" in comm
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def _worker_w2v2(rank, world, port, out_dir):
+    sys.path[:0] = [ROOT, PKG]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from ccml import seed_everything
+    from ccml.trainer import Trainer
+    from lid import hydra_lite
+    import lid.main as launcher
+    seed_everything(0)
+    ov = ["trainer.gpu_id=0", "trainer.total_epoch=2", "model.wav2vec_cfg.encoder_layers=2", "data.synthetic.items_per_lang=8",
+          "data.synthetic.val_items_per_lang=2", "data.synthetic.seconds=3.0", f"data.sampler_common.train_batch_size={8 // world}",
+          "module.freeze_tranformer_epoch=0", f"trainer.ddp={'true' if world > 1 else 'false'}", f"trainer.world_size={world}",
+          f"trainer.local_rank={rank}", "trainer.backend=gloo", f"trainer.master_port={port}", "module.interval=1000",
+          "trainer.log_interval=1000", "module.scheduler=none"]
+    cfg = hydra_lite.load_config(os.path.join(PKG, "lid", "conf"), "synthetic_w2v2", ov)
+    module, sets, params = launcher.build(cfg, rank, world)
+    w0 = module.model.state_dict()["model.featurizer.weights"].detach().cpu().clone()
+    trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
+    trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=params)
+    sd = {k: v.detach().cpu().clone() for k, v in module.model.state_dict().items()}
+    sd["__mix_before__"] = w0
+    bb = module.model.backbone
+    sd["__dropout_seed__"] = torch.tensor([float(bb.seed), float(bb.rank_salt), float(bb._drop_base())])
+    torch.save(sd, os.path.join(out_dir, f"w2v2_r{rank}.pt"))
+
+
+def test_two_ranks_wav2vec2_mixing_weights_and_backbone_stay_equal(tmp_path):
+    """the s3prl Featurizer's mixing logits (``model.featurizer.weights``) live outside the engine arena; their gradient
+    now sits at the head of the backbone's flat gradient arena and is averaged with it, so both ranks hold identical weights after
+    training (epoch 0: transformer frozen - only the arena's never-frozen prefix is exchanged; epoch 1: un-frozen) while the ranks'
+    dropout streams differ (the backbone's dropout seed is derived from the global seed AND the rank)."""
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_w2v2, args=(r, 2, 29741, str(tmp_path))) for r in range(2)]
+    [q.start() for q in procs]
+    [q.join(600) for q in procs]
+    assert [q.exitcode for q in procs] == [0, 0]
+    r0, r1 = torch.load(tmp_path / "w2v2_r0.pt"), torch.load(tmp_path / "w2v2_r1.pt")
+    s0, s1 = r0["__dropout_seed__"].tolist(), r1["__dropout_seed__"].tolist()
+    assert s0[0] == s1[0] and s0[1] != s1[1] and s0[2] != s1[2]          # same run seed, different salt -> different masks
+    for k in r0:
+        if not k.startswith("__"):
+            assert torch.equal(r0[k], r1[k]), f"ranks diverged on {k}"
+    assert not torch.equal(r0["model.featurizer.weights"], r0["__mix_before__"])
+    key = "model.featurizer.upstream.model.encoder.layers.1.fc1.weight"
+    assert bool(torch.isfinite(r0[key]).all())

@@ -175,3 +175,160 @@ def test_trainer_fit_wav2vec2_variable_length_bucketed(tmp_path, monkeypatch):
     for k in before:
         if ".feature_extractor." in k or ".post_extract_proj." in k:
             assert torch.equal(after[k].cpu(), before[k].cpu()), k
+
+
+def _spy_grads(trainer, module, seen):
+    """Record, right before every optimizer step, which parameters carry a non-zero gradient."""
+    orig = trainer._optimizer_step
+
+    def step():
+        seen.append({n for n, p in module.model.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0})
+        return orig()
+
+    trainer._optimizer_step = step
+
+
+def test_cfg5_full_size_joint_ctc_lid_bucketed_frozen_regime(tmp_path, monkeypatch):
+    """BASELINE config 5 at its own size through the launcher and ``Trainer.fit``: wav2vec2 Base (12 layers, d 768) under
+    ``LidModule`` (joint per-language CTC + ASR-confidence LID, lid/LidModule_ASR.py:178-223), batches of 64 utterances of 1 - 10 s
+    drawn by the bucketed single-language sampler (lid/raw_datasets.py:374-440), bf16, the reference's first-epoch regime
+    (extractor + transformer frozen).  No reference run of this size fits the build container, so - like the cfg4 test - this is a
+    property test: every batch holds 64 utterances of ONE language with similar durations (a window of bucket_window = 4 batches is
+    sorted by length and cut: a batch spans <= 3 of the ten 1 s bins instead of all of them), losses are
+    finite, the gradient reaches exactly what the reference trains in this regime (the batch's head, the Featurizer's mixing
+    weights, wav2vec2's layer_norm; span masking is on, so mask_emb too), validation produces finite LID metrics."""
+    monkeypatch.chdir(tmp_path)
+    from ccml import seed_everything
+    from ccml.trainer import Trainer
+    from lid import hydra_lite
+    import lid.main as launcher
+    seed_everything(0)
+    cfg = hydra_lite.load_config(os.path.join(PKG, "lid", "conf"), "synthetic_w2v2",
+                                 ["trainer.total_epoch=1", "trainer.gpu_id=0", "data.sampler_common.train_batch_size=64",
+                                  "data.synthetic.items_per_lang=256", "module.interval=1000", "trainer.log_interval=1000",
+                                  "module.scheduler=none"])
+    assert cfg["model"]["wav2vec_cfg"]["encoder_layers"] == 12 and cfg["data"]["synthetic"]["seconds"] == 10.0
+    module, sets, params = launcher.build(cfg)
+    m = module.model
+    shapes, losses, seen = [], [], []
+    orig_loop = module.train_loop
+
+    def loop(batch):
+        wavs, langs = batch[0], batch[5]
+        secs = sorted({int(w.shape[-1]) // 16000 for w in wavs})
+        shapes.append((len(wavs), secs, sorted(set(getattr(langs, "_host", langs).tolist()))))
+        out = orig_loop(batch)
+        losses.append(out["loss"].detach())
+        return out
+
+    module.train_loop = loop
+    trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
+    orig_prepare = trainer.trainer_prepare
+
+    def prepare():
+        orig_prepare()
+        _spy_grads(trainer, module, seen)
+
+    trainer.trainer_prepare = prepare
+    trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=params)
+    losses = [float(l) for l in losses]
+    print("[cfg5 full size] batches", shapes, "losses", losses, "val", module.last_val)
+    assert len(shapes) == 12 and all(b == 64 and len(langs) == 1 for b, _, langs in shapes)
+    assert cfg["data"]["sampler_common"]["bucket_window"] == 4
+    assert all(s[-1] - s[0] <= 3 for _, s, _ in shapes) and {s for _, ss, _ in shapes for s in ss} <= set(range(1, 11))
+    assert max(s[-1] for _, s, _ in shapes) == 10 and min(s[0] for _, s, _ in shapes) <= 2      # the whole range is there
+    assert all(np.isfinite(losses)) and np.isfinite(module.last_val["val_loss"])
+    pre = m.BB_PREFIX
+    for got, (_, _, langs) in zip(seen, shapes):
+        lang = module.index2lang_dict[langs[0]]
+        assert any(n.startswith(f"model.last_projects.{lang}.") for n in got)
+        assert {"model.featurizer.weights", pre + "layer_norm.weight", pre + "layer_norm.bias", pre + "mask_emb"} <= got
+        assert not any(".encoder." in n or ".feature_extractor." in n or ".post_extract_proj." in n for n in got)
+        assert not any(n.startswith("model.last_projects.") and not n.startswith(f"model.last_projects.{lang}.") for n in got)
+
+
+def test_trainer_fit_xlsr_reference_schema_yaml(tmp_path, monkeypatch):
+    """A YAML in the schema of the reference's lid/conf/xf_asr_wav2vec.yaml (``linear_dim: 1024``, ``feature_selection:
+    last_hidden_state``, ``freeze_tranformer_epoch`` / ``freeze_encoder_epoch``; ``wav2vec_cfg`` with the XLS-R flags in place of
+    the checkpoint file) builds through the launcher and trains under ``Trainer.fit``: epoch 0 transformer + extractor frozen,
+    epoch 1 transformer fine-tuned, epoch 2 the layer-norm conv extractor too."""
+    monkeypatch.chdir(tmp_path)
+    from ccml import seed_everything
+    from ccml.trainer import Trainer
+    from lid import hydra_lite
+    import lid.main as launcher
+    seed_everything(0)
+    cfg = hydra_lite.load_config(os.path.join(PKG, "lid", "conf"), "synthetic_xlsr",
+                                 ["model.wav2vec_cfg.encoder_layers=2", "trainer.total_epoch=3", "trainer.gpu_id=0",
+                                  "data.synthetic.items_per_lang=16", "data.synthetic.seconds=4.0", "module.freeze_tranformer_epoch=0",
+                                  "module.freeze_encoder_epoch=1", "module.interval=1000", "trainer.log_interval=1000",
+                                  "module.scheduler=none"])
+    assert cfg["model"]["linear_dim"] == 1024 and cfg["model"]["feature_selection"] == "last_hidden_state"
+    module, sets, params = launcher.build(cfg)
+    m = module.model
+    bb = m.backbone
+    assert type(m).__name__ == "Wav2vecMutiLangModel" and bb.pre_ln and bb.ln_extractor and bb.conv_bias and bb.normalize
+    assert bb.cfg["mask_prob"] == 0.2 and bb.cfg["mask_channel_prob"] == 0.2 and bb.cfg["mask_channel_length"] == 64
+    assert "model.featurizer.weights" not in dict(m.named_parameters())          # last_hidden_state: no Featurizer mix
+    pre = m.BB_PREFIX
+    keys = {"enc": pre + "encoder.layers.1.fc1.weight", "conv": pre + "feature_extractor.conv_layers.3.0.weight",
+            "conv_ln": pre + "feature_extractor.conv_layers.0.2.1.weight", "conv_b": pre + "feature_extractor.conv_layers.5.0.bias"}
+    before = {k: m.state_dict()[v].detach().clone() for k, v in keys.items()}
+    snaps, losses = {}, []
+    orig = module.train_loop_end
+
+    def spy(outputs):
+        losses.append(float(torch.stack([o["loss"].float() for o in outputs]).mean()))
+        snaps[len(losses)] = {k: m.state_dict()[v].detach().clone() for k, v in keys.items()}
+        return orig(outputs)
+
+    module.train_loop_end = spy
+    trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
+    trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=params)
+    print("xlsr epoch losses", losses, "val", module.last_val)
+    assert len(losses) == 3 and all(np.isfinite(losses)) and np.isfinite(module.last_val["val_loss"])
+    same = lambda a, b: torch.equal(a.cpu(), b.cpu())
+    assert all(same(snaps[1][k], before[k]) for k in keys)                       # epoch 0: everything in the backbone frozen
+    assert not same(snaps[2]["enc"], before["enc"])                              # epoch 1: transformer fine-tuned ...
+    assert all(same(snaps[2][k], before[k]) for k in ("conv", "conv_ln", "conv_b"))      # ... the extractor still frozen
+    assert not any(same(snaps[3][k], snaps[2][k]) for k in keys)                # epoch 2: the layer-norm extractor trains too
+
+
+def test_keep_train_lang_freezes_every_other_head(tmp_path, monkeypatch):
+    """``module.keep_train_lang`` (lid/conf/xf_asr_extra_finetune.yaml:43 -> lid/WavLMMutiLangModel.py:114-123): after the epoch
+    hook every head but the named one stops training - their parameters stay bit-identical over an epoch that contains batches of
+    their languages - while the kept head and the (un-frozen) transformer move."""
+    monkeypatch.chdir(tmp_path)
+    from ccml import seed_everything
+    from ccml.trainer import Trainer
+    from lid import hydra_lite
+    import lid.main as launcher
+    seed_everything(0)
+    cfg = hydra_lite.load_config(os.path.join(PKG, "lid", "conf"), "synthetic_wavlm",
+                                 ["model.wavlm_cfg.encoder_layers=2", "trainer.total_epoch=1", "trainer.gpu_id=0",
+                                  "data.synthetic.items_per_lang=16", "data.synthetic.seconds=2.0", "data.sampler_common.train_batch_size=8",
+                                  "module.freeze_tranformer_epoch=-1", "+module.keep_train_lang=l01", "module.interval=1000",
+                                  "trainer.log_interval=1000", "module.scheduler=none"])
+    module, sets, params = launcher.build(cfg)
+    assert module.keep_train_lang == "l01"
+    m = module.model
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    langs_seen = []
+    orig_loop = module.train_loop
+
+    def loop(batch):
+        langs_seen.append(int(getattr(batch[5], "_host", batch[5])[0]))
+        return orig_loop(batch)
+
+    module.train_loop = loop
+    trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
+    trainer.fit(module, train_dataset=sets["train"], val_dataset=sets["val"], test_dataset=sets["test"], dataloader_params=params)
+    after = m.state_dict()
+    assert len(set(langs_seen)) == 3                                              # batches of every language went through
+    moved = {k for k in before if before[k].is_floating_point() and "running_" not in k and not torch.equal(before[k].cpu(), after[k].cpu())}
+    assert any(k.startswith("model.last_projects.l01.") for k in moved)
+    frozen = [k for k in before if k.startswith(("model.last_projects.l00.", "model.last_projects.l02.")) and "running_" not in k
+              and "num_batches_tracked" not in k]
+    assert frozen and not (set(frozen) & moved), sorted(set(frozen) & moved)[:5]
+    assert any(".encoder.layers.1." in k for k in moved)                          # the backbone kept training on every batch
+    assert not any(p.requires_grad for n, p in m.named_parameters() if n.startswith(("model.last_projects.l00.", "model.last_projects.l02.")))

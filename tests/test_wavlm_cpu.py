@@ -86,7 +86,10 @@ def test_wav2vec2_model_state_dict_names_and_module_surface():
     want = {pre + k for k in shapes} | set(wc.head_weights()) | {"model.featurizer.weights"}
     assert set(m.state_dict()) == want
     assert m.state_dict()["model.featurizer.weights"].shape == (wc.W2V_CFG["encoder_layers"] + 1,)
-    assert m.backbone.pad_mask and not m.backbone.rel_pos and m.backbone.cfg["mask_prob"] == 0.65
+    # load_wav2vec2_for_finetune's fixed masking (wav2vec2_expert.py:210-212) and LayerDrop off for the hidden-state mix (:205-207)
+    bcfg = m.backbone.cfg
+    assert m.backbone.pad_mask and not m.backbone.rel_pos and (bcfg["mask_prob"], bcfg["mask_channel_prob"]) == (0.2, 0.2)
+    assert bcfg["mask_channel_length"] == 64 and bcfg["encoder_layerdrop"] == -1.0
     trainable = {n for n, p in m.named_parameters() if p.requires_grad and n.startswith("model.featurizer.")}
     assert trainable == {pre + "layer_norm.weight", pre + "layer_norm.bias", pre + "mask_emb", "model.featurizer.weights"}
     m.unfreeze_tranformer_encoder()
@@ -98,6 +101,34 @@ def test_wav2vec2_model_state_dict_names_and_module_surface():
     last = LidModule(use_wav2vec=True, conformer_linear=True, feature_selection="last_hidden_state", lang2vocab=wc.L2V,
                      lang2index_dict=wc.L2I, tokenizer_dict=toks, wav2vec_cfg=wc.W2V_CFG, linear_dim=768)
     assert "model.featurizer.weights" not in last.model.state_dict()
+    assert last.model.backbone.cfg["encoder_layerdrop"] == 0.0                   # drop_layer: the checkpoint's own LayerDrop stays
+    # the Large / XLS-R form and the nested fairseq cfg layout
+    nested = {"model": {k: v for k, v in wc.XLSR_CFG.items() if k != "normalize"}, "task": {"normalize": True}}
+    big = LidModule(use_wav2vec=True, conformer_linear=True, feature_selection="last_hidden_state", lang2vocab=wc.L2V,
+                    lang2index_dict=wc.L2I, tokenizer_dict=toks, wav2vec_cfg=nested, linear_dim=1024, hidden_dim=64)
+    bb = big.model.backbone
+    assert bb.normalize and bb.pre_ln and bb.ln_extractor and bb.conv_bias and (bb.d, bb.H, bb.ffn) == (1024, 16, 4096)
+    names = set(big.model.state_dict())
+    for i in range(7):
+        assert {pre + f"feature_extractor.conv_layers.{i}.0.bias", pre + f"feature_extractor.conv_layers.{i}.2.1.weight",
+                pre + f"feature_extractor.conv_layers.{i}.2.1.bias"} <= names
+    assert pre + "feature_extractor.conv_layers.0.2.weight" not in names
+
+
+def test_wavlm_large_config_ignores_normalize_and_keep_last_lang_freezes_other_heads():
+    """WavLM Large cfg (lid/conf/xf_asr_extra_finetune.yaml:12): layer_norm extractor without conv bias, pre-LN layers, the gate's
+    parameters; ``normalize`` in the checkpoint cfg is NOT applied (lid/wavlm/example.py:43-45 never normalises).
+    keep_last_lang_model_train (lid/WavLMMutiLangModel.py:114-123) switches requires_grad off for every other head."""
+    from lid.WavLMMutiLangModel import WavLMMutiLangModel
+    m = WavLMMutiLangModel(wavlm_cfg=dict(wc.WAVLM_LARGE_CFG), lang2vocab=wc.L2V, lang2index=wc.L2I, conformer_linear=True,
+                           linear_dim=1024, hidden_dim=64)
+    bb = m.backbone
+    assert bb.pre_ln and bb.ln_extractor and not bb.conv_bias and bb.rel_pos and not bb.normalize
+    assert "model.featurizer.model.feature_extractor.conv_layers.0.0.bias" not in m.state_dict()
+    m.keep_last_lang_model_train("b")
+    for n, p in m.named_parameters():
+        if n.startswith("model.last_projects."):
+            assert p.requires_grad == n.startswith("model.last_projects.b."), n
 
 
 def test_padding_frames_closed_form_equals_forward_padding_mask():
