@@ -364,6 +364,19 @@ int lidk_lid_score(const float* logits, float* scores, int score_stride, int B, 
 /* Greedy CTC decode on the device (CTCTokenizer.ctc_decode, lid/tokenizer.py:55-70): per frame argmax (ties -> lowest index), a
  * frame's symbol is kept iff it is not `blank` and differs from the previous frame's.  logits [B][T][V1] f32; in_len [B]
  * (int64, may be NULL = T frames); ids [B][T] int32 receives the kept symbols of utterance b at ids[b][0..out_len[b]). */
+/* The training step's form of the same loss (lid/LidModule_ASR_Supervised.py:162-168 then ccml/trainer.py:521,531):
+ * lidk_ctc_forward : in_len = (long)(T * wav_pct), tg_len = (long)(Lmax * txt_pct) (f32 products truncated, as the module's
+ *                    `(out.shape[1] * wav_percents).long()`), per-utterance losses loss [B] and their mean loss_mean [1].
+ * lidk_ctc_backward: dlogits [B*T][ld] of `dtype` (columns V1..ld-1 zero) = grad_scale * (*grad_scale_dev, if given) * d loss_b /
+ *                    d logits from the lattices the forward left in `workspace` - written straight in the layout of the
+ *                    vocabulary projection's gradient GEMMs, with the mean's 1/B and autograd's upstream scalar folded in.
+ * LIDK_ERR_UNSUPPORTED when the lattice does not fit LDS (callers use lidk_ctc_loss). */
+int lidk_ctc_forward(const float* logits, const int64_t* targets, const float* wav_pct, const float* txt_pct, int64_t* in_len,
+                     int64_t* tg_len, float* loss, float* loss_mean, void* workspace, int B, int T, int V1, int Lmax, int blank,
+                     int zero_infinity, void* stream);
+int lidk_ctc_backward(const float* logits, const int64_t* targets, const int64_t* in_len, const int64_t* tg_len, void* dlogits,
+                      int ld, int dtype, void* workspace, int B, int T, int V1, int Lmax, int blank, float grad_scale,
+                      const float* grad_scale_dev, void* stream);
 int lidk_ctc_greedy(const float* logits, const int64_t* in_len, int* ids, int* out_len, int B, int T, int V1, int blank,
                     void* stream);
 /* LangDiscriminator.linear on the detached scores (lid/ConformerLangModel.py:374-378,394): out [B,C] =

@@ -467,7 +467,7 @@ class Trainer:
         with ctx:
             batch = self.batch_to_device(batch)
             out = self.train_loop(batch)
-            loss = out["loss"] / acc
+            loss = out["loss"] if acc == 1 else out["loss"] / acc          # (reference: loss / accumulate_grad, ccml/trainer.py:521)
             loss.backward()
         _time_cost_recoder.recoder("forward", time.time() - t0)
         if stepping:

@@ -382,7 +382,9 @@ extern "C" int lidk_attn_ldp(int T_, int dh, int dtype) {
 //                    dq = scale * (dS.K + skew(dS).E)
 //   K2 (per b,h)   : dv = P^T.dO ; dk = scale * dS^T.Q ; dE[r] += scale * sum_i dS[i][i-r] q[i]
 // =====================================================================================================================
-template <int DH>
+// NJM: compile-time bound on the key tiles NJ = Tp / 16 of the call (the score / dP tiles of a row block live in registers:
+// with the bound at 16 for every T the arrays cost 128 VGPRs and the kernel spilled 188 bytes per lane to scratch)
+template <int DH, int NJM>
 __global__ void __launch_bounds__(640)
 attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT, const bf16* __restrict__ probs,
                           const bf16* __restrict__ dout, bf16* __restrict__ dqkv, bf16* __restrict__ dsT, AttGeom g,
@@ -439,10 +441,10 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
         if (i0 + fr < T_) v = *reinterpret_cast<const uint4*>(base + (size_t)(i0 + fr) * g.ld + ks * 32 + fq * 8);
         qf[ks] = *reinterpret_cast<bf16x8*>(&v);
       }
-      float sc[AF_NJ_MAX][4];
+      float sc[NJM][4];
       float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-      for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+      for (int jt = 0; jt < NJM; ++jt) {
         if (jt < NJ) {
           const int j0 = jt * 16;
           f32x4 as = {0.f, 0.f, 0.f, 0.f}, r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
@@ -475,7 +477,7 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
         for (int o = 1; o < 16; o <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
       }
 #pragma unroll
-      for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+      for (int jt = 0; jt < NJM; ++jt) {
         if (jt < NJ) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { float p = __expf(sc[jt][r] - mx[r]); sc[jt][r] = p; sum[r] += p; }
@@ -489,7 +491,7 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
         sum[r] = __builtin_amdgcn_rcpf(sum[r]);
       }
 #pragma unroll
-      for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+      for (int jt = 0; jt < NJM; ++jt) {
         if (jt < NJ) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -505,10 +507,10 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
       dof[ks] = *reinterpret_cast<bf16x8*>(&v);
     }
     __builtin_amdgcn_wave_barrier();
-    float dp[AF_NJ_MAX][4];
+    float dp[NJM][4];
     float delta[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+    for (int jt = 0; jt < NJM; ++jt) {
       if (jt < NJ) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -530,7 +532,7 @@ attn_bwd_rows_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
       if (!probs && fr == 0 && i0 + fq * 4 + r < T_) row_stats[(size_t)g.B * g.H * T_ + bh + i0 + fq * 4 + r] = delta[r];
     }
 #pragma unroll
-    for (int jt = 0; jt < AF_NJ_MAX; ++jt) {
+    for (int jt = 0; jt < NJM; ++jt) {
       if (jt < NJ) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -696,8 +698,8 @@ attn_bwd_cols_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__
 // A operands of dV += P^T.dO and dK += dS^T.Q (slot-permuted MFMA, common.h tr_frag_split): no probabilities, no dS and nothing
 // transposed is read from HBM or staged through LDS.  (dE, the embedding table's gradient, stays with the PART-2 launch of
 // attn_bwd_cols_mfma_kernel on the weight-gradient stream, fed by the dS rows the row kernel writes.)
-template <int DH>
-__global__ void __launch_bounds__(1024)
+template <int DH, int MAXW>      // MAXW: waves per workgroup the call may use (T <= 160: 10 waves, 170 VGPRs each instead of 128)
+__global__ void __launch_bounds__(64 * MAXW)
 attn_bwd_kv_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ embT, const bf16* __restrict__ dout,
                         const float* __restrict__ row_stats, bf16* __restrict__ dqkv, AttGeom g, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -825,16 +827,33 @@ static void att_bwd_mfma_launch(const void* qkv, const void* embT, const void* p
   size_t l1 = att_bwd_rows_mfma_lds(g.T, DH, nw), l2 = att_bwd_cols_mfma_lds(g.T, DH);
   // row statistics (log-sum-exp, delta) of the recompute path live behind the bf16 dS rows in the caller's f32 scratch
   float* row_stats = reinterpret_cast<float*>(dsT) + (size_t)g.B * g.H * g.T * ldp / 2;
-  (void)hipFuncSetAttribute((const void*)attn_bwd_rows_mfma_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
-  attn_bwd_rows_mfma_kernel<DH><<<g.B * g.H, 64 * nw, l1, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)probs,
-                                                           (const bf16*)dout, (bf16*)dqkv, (bf16*)dsT, g, ldp, scale, row_stats);
   const int Tp = (g.T + 31) / 32 * 32;
+#define LIDK_ROWS_LAUNCH(NJM_)                                                                                                  \
+  do {                                                                                                                         \
+    (void)hipFuncSetAttribute((const void*)attn_bwd_rows_mfma_kernel<DH, NJM_>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                              (int)l1);                                                                                        \
+    attn_bwd_rows_mfma_kernel<DH, NJM_><<<g.B * g.H, 64 * nw, l1, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)probs, \
+                                                                     (const bf16*)dout, (bf16*)dqkv, (bf16*)dsT, g, ldp, scale, \
+                                                                     row_stats);                                               \
+  } while (0)
+  if (Tp <= 64) LIDK_ROWS_LAUNCH(4);
+  else if (Tp <= 128) LIDK_ROWS_LAUNCH(8);
+  else if (Tp <= 160) LIDK_ROWS_LAUNCH(10);
+  else if (Tp <= 192) LIDK_ROWS_LAUNCH(12);
+  else LIDK_ROWS_LAUNCH(16);
+#undef LIDK_ROWS_LAUNCH
   if (!probs) {                                      // recompute path: dK / dV from recomputed tiles, then (optionally) dE
     const size_t l3 = att_bwd_kv_mfma_lds(g.T, DH);
     const int nwk = min(16, max(4, Tp / 16));
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_mfma_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3);
-    attn_bwd_kv_mfma_kernel<DH><<<g.B * g.H, 64 * nwk, l3, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)dout, row_stats,
-                                                            (bf16*)dqkv, g, scale);
+    if (nwk <= 10) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_kv_mfma_kernel<DH, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3);
+      attn_bwd_kv_mfma_kernel<DH, 10><<<g.B * g.H, 64 * nwk, l3, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)dout,
+                                                                    row_stats, (bf16*)dqkv, g, scale);
+    } else {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_kv_mfma_kernel<DH, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3);
+      attn_bwd_kv_mfma_kernel<DH, 16><<<g.B * g.H, 64 * nwk, l3, s>>>((const bf16*)qkv, (const bf16*)embT, (const bf16*)dout,
+                                                                    row_stats, (bf16*)dqkv, g, scale);
+    }
     if (demb) {
       const void* np = nullptr; const void* nd = nullptr; void* nq = nullptr;
       const int nwc = min(16, max(4, 2 * Tp / 16 / 2));

@@ -171,12 +171,16 @@ colreduce_kernel(const float* __restrict__ partial, int nparts, int ncols, TOUT*
   }
   red[w][lane] = acc;
   __syncthreads();
-  if (w == 0 && lane < 16 && c < ncols) {
-    ACC s = 0;
+  if (w != 0) return;
+  // second stage on the whole first wave: lane (sub, column) adds its quarter's 16 rows, the four quarters meet by two xor
+  // shuffles (fixed order: deterministic).  (One lane per column adding all 64 values serially cost the f64 instantiation 68
+  // bytes of scratch per lane under the 1024-thread register cap.)
+  ACC s = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) s += red[i][q * 16 + lane];
+  for (int i = 0; i < 16; ++i) s += red[i][lane];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  if (lane < 16 && c < ncols) {
     TOUT* dst = (c < split) ? (out0 ? out0 + c : nullptr) : (out1 ? out1 + (c - split) : nullptr);
     if (dst) *dst = ACCUM ? (TOUT)(*dst + (TOUT)scale * (TOUT)s) : (TOUT)s;
     if (dup) dup[c] = (TOUT)s;

@@ -198,7 +198,51 @@ ctc_lattice_kernel(const int64_t* __restrict__ targets, const int64_t* __restric
     if (tid == 0) { float v = (Lb == 0) ? 0.f : INFINITY; ws.nll[b] = v; loss[b] = (v == INFINITY && zero_inf) ? 0.f : v; }
     return;
   }
-  if (wave == 0) {                                   // alpha, forwards
+  if (S <= 64 && wave < 2) {
+    // One lane per lattice state: the previous row lives in a register and the neighbours s -+ 1, s -+ 2 come by wave shuffles -
+    // no LDS ping-pong and no barrier inside the only sequential loop of the loss (T steps of ~150 clocks instead of ~800).
+    const int s = lane;
+    const bool in = s < S;
+    if (wave == 0) {                                 // alpha, forwards
+      float* ga = ws.alpha + (size_t)b * T_ * Smax;
+      const bool skip = in && s >= 2 && (s & 1) && lab[s] != lab[s - 2];
+      float a = (in && s < 2) ? lp[s] : NEG_INF;
+      if (in) ga[s] = a;
+      float nxt_lp = (in && Tb > 1) ? lp[(size_t)Smax + s] : 0.f;
+      for (int t = 1; t < Tb; ++t) {
+        const float lpt = nxt_lp;
+        if (in && t + 1 < Tb) nxt_lp = lp[(size_t)(t + 1) * Smax + s];
+        float a1 = __shfl_up(a, 1, 64), a2 = __shfl_up(a, 2, 64);
+        if (s < 1) a1 = NEG_INF;
+        if (!skip) a2 = NEG_INF;
+        const float v = lse3(a, a1, a2) + lpt;
+        a = in ? v : NEG_INF;
+        if (in) ga[(size_t)t * Smax + s] = a;
+      }
+      const float e1 = __shfl(a, S - 1, 64), e2 = __shfl(a, S >= 2 ? S - 2 : 0, 64);
+      if (lane == 0) {
+        float nll = -lse2(e1, S >= 2 ? e2 : NEG_INF);
+        ws.nll[b] = nll;
+        loss[b] = (nll == INFINITY && zero_inf) ? 0.f : nll;
+      }
+    } else {                                         // beta, backwards
+      float* gb = ws.beta + (size_t)b * T_ * Smax;
+      const bool skip = in && s + 2 < S && (s & 1) && lab[s] != lab[s + 2];
+      float a = (in && s >= S - 2) ? lp[(size_t)(Tb - 1) * Smax + s] : NEG_INF;
+      if (in) gb[(size_t)(Tb - 1) * Smax + s] = a;
+      float nxt_lp = (in && Tb > 1) ? lp[(size_t)(Tb - 2) * Smax + s] : 0.f;
+      for (int t = Tb - 2; t >= 0; --t) {
+        const float lpt = nxt_lp;
+        if (in && t > 0) nxt_lp = lp[(size_t)(t - 1) * Smax + s];
+        float b1 = __shfl_down(a, 1, 64), b2 = __shfl_down(a, 2, 64);
+        if (s + 1 >= S) b1 = NEG_INF;
+        if (!skip) b2 = NEG_INF;
+        const float v = lse3(a, b1, b2) + lpt;
+        a = in ? v : NEG_INF;
+        if (in) gb[(size_t)t * Smax + s] = a;
+      }
+    }
+  } else if (wave == 0) {                            // alpha, forwards
     float* ga = ws.alpha + (size_t)b * T_ * Smax;
     float* cur = rowbuf; float* prv = rowbuf + Smax;
     for (int s = lane; s < S; s += 64) { float v = (s < 2) ? lp[s] : NEG_INF; cur[s] = v; ga[s] = v; }
@@ -247,11 +291,13 @@ ctc_lattice_kernel(const int64_t* __restrict__ targets, const int64_t* __restric
   }
 }
 
-// dynamic LDS per wave: post[Smax] | corr[V1]
+// dynamic LDS per wave: post[Smax] | corr[V1].  dlogits [rows][ld] of T (columns V1 .. ld-1, the GEMM operand's padding, are
+// written as zero); gscale_dev (optional): a device scalar multiplied into gscale - the upstream gradient of the mean loss.
+template <typename T>
 __global__ void __launch_bounds__(256)
 ctc_grad_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets, const int64_t* __restrict__ in_len,
-                const int64_t* __restrict__ tg_len, float* __restrict__ dlogits, CtcWs ws, int rows, int T_, int V1, int Lmax,
-                int blank, float gscale) {
+                const int64_t* __restrict__ tg_len, T* __restrict__ dlogits, int ld, CtcWs ws, int rows, int T_, int V1, int Lmax,
+                int blank, float gscale, const float* __restrict__ gscale_dev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Smax = 2 * Lmax + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = blockIdx.x * 4 + wave;
@@ -259,11 +305,12 @@ ctc_grad_kernel(const float* __restrict__ logits, const int64_t* __restrict__ ta
   float* post = reinterpret_cast<float*>(smem) + (size_t)wave * (Smax + V1);
   float* corr = post + Smax;
   const int b = row / T_, t = row - b * T_;
-  float* dl = dlogits + (size_t)row * V1;
+  T* dl = dlogits + (size_t)row * ld;
+  if (gscale_dev) gscale *= *gscale_dev;
   int Tb = (int)in_len[b]; if (Tb > T_) Tb = T_; if (Tb < 0) Tb = 0;
   const float nll = ws.nll[b];
   if (t >= Tb || nll == INFINITY || nll != nll) {    // padded frame, or zero_infinity: zero gradient as torch does
-    for (int c = lane; c < V1; c += 64) dl[c] = 0.f;
+    for (int c = lane; c < ld; c += 64) dl[c] = from_f<T>(0.f);
     return;
   }
   int Lb = (int)tg_len[b]; if (Lb > Lmax) Lb = Lmax; if (Lb < 0) Lb = 0;
@@ -282,7 +329,24 @@ ctc_grad_kernel(const float* __restrict__ logits, const int64_t* __restrict__ ta
   __builtin_amdgcn_wave_barrier();
   const float* lg = logits + (size_t)row * V1;
   const float l = ws.lse[row];
-  for (int c = lane; c < V1; c += 64) dl[c] = gscale * (__expf(lg[c] - l) - corr[c]);
+  for (int c = lane; c < ld; c += 64) dl[c] = from_f<T>(c < V1 ? gscale * (__expf(lg[c] - l) - corr[c]) : 0.f);
+}
+
+// in_len[b] = (long)(T * wav_pct[b]), tg_len[b] = (long)(Lmax * txt_pct[b]) in f32, truncated toward zero - the module's
+// ``(out.shape[1] * wav_percents).long()`` / ``(texts.shape[-1] * text_percents).long()`` (lid/LidModule_ASR_Supervised.py:163-166)
+__global__ void ctc_lengths_kernel(const float* __restrict__ wav_pct, const float* __restrict__ txt_pct, int64_t* __restrict__ in_len,
+                                   int64_t* __restrict__ tg_len, int B, int T_, int Lmax) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  in_len[b] = (int64_t)((float)T_ * wav_pct[b]);
+  tg_len[b] = (int64_t)((float)Lmax * txt_pct[b]);
+}
+// mean of the per-utterance losses (reduction='none' then .mean(), :167-168), one wave
+__global__ void __launch_bounds__(64) ctc_mean_kernel(const float* __restrict__ loss, float* __restrict__ mean, int B) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 64) s += loss[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) *mean = s / (float)B;
 }
 
 extern "C" int lidk_ctc_loss(const float* logits, const int64_t* targets, const int64_t* in_len, const int64_t* tg_len,
@@ -302,9 +366,9 @@ extern "C" int lidk_ctc_loss(const float* logits, const int64_t* targets, const 
     (void)hipFuncSetAttribute((const void*)ctc_lattice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);
     ctc_lattice_kernel<<<B, 192, fast, st>>>(targets, in_len, tg_len, loss, ws, T_, Lmax, blank, zero_infinity);
     if (dlogits) {
-      (void)hipFuncSetAttribute((const void*)ctc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
-      ctc_grad_kernel<<<(rows + 3) / 4, 256, glds, st>>>(logits, targets, in_len, tg_len, dlogits, ws, rows, T_, V1, Lmax, blank,
-                                                         grad_scale);
+      (void)hipFuncSetAttribute((const void*)ctc_grad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+      ctc_grad_kernel<float><<<(rows + 3) / 4, 256, glds, st>>>(logits, targets, in_len, tg_len, dlogits, V1, ws, rows, T_, V1, Lmax,
+                                                                blank, grad_scale, nullptr);
     }
     return launch_status();
   }
@@ -313,6 +377,48 @@ extern "C" int lidk_ctc_loss(const float* logits, const int64_t* targets, const 
   (void)hipFuncSetAttribute((const void*)ctc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   ctc_kernel<<<B, 256, lds, as_stream(stream)>>>(logits, targets, in_len, tg_len, loss, dlogits, (float*)workspace, T_, V1,
                                                  Lmax, blank, grad_scale, zero_infinity);
+  return launch_status();
+}
+
+// The training step's form of the same loss (lid/LidModule_ASR_Supervised.py:162-168 + ccml/trainer.py:521,531): lengths from the
+// batch's percents, per-utterance losses AND their mean in one call; the gradient is produced later, at backward time, straight
+// into the T-typed, column-padded operand of the vocabulary projection's data / weight gradient GEMMs, scaled by
+// grad_scale * (*grad_scale_dev) - the upstream gradient autograd hands the mean (1 / accumulate_grad).  Fast path only
+// (LIDK_ERR_UNSUPPORTED when the lattice does not fit LDS: callers fall back to lidk_ctc_loss).
+extern "C" int lidk_ctc_forward(const float* logits, const int64_t* targets, const float* wav_pct, const float* txt_pct,
+                                int64_t* in_len, int64_t* tg_len, float* loss, float* loss_mean, void* workspace, int B, int T_, int V1,
+                                int Lmax, int blank, int zero_infinity, void* stream) {
+  if (!logits || !targets || !wav_pct || !txt_pct || !in_len || !tg_len || !loss || !loss_mean || !workspace || B <= 0 || T_ <= 0 ||
+      V1 <= 1 || Lmax <= 0 || blank < 0 || blank >= V1)
+    return LIDK_ERR_ARG;
+  const int Smax = 2 * Lmax + 1;
+  const size_t fast = ((size_t)T_ * Smax + 4 * Smax) * sizeof(float) + (size_t)Smax * sizeof(int);
+  if (fast > 150 * 1024 || (size_t)4 * (Smax + V1) * sizeof(float) > 150 * 1024) return LIDK_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  CtcWs ws = ctc_ws(workspace, B, T_, Smax);
+  const int rows = B * T_;
+  ctc_lengths_kernel<<<cdiv(B, 64), 64, 0, st>>>(wav_pct, txt_pct, in_len, tg_len, B, T_, Lmax);
+  ctc_prep_kernel<<<(rows + 3) / 4, 256, 0, st>>>(logits, targets, tg_len, ws.lse, ws.lpl, rows, T_, V1, Lmax, blank);
+  (void)hipFuncSetAttribute((const void*)ctc_lattice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast);
+  ctc_lattice_kernel<<<B, 192, fast, st>>>(targets, in_len, tg_len, loss, ws, T_, Lmax, blank, zero_infinity);
+  ctc_mean_kernel<<<1, 64, 0, st>>>(loss, loss_mean, B);
+  return launch_status();
+}
+extern "C" int lidk_ctc_backward(const float* logits, const int64_t* targets, const int64_t* in_len, const int64_t* tg_len,
+                                 void* dlogits, int ld, int dtype, void* workspace, int B, int T_, int V1, int Lmax, int blank,
+                                 float grad_scale, const float* grad_scale_dev, void* stream) {
+  if (!logits || !targets || !in_len || !tg_len || !dlogits || !workspace || B <= 0 || T_ <= 0 || V1 <= 1 || ld < V1 || Lmax <= 0)
+    return LIDK_ERR_ARG;
+  const int Smax = 2 * Lmax + 1;
+  const size_t glds = (size_t)4 * (Smax + V1) * sizeof(float);
+  if (glds > 150 * 1024) return LIDK_ERR_UNSUPPORTED;
+  CtcWs ws = ctc_ws(workspace, B, T_, Smax);
+  const int rows = B * T_;
+  LIDK_DISPATCH(dtype, {
+    (void)hipFuncSetAttribute((const void*)ctc_grad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+    ctc_grad_kernel<T><<<(rows + 3) / 4, 256, glds, as_stream(stream)>>>(logits, targets, in_len, tg_len, (T*)dlogits, ld, ws, rows, T_,
+                                                                        V1, Lmax, blank, grad_scale, grad_scale_dev);
+  });
   return launch_status();
 }
 

@@ -47,19 +47,30 @@ class _EngineFn(torch.autograd.Function):
     """Autograd node for the whole network: forward = Engine.forward, backward = Engine.backward."""
 
     @staticmethod
-    def forward(ctx, anchor, feats, model, lang, keep, masks):
-        out = model.lidk_engine.forward(feats, lang, True, keep, masks)[lang]
-        ctx.model, ctx.lang, ctx.keep = model, lang, keep
-        return out
+    def forward(ctx, anchor, feats, model, lang, keep, masks, ctc=None):
+        """ctc = (texts, wav_percents, text_percents) (``forward_ctc``): the mean CTC loss of the module's training loop rides
+        in the same node - outputs (logits, loss, in_len, tg_len), only the loss differentiable."""
+        eng = model.lidk_engine
+        out = eng.forward(feats, lang, True, keep, masks)[lang]
+        ctx.model, ctx.lang, ctx.keep, ctx.ctc = model, lang, keep, False
+        if ctc is None:
+            return out
+        res = eng.ctc_forward(out, ctc[0], ctc[1], ctc[2], model.cfg.lang2vocab[lang])
+        if res is None:                                  # lattice too large for the fused kernels: the caller takes CtcLossFn
+            return out
+        loss, in_len, tg_len = res
+        ctx.ctc = True
+        ctx.mark_non_differentiable(out, in_len, tg_len)
+        return out, loss, in_len, tg_len
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, dlogits, gloss=None, _g_in=None, _g_tg=None):
         model = ctx.model
-        dfeat = model.lidk_engine.backward(dlogits)
+        dfeat = model.lidk_engine.backward(None, ctc_gscale=gloss) if ctx.ctc else model.lidk_engine.backward(dlogits)
         model._publish_grads(ctx.lang, ctx.keep)
         if dfeat is not None and hasattr(model, "_backbone_backward"):      # features front: the backbone's own backward
             model._backbone_backward(dfeat)
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
 class CtcLossFn(torch.autograd.Function):
@@ -144,6 +155,38 @@ class _EngineBoundModel(nn.Module):
 
     def _moved(self, device):
         pass
+
+    def _engine_apply(self, feats, lang, keep, masks):
+        """The autograd node of the whole network; with a pending ``forward_ctc`` request the mean CTC loss rides in it."""
+        req = getattr(self, "_ctc_request", None)
+        res = _EngineFn.apply(self._anchor, feats, self, lang, keep, masks, req)
+        if isinstance(res, tuple):
+            self._ctc_result = res[1:]
+            return res[0]
+        return res
+
+    def forward_ctc(self, x, sample_rate: int, lang: str, texts, wav_percents, text_percents):
+        """``model(x, sample_rate, lang)`` + the training loop's loss (lid/LidModule_ASR_Supervised.py:160-168: CTCLoss(reduction=
+        'none', zero_infinity)(log_softmax(out).T, texts, (T * wav_percents).long(), (L * text_percents).long()).mean()) as ONE
+        autograd node: -> (logits (B, T, V+1), loss 0-dim, in_len, tg_len).  Same numbers as the two-step route (forward, then
+        ``CtcLossFn`` + ``.mean()``), which is what runs in eval mode, without gradients, on the CPU test backend and for lattices
+        beyond the fused kernels' LDS budget."""
+        blank = self.cfg.lang2vocab[lang]
+        self._ctc_request, self._ctc_result = None, None
+        if self.training and torch.is_grad_enabled() and self.lidk_engine.ctc_supported():
+            self._ctc_request = (texts, wav_percents, text_percents)
+        try:
+            out, _ = self.forward(x, sample_rate, lang)
+        finally:
+            self._ctc_request = None
+        out = out[lang]
+        if self._ctc_result is not None:
+            (loss, in_len, tg_len), self._ctc_result = self._ctc_result, None
+            return out, loss, in_len, tg_len
+        in_len = (out.shape[1] * wav_percents).long()
+        tg_len = (texts.shape[-1] * text_percents).long()
+        per_utt = CtcLossFn.apply(out, texts, in_len, tg_len, blank, self.lidk_engine.k)
+        return out, per_utt.mean(), in_len, tg_len
 
     def set_compute_dtype(self, dtype):
         """bf16 (production) or f32 (parity mode); must be chosen before the model is moved to the GPU."""
@@ -248,7 +291,7 @@ class ConformerMutiLangModel(_EngineBoundModel):
             if self._anchor is None or self._anchor.device != feats.device:
                 self._anchor = torch.zeros(1, device=feats.device, requires_grad=True)
             keep = self._layer_keep()
-            logits = _EngineFn.apply(self._anchor, feats, self, lang, keep, self.forced_masks)
+            logits = self._engine_apply(feats, lang, keep, self.forced_masks)
             return {lang: logits}, (None, None)
         out = eng.forward(feats, lang, self.training, self._layer_keep() if self.training else None, self.forced_masks)
         out = {k: v.clone() for k, v in out.items()}          # the engine reuses its logits buffers on the next call

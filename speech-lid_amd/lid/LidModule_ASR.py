@@ -116,12 +116,8 @@ class LidModule(CCMLModule):
         # int(langs[0]) on the device tensor is a blocking read behind everything queued, i.e. one full host-device sync per step
         lang = self.index2lang_dict[int(getattr(langs, "_host", langs)[0])]
         wavs = self._prepare_wavs(wavs, train_stat and self.model.training)
-        out, _ = self.model(wavs, self.sr, lang)
-        out = out[lang]
-        in_len = (out.shape[1] * wav_percents).long()
-        tg_len = (texts.shape[-1] * text_percents).long()
-        per_utt = CtcLossFn.apply(out, texts, in_len, tg_len, self.model.cfg.lang2vocab[lang], self.model.lidk_engine.k)
-        loss = per_utt.mean()
+        # forward + CTCLoss(reduction='none', zero_infinity)(...).mean() (reference :185-192); in training one autograd node
+        out, loss, in_len, tg_len = self.model.forward_ctc(wavs, self.sr, lang, texts, wav_percents, text_percents)
         # greedy transcripts: every step, or in extrme_mode only every 20th training step (reference :200-216)
         if self.countdown_20 == 0 or (self.predict_texts is None or not self.extrme_mode) or not train_stat:
             self.countdown_20 = 20

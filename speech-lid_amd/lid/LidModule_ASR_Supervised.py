@@ -79,12 +79,8 @@ class LidSuperviseModule(CCMLModule):
         wavs, texts, wav_percents, text_percents, langs = batch[0], batch[1], batch[2], batch[3], batch[5]
         lang_id = getattr(wavs, "lang_id", None)                          # host-side metadata: no device sync
         lang = self.index2lang_dict[int(getattr(langs, "_host", langs)[0]) if lang_id is None else lang_id]   # single-language batches (Q7)
-        out, _ = self.model(wavs, self.sr, lang)
-        out = out[lang]
-        in_len = (out.shape[1] * wav_percents).long()
-        tg_len = (texts.shape[-1] * text_percents).long()
-        per_utt = CtcLossFn.apply(out, texts, in_len, tg_len, self.model.cfg.lang2vocab[lang], self.model.lidk_engine.k)
-        loss = per_utt.mean()
+        # forward + CTCLoss(reduction='none', zero_infinity)(...).mean() (reference :160-168); in training one autograd node
+        out, loss, in_len, tg_len = self.model.forward_ctc(wavs, self.sr, lang, texts, wav_percents, text_percents)
         res = {"loss": loss, "wer": self._last_wer, "lang": lang, "predict_texts": [], "label_texts": []}
         if with_text:
             tok = self.tokenizer_dict[lang]

@@ -163,7 +163,7 @@ class WavLMMutiLangModel(_EngineBoundModel):
         if grad_path:
             if self._anchor is None or self._anchor.device != feats.device:
                 self._anchor = torch.zeros(1, device=feats.device, requires_grad=True)
-            logits = _EngineFn.apply(self._anchor, feats, self, lang, [], self.forced_masks)
+            logits = self._engine_apply(feats, lang, [], self.forced_masks)
             return {lang: logits}, (None, None)
         out = eng.forward(feats, lang, self.training, None, self.forced_masks)
         out = {k: v.clone() for k, v in out.items()}

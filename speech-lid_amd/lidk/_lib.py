@@ -10,6 +10,7 @@ LN_PARTIAL_BLOCKS = 256
 LN_BWD_BLOCKS = 1024
 BN_PARTIAL_BLOCKS = 1024
 OPT_CHUNK = 8192
+ERR_UNSUPPORTED = -3
 
 
 class LidkError(RuntimeError):
@@ -132,6 +133,8 @@ SIGNATURES = {
     "lidk_xattn_max_frames": (_I, [_I]),
     "lidk_xattn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _U64, _I, _I, _I, _I, _I, _P]),
     "lidk_xattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "lidk_ctc_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "lidk_ctc_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P]),
     "lidk_ctc_greedy": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "lidk_lid_mlp": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "lidk_novograd_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _I, _F, _P, _P, _P]),

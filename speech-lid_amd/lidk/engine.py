@@ -210,8 +210,9 @@ class _Work:
         # LIDK_SCRATCH_SETS=3: a third set lets the whole-chain backward leave the weight-gradient stream alone until the end of
         # a block (with two sets the fused LayerNorm pair at a block's tail writes into the set the previous block's weight
         # gradients are still reading, so the data-gradient chain joins the second stream before it: a second cross-queue hop per
-        # block in the captured graph).  Measured: 7.39 / 7.30 vs 7.39 / 7.36 ms per step - within noise, so the default stays 2.
-        for _ in range(max(2, int(_os_env("LIDK_SCRATCH_SETS", "2")))):
+        # block in the captured graph).  Round 3: 7.39 / 7.30 vs 7.39 / 7.36 ms per step - within noise; round 4, with the
+        # data-gradient chain as the critical path: 6.852 / 6.854 vs 6.89 / 6.90 (same box, two rounds each): the default is 3.
+        for _ in range(max(2, int(_os_env("LIDK_SCRATCH_SETS", "3")))):
             S = _Set()
             S.da = [e(M, ff), e(M, ff)]                       # ff2 / ff1 hidden gradients
             S.dy1 = e(M, 2 * ci)                              # conv pointwise-1 output gradient
@@ -732,6 +733,33 @@ class Engine:
         self._forced_masks = {}
         return out
 
+    # ------------------------------------------------------------------ CTC loss fused behind the training forward
+    def ctc_supported(self) -> bool:
+        return bool(self._hip and hasattr(self.k, "ctc_forward") and _os_env("LIDK_CTC_FUSED", "1") == "1")
+
+    def ctc_forward(self, logits: torch.Tensor, texts: torch.Tensor, wav_pct: torch.Tensor, txt_pct: torch.Tensor, blank: int):
+        """Mean CTC loss of the last training forward's logits (lid/LidModule_ASR_Supervised.py:162-168): lengths from the batch's
+        percents, the three CTC launches and the mean - 5 launches, no torch elementwise kernels; the lattices stay in the
+        workspace and ``backward(None, ctc_gscale=...)`` turns them into the vocabulary projection's gradient operand.
+        -> (loss 0-dim f32, in_len, tg_len) or None when the lattice does not fit the fast path."""
+        w = self._ctx["w"]
+        B, T, V1 = logits.shape
+        texts = texts.contiguous()
+        Lmax = texts.shape[1]
+        key = ("ctc", B, T, V1, Lmax)
+        c = w.__dict__.setdefault("_ctc_bufs", {}).get(key)
+        if c is None:
+            dev = logits.device
+            c = w._ctc_bufs[key] = dict(ws=torch.empty(max(self.k.ctc_workspace_bytes(B, T, V1, Lmax) // 4, 1), device=dev),
+                                        in_len=torch.empty(B, device=dev, dtype=torch.int64),
+                                        tg_len=torch.empty(B, device=dev, dtype=torch.int64), per=torch.empty(B, device=dev))
+        mean = torch.empty(1, device=logits.device)                # a fresh scalar per step: callers keep the losses they are handed
+        if not self.k.ctc_forward(logits, texts, wav_pct.float().contiguous(), txt_pct.float().contiguous(), c["in_len"], c["tg_len"],
+                                  c["per"], mean, c["ws"], blank):
+            return None
+        self._ctc = dict(c, logits=logits, texts=texts, blank=blank, B=B)
+        return mean.view(()), c["in_len"], c["tg_len"]
+
     # ------------------------------------------------------------------ backward pieces
     @staticmethod
     def _splitk(n, k):
@@ -1036,8 +1064,11 @@ class Engine:
             if self.on_stage_grads_ready:
                 self.on_stage_grads_ready(prev[4])
 
-    def backward(self, dlogits: torch.Tensor):
-        """dlogits (B, T, V+1) f32 for the language of the last training forward.  Accumulates into ``grad``."""
+    def backward(self, dlogits: Optional[torch.Tensor], ctc_gscale: Optional[torch.Tensor] = None):
+        """dlogits (B, T, V+1) f32 for the language of the last training forward.  Accumulates into ``grad``.
+        ctc_gscale (with dlogits None): the upstream gradient of the mean loss ``ctc_forward`` returned - a device scalar; the CTC
+        gradient kernel then writes the operand of the vocabulary projection's gradient GEMMs itself (T-typed, padded columns
+        zero, scaled by ctc_gscale / B): no f32 dlogits tensor, no converting copy."""
         ctx = self._ctx
         if not ctx["training"] or ctx["lang"] is None:
             raise LidkError("Engine.backward needs a preceding training-mode forward with a single language")
@@ -1045,12 +1076,20 @@ class Engine:
         M, d = w.M, cfg.d
         v1 = cfg.lang2vocab[lang] + 1
         v1p = _ceil(v1, 8)
-        dl = dlogits.contiguous().view(M, v1)
         p = f"model.last_projects.{lang}.linear"
         dlT = w.dlT.view(-1)[:M * v1p].view(M, v1p)
-        if v1p != v1:
-            dlT.zero_()
-        self.k.scale_cast_2d(dl, dlT, M, v1)
+        if dlogits is None:
+            c = getattr(self, "_ctc", None)
+            if c is None or ctc_gscale is None or c["logits"].shape[-1] != v1:
+                raise LidkError("Engine.backward(None): needs a preceding ctc_forward of the same step and its upstream gradient")
+            self.k.ctc_backward(c["logits"], c["texts"], c["in_len"], c["tg_len"], dlT, c["ws"], c["blank"], 1.0 / c["B"],
+                                ctc_gscale.reshape(1).float())
+            self._ctc = None
+        else:
+            dl = dlogits.contiguous().view(M, v1)
+            if v1p != v1:
+                dlT.zero_()
+            self.k.scale_cast_2d(dl, dlT, M, v1)
         # vocabulary projection
         self._wgrad(w, dlT, w.head_h, self.gview(p + ".weight"), v1, d, self.gview(p + ".bias"))
         self.k.gemm_nt(dlT, self.wview(p + ".weight")[1][:, :v1p], w.dh, N=d, K=v1p)

@@ -664,6 +664,26 @@ def ctc_loss(logits, targets, in_len, tg_len, loss, dlogits, workspace, blank, g
                               V1, Lmax, blank, grad_scale, int(zero_infinity), _stream()), "ctc_loss")
 
 
+def ctc_forward(logits, targets, wav_pct, txt_pct, in_len, tg_len, loss, loss_mean, workspace, blank, zero_infinity=True):
+    """Lengths from the batch's percents, per-utterance losses and their mean; the lattices stay in ``workspace`` for
+    ``ctc_backward``.  Returns False when the fast path does not apply (the caller then uses ``ctc_loss``)."""
+    B, T, V1 = logits.shape
+    rc = lib().lidk_ctc_forward(_p(logits), _p(targets), _p(wav_pct), _p(txt_pct), _p(in_len), _p(tg_len), _p(loss), _p(loss_mean),
+                                _p(workspace), B, T, V1, targets.shape[1], blank, int(zero_infinity), _stream())
+    if rc == L.ERR_UNSUPPORTED:
+        return False
+    check(rc, "ctc_forward")
+    return True
+
+
+def ctc_backward(logits, targets, in_len, tg_len, dlogits, workspace, blank, grad_scale=1.0, grad_scale_dev=None):
+    """dlogits (B*T, ld) bf16 / f32, pad columns zeroed: grad_scale * grad_scale_dev[0] * d loss_b / d logits."""
+    B, T, V1 = logits.shape
+    check(lib().lidk_ctc_backward(_p(logits), _p(targets), _p(in_len), _p(tg_len), _p(dlogits), dlogits.stride(0), _code(dlogits),
+                                  _p(workspace), B, T, V1, targets.shape[1], blank, grad_scale, _p(grad_scale_dev), _stream()),
+          "ctc_backward")
+
+
 def lid_score(logits, scores_col, stride, blank):
     """scores_col: 1-element-offset view into a (B, n_lang) f32 matrix column; stride = n_lang."""
     B, T, V1 = logits.shape

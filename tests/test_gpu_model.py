@@ -258,3 +258,46 @@ def test_baseline_cfg2_depth_against_the_oracle(dt):
     print(f"[cfg2-depth grads {dt}] worst_cos={worst_cos:.6f} worst_rel_l2={worst_rel:.3e}")
     assert worst_cos >= (0.999999 if dt == torch.float32 else 0.99)
     assert worst_rel <= (5e-4 if dt == torch.float32 else 0.15)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fused_ctc_node_equals_the_two_step_route(dt, monkeypatch):
+    """``forward_ctc`` (engine forward + lengths + CTC + mean as one autograd node, the CTC gradient written at backward time
+    straight into the vocabulary projection's operand with the upstream scalar folded in) against the two-step route the module
+    used before (forward, ``CtcLossFn``, ``.mean()``, torch's autograd in between): ragged lengths, an upstream gradient != 1
+    (accumulate_grad = 2), same loss, same lengths, same gradients."""
+    from lid.LidModule_ASR_Supervised import LidSuperviseModule
+    from lid.tokenizer import CTCTokenizer
+    l2v, l2i = {"a": 30, "b": 40, "c": 50}, {"a": 0, "b": 1, "c": 2}
+    toks = {k: CTCTokenizer([chr(0x4E00 + i) for i in range(v)]) for k, v in l2v.items()}
+    g = torch.Generator().manual_seed(11)
+    mel = torch.randn(6, 101, 80, generator=g).to(DEV)
+    texts = torch.randint(0, 40, (6, 9), generator=g).to(DEV)
+    wp = torch.tensor([1.0, 0.52, 0.8, 0.33, 1.0, 0.9], device=DEV)
+    tp = torch.tensor([1.0, 0.45, 0.7, 0.25, 0.9, 1.0], device=DEV)
+    langs = torch.full((6,), 1, device=DEV)
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("LIDK_CTC_FUSED", fused)
+        torch.manual_seed(0)
+        mod = LidSuperviseModule(optimizer_name="novograd", optimizer_param={"lr": 0.01}, scheduler="none", lang2index_dict=l2i,
+                                 tokenizer_dict=toks, lang2vocab=l2v, dropout=0.0, linear_dim=64, n_blocks=2, encoder_dim=64,
+                                 dim_head=16, last_dim_head=8, heads=4)
+        m = mod.model
+        m.set_compute_dtype(dt)
+        m.lidk_engine.cfg.pos_dropout = 0.0
+        m.use_stochastic_depth = False
+        m.to(DEV).train()
+        assert m.lidk_engine.ctc_supported() == (fused == "1")
+        m.zero_grad()
+        out = mod.common_loop([mel, texts, wp, tp, ["x"] * 6, langs], with_text=True)
+        (out["loss"] / 2).backward()
+        torch.cuda.synchronize()
+        res[fused] = (float(out["loss"]), out["predict_texts"], {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    (l1, t1, g1), (l0, t0, g0) = res["1"], res["0"]
+    print(f"[fused ctc {dt}] loss {l1:.6f} vs {l0:.6f}; {len(g1)} gradient tensors")
+    assert abs(l1 - l0) <= 2e-6 * abs(l0) and t1 == t0 and g1.keys() == g0.keys() and len(g1) > 40
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    for k in g1:
+        scale = float(g0[k].abs().max()) + 1e-12
+        assert float((g1[k] - g0[k]).abs().max()) <= tol * scale, (k, float((g1[k] - g0[k]).abs().max()), scale)
