@@ -441,22 +441,29 @@ class Trainer:
         else:
             self.lr_scheduler.step()
 
-    def prefetch(self, batch):
+    def prefetch(self, batch, after=None):
         """Move an upcoming batch to the device and start its GPU feature extraction on the feature stream, so it overlaps
-        the training step that is about to be issued (the batch keeps the result; its ``to_mel`` waits for it)."""
+        the training step in flight (the batch keeps the result; its ``to_mel`` waits for it).  ``after``: an event of the main
+        stream the feature work is ordered behind (the engine's "logits done": the kernels then run beside the CTC lattice and
+        the first backward launches, which leave most of the chip idle); None: behind everything issued so far."""
         if batch is None or self.device.type != "cuda":
             return
         wb = batch[0] if isinstance(batch, (list, tuple)) and len(batch) else None
         if hasattr(wb, "prefetch_mel"):
-            wb.to(self.device, non_blocking=True)
             if self._feat_stream is None:
                 self._feat_stream = torch.cuda.Stream(device=self.device)
-            wb.prefetch_mel(self._feat_stream)
+            st = self._feat_stream
+            if after is not None:
+                st.wait_event(after)
+            else:
+                st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):                      # the H2D copy of the waveforms rides on the feature stream too
+                wb.to(self.device, non_blocking=True)
+            wb.prefetch_mel(st, ordered=True)
 
     def train_step(self, i: int, batch, n_batches: int, next_batch=None):
         """One micro-batch: forward, backward, and (on a stepping micro-batch) clip + optimizer + schedule.  ``next_batch``
-        (optional) is the batch after this one: its feature extraction is started first, on its own stream."""
-        self.prefetch(next_batch)
+        (optional) is the batch after this one: its feature extraction is started on its own stream behind this batch's logits."""
         acc = self.accumulate_grad
         stepping = (i % acc == acc - 1) or (i == n_batches - 1)
         self._sync_grads = (stepping or not self.ddp) and not getattr(self, "ddp_comm_stub", False)   # (stub: bench.py's probe)
@@ -467,6 +474,8 @@ class Trainer:
         with ctx:
             batch = self.batch_to_device(batch)
             out = self.train_loop(batch)
+            # the next batch's features: issued between this batch's forward and backward, ordered behind its logits
+            self.prefetch(next_batch, after=getattr(self.engine, "fwd_done", None) if self.engine is not None else None)
             loss = out["loss"] if acc == 1 else out["loss"] / acc          # (reference: loss / accumulate_grad, ccml/trainer.py:521)
             loss.backward()
         _time_cost_recoder.recoder("forward", time.time() - t0)

@@ -61,6 +61,7 @@ class _EngineFn(torch.autograd.Function):
         loss, in_len, tg_len = res
         ctx.ctc = True
         ctx.mark_non_differentiable(out, in_len, tg_len)
+        ctx.set_materialize_grads(False)                 # no zero-filled stand-ins for the three outputs that carry no gradient
         return out, loss, in_len, tg_len
 
     @staticmethod

@@ -150,13 +150,14 @@ class WaveBatch:
     _mel = None
     _mel_ready = None
 
-    def prefetch_mel(self, stream) -> None:
+    def prefetch_mel(self, stream, ordered: bool = False) -> None:
         """Start the feature kernels for this batch on ``stream`` (the Trainer's feature stream) so that they run beside the
         training step of the batch before it; ``to_mel`` then only waits for their completion event.  The reference gets the
         same overlap from its DataLoader workers, which compute mel on the CPU while the GPU trains."""
         if self._mel is not None or not self.wav.is_cuda:
             return
-        stream.wait_stream(torch.cuda.current_stream())          # the H2D copy of wav and everything issued before
+        if not ordered:                                          # (ordered: the caller has placed `stream` behind its inputs)
+            stream.wait_stream(torch.cuda.current_stream())      # the H2D copy of wav and everything issued before
         with torch.cuda.stream(stream):
             self._mel = self._compute_mel()
             self._mel_ready = torch.cuda.Event()

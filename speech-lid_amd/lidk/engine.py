@@ -731,6 +731,11 @@ class Engine:
             out[l] = w.logits[key].view(B, w.T, v1)
         self._ctx = dict(w=w, feat=x, keep=keep, lang=lang, training=training, front_in=mel)
         self._forced_masks = {}
+        if self._hip and training:
+            # "the logits are done": the Trainer starts the NEXT batch's feature kernels behind this point, i.e. beside the CTC
+            # lattice (64 workgroups, the only sequential stretch of the step) instead of beside the first encoder kernels
+            self.fwd_done = torch.cuda.Event()
+            self.fwd_done.record()
         return out
 
     # ------------------------------------------------------------------ CTC loss fused behind the training forward
@@ -1090,19 +1095,42 @@ class Engine:
             if v1p != v1:
                 dlT.zero_()
             self.k.scale_cast_2d(dl, dlT, M, v1)
-        # vocabulary projection
-        self._wgrad(w, dlT, w.head_h, self.gview(p + ".weight"), v1, d, self.gview(p + ".bias"))
-        self.k.gemm_nt(dlT, self.wview(p + ".weight")[1][:, :v1p], w.dh, N=d, K=v1p)
         bp, bb = self.head_params[lang], w.head
-        dy_ln = w.dh
-        if cfg.dropout > 0:
-            self.k.dropout(w.dh, w.dyT, cfg.dropout, keep_in=w.head_keep)
-            dy_ln = w.dyT
-            # post_norm backward consumes dy_ln; it must not alias its dxT output
-            self.k.scale_cast(dy_ln, w.dh, 1.0)
+
+        def head_prologue():
+            # vocabulary projection, head dropout, the head block's post_norm: fixed buffers, no per-step scalars
+            self._wgrad(w, dlT, w.head_h, self.gview(p + ".weight"), v1, d, self.gview(p + ".bias"))
+            self.k.gemm_nt(dlT, self.wview(p + ".weight")[1][:, :v1p], w.dh, N=d, K=v1p)
             dy_ln = w.dh
-        self.k.layernorm_bwd(dy_ln, bb.x4, bb.mean[4], bb.rstd[4], bp.post["w"], w.partial, dx=w.dxa, dxT=w.dyT,
-                          dxT_scale=0.5, dgamma=bp.post["dw"], dbeta=bp.post["db"], dtype=self.act_dtype)
+            if cfg.dropout > 0:
+                self.k.dropout(w.dh, w.dyT, cfg.dropout, keep_in=w.head_keep)
+                dy_ln = w.dyT
+                # post_norm backward consumes dy_ln; it must not alias its dxT output
+                self.k.scale_cast(dy_ln, w.dh, 1.0)
+                dy_ln = w.dh
+            self.k.layernorm_bwd(dy_ln, bb.x4, bb.mean[4], bb.rstd[4], bp.post["w"], w.partial, dx=w.dxa, dxT=w.dyT,
+                                 dxT_scale=0.5, dgamma=bp.post["dw"], dbeta=bp.post["db"], dtype=self.act_dtype)
+
+        def front_epilogue():
+            # front end: x0 = sqrt(d) * (r @ Wl^T + b) [dropout]; r = relu(col @ Wc^T + bc)
+            fz = "model.featurizer.sub_sampling"
+            dy = w.dfeat                                 # f32 gradient at the first block's input (after pos-enc dropout)
+            if cfg.pos_dropout > 0:
+                self.k.dropout(dy, w.dxa, cfg.pos_dropout, keep_in=w.pos_keep)
+                dy = w.dxa
+            self.k.scale_cast(dy, w.dyT, math.sqrt(d))
+            nm = cfg.n_mels
+            self._wgrad(w, w.dyT, w.r, self.gview(fz + ".linear.weight"), d, nm, self.gview(fz + ".linear.bias"))
+            dr = w.dmid.view(-1)[:M * nm].view(M, nm)
+            self.k.gemm_nt(w.dyT, self.wview(fz + ".linear.weight")[1], dr, N=nm, K=d)
+            self.k.relu_bwd(dr, w.r, dr)
+            w.dconv3.zero_()
+            self._wgrad(w, dr, w.col, w.dconv3, nm, 3 * nm, self.gview(fz + ".sub_sampling.0.bias"))
+            self.gview(fz + ".sub_sampling.0.weight").add_(w.dconv3.view(nm, 3, nm).permute(0, 2, 1))   # layout glue
+
+        whole = self._whole_graphs(ctx["keep"])
+        if not whole:
+            head_prologue()
         dfeat = w.dfeat
         feat = ctx["feat"]
         # Blocks in backward order: the head block, then the kept encoder blocks in reverse.  In deferred mode (side stream)
@@ -1115,10 +1143,13 @@ class Engine:
             i = kept[idx]
             x_in = w.enc[kept[idx - 1]].out if idx > 0 else (w.x0d if (cfg.pos_dropout > 0) else w.x0)
             blocks.append(("enc", i, self.enc_params[i], w.enc[i], x_in, f"enc.{i}"))
-        if self._whole_graphs(ctx["keep"]):
-            # the whole chain - every block's dgrad sequence with the previous block's weight gradients forked beside it, and
-            # the last block's weight gradients - as one captured sequence per (workspace, language)
+        if whole:
+            # the whole chain - the head's prologue (vocabulary projection, dropout, post_norm), every block's dgrad sequence with
+            # the previous block's weight gradients forked beside it, the last block's weight gradients and the front end's
+            # backward - as one captured sequence per (workspace, language): between the CTC gradient kernel and the optimizer the
+            # host issues ONE call
             def bwd_all():
+                head_prologue()
                 prv = None
                 self._after_first = None              # (a capture that raised half-way must not leave its callback behind)
                 fuse_ok = defer and self._ln2_ok()
@@ -1162,27 +1193,16 @@ class Engine:
                         prv = ((kind, tag), bpk, bbk, S, stage)
                 if prv is not None:
                     self._block_wgrads(w, prv[1], prv[2], prv[3], prv[0][0] == "enc")
+                if cfg.front == "subsample":
+                    front_epilogue()
 
             self.graphs.run(("bbA", id(w), lang, feat.data_ptr()), bwd_all)
         else:
             self._backward_blocks(w, blocks, dfeat, defer)
-        dy = dfeat                                   # f32 gradient at the first block's input (after pos-enc dropout)
         if cfg.front != "subsample":                 # backbone features: hand d(loss)/d(features) to the caller
             return dfeat[:M].view(ctx["front_in"].shape)
-        # front end: x0 = sqrt(d) * (r @ Wl^T + b) [dropout]; r = relu(col @ Wc^T + bc)
-        fz = "model.featurizer.sub_sampling"
-        if cfg.pos_dropout > 0:
-            self.k.dropout(dy, w.dxa, cfg.pos_dropout, keep_in=w.pos_keep)
-            dy = w.dxa
-        self.k.scale_cast(dy, w.dyT, math.sqrt(d))
-        nm = cfg.n_mels
-        self._wgrad(w, w.dyT, w.r, self.gview(fz + ".linear.weight"), d, nm, self.gview(fz + ".linear.bias"))
-        dr = w.dmid.view(-1)[:M * nm].view(M, nm)
-        self.k.gemm_nt(w.dyT, self.wview(fz + ".linear.weight")[1], dr, N=nm, K=d)
-        self.k.relu_bwd(dr, w.r, dr)
-        w.dconv3.zero_()
-        self._wgrad(w, dr, w.col, w.dconv3, nm, 3 * nm, self.gview(fz + ".sub_sampling.0.bias"))
-        self.gview(fz + ".sub_sampling.0.weight").add_(w.dconv3.view(nm, 3, nm).permute(0, 2, 1))   # layout glue
+        if not whole:
+            front_epilogue()
         if self.on_stage_grads_ready:
             self.on_stage_grads_ready("front")
 
