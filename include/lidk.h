@@ -155,6 +155,14 @@ typedef struct lidk_gemm_args {
   int splitk;
 } lidk_gemm_args;
 int lidk_gemm_nt(const lidk_gemm_args* args, int dtype, void* stream);
+/* The conv module's second pointwise convolution run backwards (lid/conformer.py:197-199: BatchNorm1d -> Swish -> Conv1d(2d, d, 1)):
+ * out = ds [M][N] bf16 = A [M][256] . B [N][256]^T, and in the same launch the BatchNorm + Swish backward statistics of that
+ * output - dz = ds * swish'(xhat * gamma + beta), xhat = (c - mean) * rstd with c = g->aux [M][N] bf16 (the BatchNorm input) -
+ * as per-channel partial sums: partial [(M / 64) * 2][2 N] f32 rows of (sum dz | sum dz * xhat); *nparts = the row count
+ * (finish with lidk_reduce_partials_f64).  Replaces lidk_gemm_nt + lidk_bn_swish_bwd_reduce (a launch that re-reads ds).
+ * K = 256, M % 64 == 0, N % 64 == 0, more than 1024 output tiles, bf16; otherwise LIDK_ERR_UNSUPPORTED. */
+int lidk_gemm_nt_bn_sums(const lidk_gemm_args* g, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         float* partial, int* nparts, int dtype, void* stream);
 
 /* LayerNorm fused into the GEMM that consumes it (PreNorm -> Linear / 1x1 Conv1d: lid/conformer.py:81-89 with :163 ff
  * up-projection, :98-100 q/kv projections, :190-192 conv module) for K == 256 (the model width) and N % 256 == 0, bf16:

@@ -54,8 +54,7 @@ __device__ __forceinline__ void store4(bf16* p, float4 v) {
 
 // 8-wide (16-byte) load/store of bf16 activations; p must be 8-element aligned.
 struct f32x8_t { float4 lo, hi; };
-__device__ __forceinline__ f32x8_t load8(const bf16* p) {
-  uint4 r = *reinterpret_cast<const uint4*>(p);
+__device__ __forceinline__ f32x8_t unpack8(uint4 r) {
   f32x8_t v;
   v.lo.x = __uint_as_float(r.x << 16); v.lo.y = __uint_as_float(r.x & 0xffff0000u);
   v.lo.z = __uint_as_float(r.y << 16); v.lo.w = __uint_as_float(r.y & 0xffff0000u);
@@ -63,6 +62,7 @@ __device__ __forceinline__ f32x8_t load8(const bf16* p) {
   v.hi.z = __uint_as_float(r.w << 16); v.hi.w = __uint_as_float(r.w & 0xffff0000u);
   return v;
 }
+__device__ __forceinline__ f32x8_t load8(const bf16* p) { return unpack8(*reinterpret_cast<const uint4*>(p)); }
 __device__ __forceinline__ void store8(bf16* p, const f32x8_t& v) {
   union { bf16 h[8]; uint4 u; } t;
   t.h[0] = (bf16)v.lo.x; t.h[1] = (bf16)v.lo.y; t.h[2] = (bf16)v.lo.z; t.h[3] = (bf16)v.lo.w;

@@ -30,6 +30,8 @@ struct Epi {
   void* out2; int ldo2;
   const void* aux; int ldaux;
   int atomic;
+  // PIPE_BN_SUMS (lidk_gemm_nt_bn_sums): BatchNorm + Swish backward statistics of the output tile, see the pipelined kernel
+  const float* bn_mean; const float* bn_rstd; const float* bn_gamma; const float* bn_beta; float* bn_partial;
 };
 
 template <typename T>
@@ -629,7 +631,11 @@ gemm_nt_bf16_dma_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, 
 // Everything in the steady state is unconditional (M % 64 == 0, N % 64 == 0, K == 256, epilogue chosen at compile time,
 // tile indices past the end are clamped to the last tile, which is then simply computed twice with identical stores), so
 // hipcc can keep counted vmcnt waits instead of draining the stores.
-enum { PIPE_PLAIN = 0, PIPE_BIAS = 1, PIPE_BIAS_SWISH_PRE = 2, PIPE_SWISH_GRAD = 3 };
+// PIPE_BN_SUMS: the output is ds, the gradient at a BatchNorm + Swish output (the conv module's second pointwise convolution run
+// backwards, lid/conformer.py:197-199); besides storing it the epilogue forms dz = ds * swish'(xhat * gamma + beta), xhat = (c -
+// mean) * rstd from the saved BatchNorm input c (aux) and leaves per-channel partial sums (sum dz | sum dz * xhat) over the wave's
+// 32 rows: bn_partial[(m_tile * 2 + wm)][2][N] - what lidk_bn_swish_bwd_reduce computes in a launch of its own that re-reads ds.
+enum { PIPE_PLAIN = 0, PIPE_BIAS = 1, PIPE_BIAS_SWISH_PRE = 2, PIPE_SWISH_GRAD = 3, PIPE_BN_SUMS = 4 };
 
 template <int MODE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
@@ -682,6 +688,7 @@ gemm_nt_bf16_pipe_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
   };
+  float bns0[8], bns1[8];                                  // PIPE_BN_SUMS: this lane's two rows of the tile, 8 channels
   // rows i*16 + fr of this wave's 32x32 block of the tile at (m0, n0): 8 consecutive columns per lane
   auto epi = [&](const f32x4 (&a)[2][2], int i, int m0, int n0) __attribute__((always_inline)) {
     const int m = m0 + wm * 32 + i * 16 + fr, n = n0 + wn * 32 + 8 * fq;
@@ -695,6 +702,35 @@ gemm_nt_bf16_pipe_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
       *reinterpret_cast<uint4*>((bf16*)e.out2 + (size_t)m * e.ldo2 + n) = pack8(v0, v1);
       v0.x *= sigmoidf_(v0.x); v0.y *= sigmoidf_(v0.y); v0.z *= sigmoidf_(v0.z); v0.w *= sigmoidf_(v0.w);
       v1.x *= sigmoidf_(v1.x); v1.y *= sigmoidf_(v1.y); v1.z *= sigmoidf_(v1.z); v1.w *= sigmoidf_(v1.w);
+    }
+    if (MODE == PIPE_BN_SUMS) {
+      const uint4 pk = pack8(v0, v1);                    // the statistics are those of the ROUNDED ds the later kernels read
+      *reinterpret_cast<uint4*>((bf16*)e.out + (size_t)m * e.ldo + n) = pk;
+      const f32x8_t dsr = unpack8(pk);
+      const f32x8_t cv = load8((const bf16*)e.aux + (size_t)m * e.ldaux + n);
+      const float dv[8] = {dsr.lo.x, dsr.lo.y, dsr.lo.z, dsr.lo.w, dsr.hi.x, dsr.hi.y, dsr.hi.z, dsr.hi.w};
+      const float cc[8] = {cv.lo.x, cv.lo.y, cv.lo.z, cv.lo.w, cv.hi.x, cv.hi.y, cv.hi.z, cv.hi.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (cc[j] - e.bn_mean[n + j]) * e.bn_rstd[n + j];
+        const float z = xh * e.bn_gamma[n + j] + e.bn_beta[n + j];
+        const float sg = sigmoidf_(z);
+        const float dz = dv[j] * (sg * (1.f + z * (1.f - sg)));
+        if (i == 0) { bns0[j] = dz; bns1[j] = dz * xh; } else { bns0[j] += dz; bns1[j] = fmaf(dz, xh, bns1[j]); }
+      }
+      if (i == 1) {                                      // both row groups of the tile are in: 16 row-lanes -> one
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { bns0[j] += __shfl_xor(bns0[j], o, 64); bns1[j] += __shfl_xor(bns1[j], o, 64); }
+        }
+        if (fr == 0) {
+          float* pr = e.bn_partial + ((size_t)(m0 / 64) * 2 + wm) * 2 * N + n;
+          store4(pr, make_float4(bns0[0], bns0[1], bns0[2], bns0[3])); store4(pr + 4, make_float4(bns0[4], bns0[5], bns0[6], bns0[7]));
+          store4(pr + N, make_float4(bns1[0], bns1[1], bns1[2], bns1[3])); store4(pr + N + 4, make_float4(bns1[4], bns1[5], bns1[6], bns1[7]));
+        }
+      }
+      return;
     }
     if (MODE == PIPE_SWISH_GRAD) {
       const bf16* ap = (const bf16*)e.aux + (size_t)m * e.ldaux + n;
@@ -931,6 +967,24 @@ gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, int
 }
 
 // ------------------------------------------------------------------------------------ host dispatch
+// out [M][N] bf16 = A [M][256] . B [N][256]^T with the BatchNorm + Swish backward statistics of the output in the epilogue
+// (PIPE_BN_SUMS above).  partial: (M / 64) * 2 rows of (sum dz | sum dz * xhat) [2 N] f32, *nparts receives that row count.
+extern "C" int lidk_gemm_nt_bn_sums(const lidk_gemm_args* g, const float* mean, const float* rstd, const float* gamma,
+                                    const float* beta, float* partial, int* nparts, int dtype, void* stream) {
+  if (!g || !g->A || !g->B || !g->out || !g->aux || !mean || !rstd || !gamma || !beta || !partial || !nparts) return LIDK_ERR_ARG;
+  const long tiles = (long)(g->M / 64) * (g->N / 64);
+  if (dtype != LIDK_BF16 || g->K != 256 || (g->M & 63) || (g->N & 63) || g->out_f32 || g->res || g->bias || g->out2 ||
+      g->act != LIDK_ACT_NONE || g->alpha != 1.0f || (g->ldo & 7) || (g->ldaux & 7) || (g->lda & 7) || (g->ldb & 7) || g->ldb < g->K ||
+      tiles <= 1024)
+    return LIDK_ERR_UNSUPPORTED;
+  Epi e{0, nullptr, LIDK_ACT_NONE, 1.0f, nullptr, 0, g->out, g->ldo, 0, nullptr, 0, g->aux, g->ldaux, 0, mean, rstd, gamma, beta, partial};
+  const int tpb = 2, G = cdiv(cdiv((int)tiles, tpb), 8) * 8;
+  gemm_nt_bf16_pipe_kernel<PIPE_BN_SUMS><<<G, 256, 0, as_stream(stream)>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->lda,
+                                                                          g->ldb, (int)tiles, G, tpb, e);
+  *nparts = (g->M / 64) * 2;
+  return launch_status();
+}
+
 extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
   if (!g || !g->A || !g->B || !g->out || g->M <= 0 || g->N <= 0 || g->K <= 0) return LIDK_ERR_ARG;
   if ((g->K & 7) || (g->lda & 7) || (g->ldb & 7) || g->ldb < g->K || g->ldo < g->N) return LIDK_ERR_ARG;

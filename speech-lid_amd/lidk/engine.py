@@ -904,11 +904,20 @@ class Engine:
             # ---- conv module: y = x2 + conv(x2)
             if wg:
                 self._wgrad(w, t1, bb.s, C["dw2"].view(d, ci), d, ci, C["db2"])
-            self.k.gemm_nt(t1, C["w2"][1], ds, N=ci, K=d)
-            self.k.bn_swish_bwd_reduce(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial)
+            # data gradient of the second pointwise convolution; its epilogue also leaves the BatchNorm + Swish backward sums of
+            # the tile (lidk_gemm_nt_bn_sums: one launch and one pass over ds less on the data-gradient chain, LIDK_BN_GEMM=0 or a
+            # shape outside the pipelined kernel: GEMM, then the streaming reduction)
+            nparts = 0
+            if self._hip and hasattr(self.k, "gemm_nt_bn_sums") and _os_env("LIDK_BN_GEMM", "1") == "1" \
+                    and (M // 64) * 2 * 2 * ci <= w.partial.numel():
+                nparts = self.k.gemm_nt_bn_sums(t1, C["w2"][1], ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial,
+                                                M=M, N=ci, K=d)
+            if not nparts:
+                self.k.gemm_nt(t1, C["w2"][1], ds, N=ci, K=d)
+                self.k.bn_swish_bwd_reduce(ds, bb.c, bb.bn_mean, bb.bn_rstd, C["bn_w"], C["bn_b"], w.partial)
+                nparts = L.BN_PARTIAL_BLOCKS
             # sums is all-reduced in place by the SyncBN collective under DP; sums_local keeps this rank's share
-            self.k.reduce_partials_f64(w.partial, L.BN_PARTIAL_BLOCKS, 2 * ci, S.sums[:2 * ci + 1], S.sums_local[:2 * ci + 1],
-                                       tail=M)
+            self.k.reduce_partials_f64(w.partial, nparts, 2 * ci, S.sums[:2 * ci + 1], S.sums_local[:2 * ci + 1], tail=M)
         if part in ("all", "b"):
             # BatchNorm+Swish backward, depthwise-conv input gradient and GLU backward in one launch; the conv's weight
             # gradient (which needs dc materialised) goes with the other weight gradients

@@ -327,6 +327,31 @@ def gemm_nt(A, B, out, bias=None, act=L.ACT_NONE, alpha=1.0, res=None, out2=None
     return out
 
 
+def gemm_nt_bn_sums(A, B, out, c, mean, rstd, gamma, beta, partial, M=None, N=None, K=None):
+    """out = A @ B^T (bf16) with the BatchNorm + Swish backward sums of the output in the epilogue (c: the BatchNorm input).
+    -> number of partial rows written (finish with reduce_partials_f64), or 0 when the shape is outside the fused kernel."""
+    M = A.shape[0] if M is None else M
+    K = A.shape[1] if K is None else K
+    N = B.shape[0] if N is None else N
+    g = L.GemmArgs()
+    g.A, g.B = _pv(A), _pv(B)
+    g.M, g.N, g.K, g.lda, g.ldb = M, N, K, A.stride(0), B.stride(0)
+    g.bias, g.act, g.alpha = None, L.ACT_NONE, 1.0
+    g.res, g.ldres = None, 0
+    g.out, g.ldo, g.out_f32 = _pv(out), out.stride(0), 0
+    g.out2, g.ldo2 = None, 0
+    g.aux, g.ldaux = _pv(c), c.stride(0)
+    g.splitk = 1
+    if A.dtype != torch.bfloat16 or B.dtype != A.dtype or out.dtype != A.dtype or c.dtype != A.dtype:
+        return 0
+    n = C.c_int(0)
+    rc = lib().lidk_gemm_nt_bn_sums(C.byref(g), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(partial), C.byref(n), _code(A), _stream())
+    if rc == L.ERR_UNSUPPORTED:
+        return 0
+    check(rc, "gemm_nt_bn_sums")
+    return n.value
+
+
 def ln_gemm_supported(M, N, K, dtype):
     return bool(lib().lidk_ln_gemm_supported(M, N, K, dtype_code(dtype)))
 

@@ -1071,3 +1071,35 @@ def test_grouped_weight_gradients_equal_the_separate_launches(M, monkeypatch):
             ref, refc = X.float().t() @ Y.float(), X.float().sum(0)
             assert float((Cg - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
             assert float((csg - refc).abs().max()) <= 2e-3 * float(refc.abs().max())
+
+
+def test_gemm_with_batchnorm_swish_backward_sums_in_the_epilogue():
+    """lidk_gemm_nt_bn_sums (the conv module's second pointwise convolution run backwards, lid/conformer.py:197-199, with the
+    BatchNorm + Swish backward statistics of its output formed in the GEMM's epilogue) against the two launches it replaces:
+    the same ds bit for bit, and the same per-channel sums (sum dz | sum dz * xhat) up to the summation order."""
+    from lidk import _lib as L
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 9664, 512, 256
+    A = (0.5 * torch.randn(M, K, generator=g)).to(DEV).bfloat16()
+    W = (torch.randn(N, K, generator=g) / 16).to(DEV).bfloat16()
+    c = torch.randn(M, N, generator=g).to(DEV).bfloat16()
+    mean, rstd = (0.1 * torch.randn(N, generator=g)).to(DEV), (0.5 + torch.rand(N, generator=g)).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(N, generator=g)).to(DEV), (0.1 * torch.randn(N, generator=g)).to(DEV)
+    ds0, ds1 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16), torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    part = torch.zeros(L.BN_PARTIAL_BLOCKS * 2 * N, device=DEV)
+    ops.gemm_nt(A, W, ds0)
+    ops.bn_swish_bwd_reduce(ds0, c, mean, rstd, gamma, beta, part)
+    ref = torch.zeros(2 * N + 1, device=DEV, dtype=torch.float64)
+    ops.reduce_partials_f64(part, L.BN_PARTIAL_BLOCKS, 2 * N, ref, tail=M)
+    part2 = torch.full((L.BN_PARTIAL_BLOCKS * 2 * N,), float("nan"), device=DEV)
+    n = ops.gemm_nt_bn_sums(A, W, ds1, c, mean, rstd, gamma, beta, part2)
+    assert n == (M // 64) * 2
+    got = torch.zeros(2 * N + 1, device=DEV, dtype=torch.float64)
+    ops.reduce_partials_f64(part2, n, 2 * N, got, tail=M)
+    torch.cuda.synchronize()
+    assert torch.equal(ds0, ds1)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print(f"[gemm + bn sums] max rel err of the sums {err:.2e} (|sums| up to {float(ref[:2 * N].abs().max()):.1f})")
+    assert err <= 2e-6 and float(got[2 * N]) == M
+    # shapes outside the pipelined kernel are refused (the engine then issues the two launches)
+    assert ops.gemm_nt_bn_sums(A[:640], W, ds1[:640], c[:640], mean, rstd, gamma, beta, part2) == 0
