@@ -48,9 +48,9 @@ SECONDS = 3.0
 BATCH = 64
 N_LANGS = 14
 SETUP_ROUNDS = 3                    # visits of every language before warm-up (eager, capture, replay of each head's graphs)
-PMC_FILE = os.path.join("profiles", "r03", "pmc_traffic.json")
-PMC_FALLBACK = os.path.join("profiles", "r02", "pmc_traffic.json")
-ROCPROF_STATS = (os.path.join("profiles", "r03", "bench_kernel_stats.csv"), os.path.join("profiles", "r02", "bench_v2_kernel_stats.csv"))
+PMC_FILE = os.path.join("profiles", "r04", "pmc_traffic.json")
+PMC_FALLBACK = os.path.join("profiles", "r03", "pmc_traffic.json")
+ROCPROF_STATS = (os.path.join("profiles", "r04", "bench_kernel_stats.csv"), os.path.join("profiles", "r03", "bench_kernel_stats.csv"))
 FLOP_PER_UTT_TRAIN = 21.67e9       # 7.222 GFLOP forward per 3 s utterance x 3 (one head, stochastic depth off)
 
 
@@ -306,7 +306,7 @@ def _pmc_traffic(kernel_prefix):
 
 def _rocprof_avg_us(prefixes):
     """Launch-weighted average duration of the kernels whose name contains one of ``prefixes`` in the committed rocprofv3
-    --kernel-trace --stats summary of this command (profiles/r03/bench_kernel_stats.csv) -> (us, launches, file) or Nones."""
+    --kernel-trace --stats summary of this command (profiles/r04/bench_kernel_stats.csv) -> (us, launches, file) or Nones."""
     import csv
     for rel in ROCPROF_STATS:
         path = os.path.join(ROOT, rel)
@@ -360,7 +360,7 @@ def roofline(trainer, batches, step_fn):
     from lid.audio_processor import WaveBatch
     eng = trainer.engine
     k = eng.k
-    names = ("gemm_nt", "gemm_tn", "ffn_fwd", "ffn_bwd", "build_tn_group", "gemm_tn_grouped")
+    names = ("gemm_nt", "gemm_nt_bn_sums", "gemm_tn", "ffn_fwd", "ffn_bwd", "build_tn_group", "gemm_tn_grouped")
     orig = {n: getattr(k, n) for n in names if hasattr(k, n)}
     orig_mel = WaveBatch._compute_mel
     rec = {"nt": [], "tn": [], "ffn": [], "tng": [], "feat": []}
@@ -380,6 +380,16 @@ def roofline(trainer, batches, step_fn):
             nbytes += n * 4
         rec["nt"].append((lambda: orig["gemm_nt"](A, B, out, *a, M=M, N=N, K=K, **kw), 2.0 * m * n * kk, nbytes))
         return orig["gemm_nt"](A, B, out, *a, M=M, N=N, K=K, **kw)
+
+    def timed_nt_bn(A, B, out, c, mean, rstd, gamma, beta, partial, M=None, N=None, K=None):
+        # the conv module's pw2 data gradient with the BatchNorm backward sums in its epilogue: + the BatchNorm input c read once
+        m, kk, n = (A.shape[0] if M is None else M), (A.shape[1] if K is None else K), (B.shape[0] if N is None else N)
+        nbytes = m * kk * esz(A) + n * kk * esz(B) + m * n * esz(out) + m * n * esz(c) + (m // 64) * 2 * 2 * n * 4
+        call = lambda: orig["gemm_nt_bn_sums"](A, B, out, c, mean, rstd, gamma, beta, partial, M=M, N=N, K=K)
+        r = call()
+        if r:
+            rec["nt"].append((call, 2.0 * m * n * kk, nbytes))
+        return r
 
     def timed_tn(X, Y, C, *a, M=None, N1=None, N2=None, **kw):
         m, n1, n2 = (X.shape[0] if M is None else M), (X.shape[1] if N1 is None else N1), (Y.shape[1] if N2 is None else N2)
@@ -434,7 +444,7 @@ def roofline(trainer, batches, step_fn):
     # freed: captured hipGraphs hold raw pointers into those tables) so that this step rebuilds its tables under the recorder,
     # and put them back afterwards.
     held = [(w_, w_.__dict__.pop("_tn_groups")) for w_ in list(eng._work.values()) if "_tn_groups" in w_.__dict__]
-    wraps = {"gemm_nt": timed_nt, "gemm_tn": timed_tn, "ffn_fwd": timed_ffn_fwd, "ffn_bwd": timed_ffn_bwd,
+    wraps = {"gemm_nt": timed_nt, "gemm_nt_bn_sums": timed_nt_bn, "gemm_tn": timed_tn, "ffn_fwd": timed_ffn_fwd, "ffn_bwd": timed_ffn_bwd,
              "build_tn_group": timed_build, "gemm_tn_grouped": timed_tng}
     for n in orig:
         setattr(k, n, wraps[n])
@@ -789,11 +799,16 @@ def main():
         keep_sync, keep_stat = trainer._sync_grads, eng.stat_allreduce
         n_probe = max(10, args.steps // 4)
 
+        keep_ready, keep_flush, keep_buf = eng.on_stage_grads_ready, getattr(trainer, "_dp_flush", None), getattr(trainer, "_dp_buffer_hook", None)
+
         def probe(stub):
             nonlocal it
-            if stub:
+            if stub:                                     # the probe's stubs live HERE, not in the trainer: the hooks become no-ops
                 eng.stat_allreduce = (lambda t: None) if keep_stat is not None else None
-                trainer.ddp_comm_stub = True
+                eng.on_stage_grads_ready = (lambda stage: None) if keep_ready is not None else None
+                trainer._dp_flush = (lambda: None) if keep_flush is not None else None
+                if hasattr(trainer.model, "on_backbone_grads_ready"):
+                    trainer.model.on_backbone_grads_ready = (lambda buf: None)
             sync()
             t_ = time.perf_counter()
             for _ in range(n_probe):
@@ -801,7 +816,9 @@ def main():
                 it += 1
             sync()
             dt = (time.perf_counter() - t_) / n_probe * 1e3
-            eng.stat_allreduce, trainer.ddp_comm_stub = keep_stat, False
+            eng.stat_allreduce, eng.on_stage_grads_ready, trainer._dp_flush = keep_stat, keep_ready, keep_flush
+            if hasattr(trainer.model, "on_backbone_grads_ready"):
+                trainer.model.on_backbone_grads_ready = keep_buf
             return dt
         with_comm = probe(False)
         without = probe(True)

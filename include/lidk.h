@@ -163,6 +163,11 @@ int lidk_gemm_nt(const lidk_gemm_args* args, int dtype, void* stream);
  * K = 256, M % 64 == 0, N % 64 == 0, more than 1024 output tiles, bf16; otherwise LIDK_ERR_UNSUPPORTED. */
 int lidk_gemm_nt_bn_sums(const lidk_gemm_args* g, const float* mean, const float* rstd, const float* gamma, const float* beta,
                          float* partial, int* nparts, int dtype, void* stream);
+/* Kernel-family knobs of lidk_gemm_nt, read from the environment once: "LIDK_GEMM_PIPEK" (tiles per workgroup of the K = 512 / 768 /
+ * 1024 pipelined kernel, 0 = off), "LIDK_GEMM_DMA" (smallest K that takes the LDS-DMA 128 x 128 kernel, 0 = never),
+ * "LIDK_GEMM_DMA_TILES" (its tile-count floor).  This call changes one afterwards (tests, micro-benchmarks); a negative value makes
+ * the next launch re-read the environment. */
+int lidk_gemm_option(const char* name, long value);
 
 /* LayerNorm fused into the GEMM that consumes it (PreNorm -> Linear / 1x1 Conv1d: lid/conformer.py:81-89 with :163 ff
  * up-projection, :98-100 q/kv projections, :190-192 conv module) for K == 256 (the model width) and N % 256 == 0, bf16:

@@ -466,7 +466,7 @@ class Trainer:
         (optional) is the batch after this one: its feature extraction is started on its own stream behind this batch's logits."""
         acc = self.accumulate_grad
         stepping = (i % acc == acc - 1) or (i == n_batches - 1)
-        self._sync_grads = (stepping or not self.ddp) and not getattr(self, "ddp_comm_stub", False)   # (stub: bench.py's probe)
+        self._sync_grads = stepping or not self.ddp
         ctx = contextlib.nullcontext()
         if self.ddp and not stepping and isinstance(self.model, torch.nn.parallel.DistributedDataParallel):
             ctx = self.model.no_sync()

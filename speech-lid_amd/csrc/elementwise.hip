@@ -645,12 +645,13 @@ ln_param_grads_grouped_kernel(const LnPgDesc* __restrict__ descs) {
   }
   red[w][lane] = acc;
   __syncthreads();
-  if (w == 0 && lane < 16 && c < ncols) {
-    float s = 0.f;
+  if (w != 0) return;
+  float s = 0.f;                                       // same order as colreduce_kernel's second stage: bit-identical sums
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) s += red[i][q * 16 + lane];             // same order as colreduce_kernel: bit-identical sums
+  for (int i = 0; i < 16; ++i) s += red[i][lane];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  if (lane < 16 && c < ncols) {
     float* dst = (c < e.C) ? e.dgamma + c : e.dbeta + (c - e.C);
     *dst += s;
   }

@@ -8,6 +8,7 @@
 //   C/D lane l, reg r -> row 4*(l>>4)+r, col (l&15).
 // f32 path (parity mode): 64x64 tile, BK = 16, 4x4 outputs per thread, plain FMA.
 #include "common.h"
+#include <string.h>
 #include <type_traits>
 #include <stdlib.h>
 
@@ -967,6 +968,25 @@ gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, int
 }
 
 // ------------------------------------------------------------------------------------ host dispatch
+// Kernel-family knobs of lidk_gemm_nt: read from the environment ONCE (LIDK_GEMM_PIPEK, LIDK_GEMM_DMA, LIDK_GEMM_DMA_TILES) and
+// changed afterwards only through lidk_gemm_option - tests and the micro-benchmarks flip them inside one process.
+static int g_opt_pipek = -1, g_opt_dma = -1;
+static long g_opt_dma_tiles = -1;
+static void gemm_opts_init() {
+  if (g_opt_pipek < 0) { const char* v = getenv("LIDK_GEMM_PIPEK"); g_opt_pipek = v ? atoi(v) : 1; }
+  if (g_opt_dma < 0) { const char* v = getenv("LIDK_GEMM_DMA"); g_opt_dma = v ? atoi(v) : 1024; }
+  if (g_opt_dma_tiles < 0) { const char* v = getenv("LIDK_GEMM_DMA_TILES"); g_opt_dma_tiles = v ? atol(v) : 384; }
+}
+extern "C" int lidk_gemm_option(const char* name, long value) {
+  if (!name) return LIDK_ERR_ARG;
+  gemm_opts_init();
+  if (!strcmp(name, "LIDK_GEMM_PIPEK")) g_opt_pipek = (int)value;
+  else if (!strcmp(name, "LIDK_GEMM_DMA")) g_opt_dma = (int)value;
+  else if (!strcmp(name, "LIDK_GEMM_DMA_TILES")) g_opt_dma_tiles = value;
+  else return LIDK_ERR_ARG;
+  return LIDK_OK;                                        // (a negative value: re-read the environment on the next launch)
+}
+
 // out [M][N] bf16 = A [M][256] . B [N][256]^T with the BatchNorm + Swish backward statistics of the output in the epilogue
 // (PIPE_BN_SUMS above).  partial: (M / 64) * 2 rows of (sum dz | sum dz * xhat) [2 N] f32, *nparts receives that row count.
 extern "C" int lidk_gemm_nt_bn_sums(const lidk_gemm_args* g, const float* mean, const float* rstd, const float* gamma,
@@ -1030,8 +1050,8 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
     // 24.8.  End to end at cfg2 it is neutral (7.13 / 7.21 against 7.13 / 7.17 ms per step): beside the weight-gradient stream these
     // launches take 2-3 x their isolated time whichever kernel runs.
     {
-      const char* pk_env = getenv("LIDK_GEMM_PIPEK");            // read per call (a test flips it inside one process)
-      const int pk = pk_env ? atoi(pk_env) : 1;
+      gemm_opts_init();
+      const int pk = g_opt_pipek;
       if (pk > 0 && splitk == 1 && !dbg && (g->K == 512 || g->K == 768 || g->K == 1024) && !(g->M & 63) && !(g->N & 63) && !g->out_f32 &&
           !g->res && g->alpha == 1.0f && !(g->ldo & 7) && g->act == LIDK_ACT_NONE && !g->out2) {
         const int tiles = (g->M / 64) * (g->N / 64);
@@ -1058,11 +1078,9 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
     // (K >= 2048) / 26.12 (K >= 1024) ms per step; frozen regime 21.21 (off) / 20.64 (2048) / 20.38 (1536) / 20.38 (1024).  The
     // cfg2 Conformer has no such shape (its K >= 1024 data gradients have 152 tiles: with the tile floor at 100 the step goes
     // 7.16 -> 7.28 ms (K >= 1024) / 7.68 (K >= 512)).
-    const char* dma_env = getenv("LIDK_GEMM_DMA");                 // read per call (a test flips it inside one process)
-    const int dma_min_k = dma_env ? atoi(dma_env) : 1024;
+    const int dma_min_k = g_opt_dma;
     const long dma_tiles = (long)cdiv(g->M, 128) * (g->N / 128);
-    const char* dma_tiles_env = getenv("LIDK_GEMM_DMA_TILES");
-    const long dma_min_tiles = dma_tiles_env ? atol(dma_tiles_env) : 384;
+    const long dma_min_tiles = g_opt_dma_tiles;
     if (direct && splitk == 1 && dma_min_k > 0 && g->K >= dma_min_k && (g->K & 63) == 0 && !(g->N & 127) &&
         (g->K >= 1024 || !g->out2) && dma_tiles >= dma_min_tiles && (dma_tiles <= 512 || dma_tiles >= 1024) &&
         (size_t)128 * g->lda * 2 < (1ull << 31) && (size_t)128 * g->ldb * 2 < (1ull << 31)) {

@@ -84,6 +84,7 @@ class WavLMMutiLangModel(_EngineBoundModel):
         self.forced_masks = None
         self._backbone_frozen = {"extractor": True, "encoder": True}
         self._bb_stale = False                    # encoder parameters changed since the bf16 operands were derived
+        self._bb_changed = set()                  # names of the backbone parameters that took gradients since the last refresh
         # The reference's freeze_feature_extractor / freeze_tranformer_encoder (lid/WavLMMutiLangModel.py:78-104) leave WavLM's
         # own ``layer_norm`` (in front of post_extract_proj) and ``mask_emb`` trainable, so even the "frozen" regime back-
         # propagates through the whole transformer to reach them.  train_input_norm=True (default) keeps that; False stops
@@ -119,6 +120,7 @@ class WavLMMutiLangModel(_EngineBoundModel):
     def _sync_backbone(self):
         self.backbone.load_state_dict(self._backbone_params(), share=True)      # optimizer updates reach backbone.refresh()
         self._bb_stale = False
+        self._bb_changed = set()
 
     def _moved(self, device):
         for n in self._bb_names:                                   # the frozen backbone's parameters follow the model
@@ -150,15 +152,24 @@ class WavLMMutiLangModel(_EngineBoundModel):
             raise LidkError("WavLMMutiLangModel.forward: waveforms must be on the GPU (no CPU fallback)")
         grad_path = self.training and torch.is_grad_enabled() and lang is not None
         if self._bb_stale:
-            params = dict(self.named_parameters())
-            self.backbone.refresh(changed=[n for n in self._bb_names if params[self.BB_PREFIX + n].requires_grad])
+            # the parameters that TOOK gradients in the steps since the last refresh (recorded by _backbone_backward) - not what
+            # requires_grad says now: a freeze_* call between the optimizer step and this forward must not hide an update
+            self.backbone.refresh(changed=sorted(self._bb_changed))
             self._bb_stale = False
+            self._bb_changed = set()
         self._bb_shape = tuple(wav.shape)
         mix_w = self._mix_w()
+        train_path = grad_path and (self.train_input_norm or not self._backbone_frozen["encoder"]
+                                    or not self._backbone_frozen["extractor"] or mix_w is not None)
+        if grad_path and not train_path and not getattr(self, "_warned_fast_frozen", False):
+            # train_input_norm=False with everything frozen is NOT a regime of the reference: its backbone stays in train() mode,
+            # so hidden / attention dropouts apply even while nothing in it trains; this path replays the inference graphs
+            # (span masking on, dropouts off)
+            logging.warning("lidk backbone: train_input_norm=False with a frozen backbone runs the captured inference graphs - "
+                            "span masking applies, the backbone's dropouts do not (the reference applies them in this case)")
+            self._warned_fast_frozen = True
         with torch.no_grad():
-            feats = self.backbone.forward(wav.contiguous(), mask=self.training, n_samples=n_samples, mix_w=mix_w,
-                                          train=grad_path and (self.train_input_norm or not self._backbone_frozen["encoder"]
-                                                               or not self._backbone_frozen["extractor"] or mix_w is not None))
+            feats = self.backbone.forward(wav.contiguous(), mask=self.training, n_samples=n_samples, mix_w=mix_w, train=train_path)
         eng = self.lidk_engine
         if grad_path:
             if self._anchor is None or self._anchor.device != feats.device:
@@ -250,6 +261,7 @@ class WavLMMutiLangModel(_EngineBoundModel):
             region = "extractor" if not self._backbone_frozen["extractor"] else "input" if frozen else "encoder"
             self.on_backbone_grads_ready(bb.grad_flat[:bb.grad_regions[region]])
         self._bb_stale = True                                      # an optimizer step follows
+        self._bb_changed |= set(live)
 
     def keep_last_lang_model_train(self, lang):
         """lid/WavLMMutiLangModel.py:114-123 (``module.keep_train_lang``, lid/conf/xf_asr_extra_finetune.yaml:43): every head

@@ -59,6 +59,7 @@ SIGNATURES = {
     "lidk_layernorm2_fwd": (_I, [_P] * 11 + [_I, _I, _F, _I, _P]),
     "lidk_layernorm2_bwd": (_I, [_P] * 12 + [_F, _P, _P, _I, _I, _I, _P]),
     "lidk_gemm_nt": (_I, [C.POINTER(GemmArgs), _I, _P]),
+    "lidk_gemm_option": (_I, [C.c_char_p, _L]),
     "lidk_gemm_nt_bn_sums": (_I, [C.POINTER(GemmArgs), _P, _P, _P, _P, _P, C.POINTER(C.c_int), _I, _P]),
     "lidk_ln_gemm_supported": (_I, [_I, _I, _I, _I]),
     "lidk_ln_gemm_nt": (_I, [_P, _P, _I, _P, _P, _F, _P, _P, _P, _I, _P]),

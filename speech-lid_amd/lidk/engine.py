@@ -160,7 +160,10 @@ class _BlockBuf:
         self.rstd = [f(M) for _ in range(5)]
         self.h1, self.a1, self.u1, self.x1 = e(M, d), e(M, ff), e(M, ff), f(M, d)
         self.h2, self.qkv, self.o, self.x2 = e(M, d), e(M, 3 * inner), e(M, inner), f(M, d)
-        self.probs = e(B, heads, T, eng.k.attn_ldp(T, dh, dt))
+        # attention probabilities [B, heads, T, ldp]: only for shapes whose backward cannot recompute them (the MFMA kernels with
+        # T <= 256 keep a log-sum-exp per row instead - ~260 MB per block at B = 64, T ~ 500 would otherwise sit unused)
+        self.ldp = eng.k.attn_ldp(T, dh, dt)
+        self.probs = None if eng._attn_recompute(T, dh) else e(B, heads, T, self.ldp)
         self.h3, self.y, self.g, self.c, self.s, self.x3 = e(M, d), e(M, 2 * ci), e(M, ci), e(M, ci), e(M, ci), f(M, d)
         self.bn_mean, self.bn_rstd = f(ci), f(ci)
         self.h4, self.a4, self.u4, self.x4 = e(M, d), e(M, ff), e(M, ff), f(M, d)
@@ -1025,7 +1028,7 @@ class Engine:
                 self._wgrad(w, dy, x, dW, n, k, db)
         self._conv_wgrad(w, bp, bb, S)
         if self._relpos_split(T, bp.dh):
-            self.k.attn_bwd_relpos(bb.qkv, S.dsc, bb.probs.shape[-1], A["demb"], B, T, bp.heads, bp.dh)
+            self.k.attn_bwd_relpos(bb.qkv, S.dsc, bb.ldp, A["demb"], B, T, bp.heads, bp.dh)
 
     def _attn_recompute(self, T: int, dh: int) -> bool:
         """No probabilities in HBM: the attention backward recomputes them (bf16 MFMA shapes; LIDK_ATTN_RECOMPUTE=0 turns it off)."""
@@ -1157,6 +1160,8 @@ class Engine:
             # the previous block's weight gradients forked beside it, the last block's weight gradients and the front end's
             # backward - as one captured sequence per (workspace, language): between the CTC gradient kernel and the optimizer the
             # host issues ONE call
+            poison = _os_env("LIDK_POISON_SCRATCH", "0") == "1"
+
             def bwd_all():
                 head_prologue()
                 prv = None
@@ -1166,6 +1171,17 @@ class Engine:
                 for n, (kind, tag, bpk, bbk, x_in, stage) in enumerate(blocks):
                     ns = len(w.sets)
                     S = w.sets[n % ns]
+                    if poison:
+                        # Debug mode that pins the schedule's invariant (tests/test_gpu_parity_r2.py): a block may only write its
+                        # scratch set once nobody - in particular the weight-gradient stream, still busy with the block that used
+                        # the set before - reads it any more.  Everything in the set except what the previous block's tail has
+                        # already left there for this block (dyTs[0], the post_norm partial rows lnp[0]) is overwritten with NaN at
+                        # the earliest moment the chain could touch it: a missing join turns into NaN gradients, not into a 3e-4
+                        # drift that only a lucky comparison notices.
+                        for name_, v_ in vars(S).items():
+                            for j_, t_ in enumerate(v_ if isinstance(v_, list) else [v_]):
+                                if torch.is_tensor(t_) and t_.is_floating_point() and not (name_ in ("dyTs", "lnp") and j_ == 0):
+                                    t_.fill_(float("nan"))
                     # x_in of this block is the output of the block that follows in backward order (an encoder block, unless
                     # this is encoder block 0): fuse this block's first-PreNorm backward with that block's post_norm backward
                     fuse = None
@@ -1205,7 +1221,7 @@ class Engine:
                 if cfg.front == "subsample":
                     front_epilogue()
 
-            self.graphs.run(("bbA", id(w), lang, feat.data_ptr()), bwd_all)
+            self.graphs.run(("bbA", id(w), lang, feat.data_ptr(), poison), bwd_all)
         else:
             self._backward_blocks(w, blocks, dfeat, defer)
         if cfg.front != "subsample":                 # backbone features: hand d(loss)/d(features) to the caller

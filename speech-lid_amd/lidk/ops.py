@@ -327,6 +327,12 @@ def gemm_nt(A, B, out, bias=None, act=L.ACT_NONE, alpha=1.0, res=None, out2=None
     return out
 
 
+def gemm_option(name: str, value: int):
+    """Change one of lidk_gemm_nt's kernel-family knobs (LIDK_GEMM_PIPEK / LIDK_GEMM_DMA / LIDK_GEMM_DMA_TILES) after start-up;
+    a negative value re-reads the environment."""
+    check(lib().lidk_gemm_option(name.encode(), int(value)), "gemm_option")
+
+
 def gemm_nt_bn_sums(A, B, out, c, mean, rstd, gamma, beta, partial, M=None, N=None, K=None):
     """out = A @ B^T (bf16) with the BatchNorm + Swish backward sums of the output in the epilogue (c: the BatchNorm input).
     -> number of partial rows written (finish with reduce_partials_f64), or 0 when the shape is outside the fused kernel."""

@@ -44,7 +44,8 @@ def gpu_ctc(out, g, blank=40):
     return float(loss.mean()), dl
 
 
-TOL = {torch.float32: dict(logit=2e-4, loss=1e-4, grel=2e-3, cos=0.99999), torch.bfloat16: dict(logit=6e-2, loss=2e-2, grel=None, cos=0.99)}
+# f32 logits: BASELINE.md section 2's own figure, "fp32-mode tolerance 1e-4 abs" (the achieved value is printed by each test)
+TOL = {torch.float32: dict(logit=1e-4, loss=1e-4, grel=2e-3, cos=0.99999), torch.bfloat16: dict(logit=6e-2, loss=2e-2, grel=None, cos=0.99)}
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

@@ -19,6 +19,20 @@ from oracle import features as of
 from oracle import optim as oo
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def gemm_options():
+    """Set lidk_gemm_nt's kernel-family knobs for one test (lidk_gemm_option); afterwards they are re-read from the environment."""
+    touched = []
+
+    def set_(name, value):
+        ops.gemm_option(name, value)
+        touched.append(name)
+
+    yield set_
+    for name in touched:
+        ops.gemm_option(name, -1)
 DEV = "cuda:0"
 DT = [torch.float32, torch.bfloat16]
 
@@ -221,10 +235,10 @@ def test_gemm_pipelined_tiles(M, N):
 
 @pytest.mark.parametrize("tpb", ["1", "2", "3"])
 @pytest.mark.parametrize("M,N,K", [(9664, 256, 768), (9664, 256, 1024), (9664, 256, 512), (128, 256, 768), (2112, 192, 512)])
-def test_gemm_pipelined_long_k(M, N, K, tpb, monkeypatch):
+def test_gemm_pipelined_long_k(M, N, K, tpb, gemm_options):
     """K = 512 / 768 / 1024 through the K-generic pipelined kernel (LIDK_GEMM_PIPEK = tiles per workgroup): plain and bias
     epilogues, one tile per workgroup when the launch is small, clamped duplicate tiles at the end of the range."""
-    monkeypatch.setenv("LIDK_GEMM_PIPEK", tpb)
+    gemm_options("LIDK_GEMM_PIPEK", int(tpb))
     dt = torch.bfloat16
     A = torch.randn(M, K, generator=g(34)) * 0.3
     B = torch.randn(N, K, generator=g(35)) * 0.3
@@ -237,7 +251,7 @@ def test_gemm_pipelined_long_k(M, N, K, tpb, monkeypatch):
     out.fill_(5.0)
     ops.gemm_nt(Ad, Bd, out, bias=dev(bias))
     check("pipek_bias", out, acc + bias, 2e-2, rtol=1e-2)
-    monkeypatch.setenv("LIDK_GEMM_PIPEK", "0")
+    gemm_options("LIDK_GEMM_PIPEK", 0)
     ref = torch.empty_like(out)
     ops.gemm_nt(Ad, Bd, ref, bias=dev(bias))
     assert float((out.float() - ref.float()).abs().max()) <= 2e-2 * float(ref.float().abs().max())
@@ -611,12 +625,12 @@ def test_gemm_nt_long_k_large_shape_uses_the_128_tile(mode):
 
 
 @pytest.mark.parametrize("mode", ["bf16_plain", "f32_bias_res", "gelu_pre", "strided_view"])
-def test_gemm_nt_lds_dma_128_tile(mode, monkeypatch):
-    """With LIDK_GEMM_DMA=512 (opt-in, read per call), K >= 512, N % 128 == 0 and >= 384 tiles of 128x128 dispatch
+def test_gemm_nt_lds_dma_128_tile(mode, gemm_options):
+    """With LIDK_GEMM_DMA=512 (opt-in through lidk_gemm_option), K >= 512, N % 128 == 0 and >= 384 tiles of 128x128 dispatch
     gemm_nt_bf16_dma_kernel (operands by global_load_lds, the transformer
     backbones' d = 768 shapes); M is not a multiple of 128 (clamped last row tile); 'strided_view': overlapping rows
     (lda < K), the conv feature extractor's operand form.  Reference: f32 matmul of the bf16-rounded operands."""
-    monkeypatch.setenv("LIDK_GEMM_DMA", "512")
+    gemm_options("LIDK_GEMM_DMA", 512)
     M, N, K = 9536 + 77, 768, 768
     A = (torch.randn(M, K, generator=g(170)) * 0.5).bfloat16()
     B = (torch.randn(N, K, generator=g(171)) / K ** 0.5).bfloat16()

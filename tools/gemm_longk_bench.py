@@ -30,7 +30,7 @@ for M, N, K in ((9664, 256, 768), (9664, 256, 1024), (9664, 256, 512), (9664, 51
               o=torch.empty(M, N, device=dev, dtype=torch.bfloat16)) for _ in range(NSET)]
     row = []
     for pk in ("0", "1", "2", "3"):
-        os.environ["LIDK_GEMM_PIPEK"] = pk
+        ops.gemm_option("LIDK_GEMM_PIPEK", int(pk))
         us = t(lambda i: ops.gemm_nt(S[i]["A"], S[i]["B"], S[i]["o"]))
         row.append(f"PIPEK={pk} {us:6.1f} us ({2 * M * N * K / us * 1e-6:4.0f} TF)")
     print(f"M={M} N={N} K={K}: " + "   ".join(row), flush=True)
