@@ -69,22 +69,24 @@ def build(args, rank, world, device):
           "module.interval=1000000", "trainer.log_interval=1000000", f"model.n_blocks={args.blocks}",
           f"module.optimizer_param.lr={args.lr}"]
     global N_LANGS
-    if args.model in ("wavlm", "w2v2"):
+    if args.model in ("wavlm", "w2v2", "xlsr"):
         key = "wavlm_cfg" if args.model == "wavlm" else "wav2vec_cfg"
+        if args.model == "xlsr" and args.blocks == 12:
+            args.blocks = 24                         # XLS-R 300M's own depth unless --blocks says otherwise
         ov = [o for o in ov if not o.startswith(("model.n_blocks", "trainer.total_epoch", "module.optimizer_param.lr"))] + ["trainer.total_epoch=1000",
               f"model.{key}.encoder_layers={args.blocks}",
               f"+module.train_input_norm={'false' if args.wavlm_regime == 'heads' else 'true'}"]
         if not args.ragged:
             ov += ["data.synthetic.seconds=3.0", "data.synthetic.min_seconds=null", "data.synthetic.bucket_seconds=null"] \
-                if args.model == "w2v2" else ["data.synthetic.seconds=3.0"]
-    if args.ragged and args.model != "w2v2":       # SURVEY 8d's cfg5 recipe: U[1, 10] s in 1 s bins, batches of similar length
+                if args.model in ("w2v2", "xlsr") else ["data.synthetic.seconds=3.0"]
+    if args.ragged and args.model not in ("w2v2", "xlsr"):       # SURVEY 8d's cfg5 recipe: U[1, 10] s in 1 s bins, batches of similar length
         ov += ["data.synthetic.seconds=10.0", "+data.synthetic.min_seconds=1.0", "+data.synthetic.bucket_seconds=1.0"]
     cfg = hydra_lite.load_config(os.path.join(ROOT, "speech-lid_amd", "lid", "conf"),
-                                 {"conformer": "synthetic_cfg2", "wavlm": "synthetic_wavlm", "w2v2": "synthetic_w2v2"}[args.model], ov)
+                                 {"conformer": "synthetic_cfg2", "wavlm": "synthetic_wavlm", "w2v2": "synthetic_w2v2", "xlsr": "synthetic_xlsr"}[args.model], ov)
     N_LANGS = len(cfg["data"]["langs"])
     module, sets, params = launcher.build(cfg, rank, world)
     module.model.use_stochastic_depth = bool(args.stochastic_depth)
-    if args.model in ("wavlm", "w2v2") and args.wavlm_regime == "finetune":
+    if args.model in ("wavlm", "w2v2", "xlsr") and args.wavlm_regime == "finetune":
         module.model.unfreeze_tranformer_encoder()
     trainer = Trainer(callbacks=[], loggers=[], **dict(cfg["trainer"]))
     trainer.ccml_module = module
@@ -677,7 +679,7 @@ def fit_throughput(args, cfg, module, sets, params, device):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", choices=["conformer", "wavlm", "w2v2"], default="conformer",
+    ap.add_argument("--model", choices=["conformer", "wavlm", "w2v2", "xlsr"], default="conformer",
                     help="conformer = BASELINE configs[1] (the headline); wavlm = configs[3]: WavLM-base backbone + heads; "
                          "w2v2 = configs[4]: wav2vec2-base backbone (key padding mask, hidden-state mix) + heads")
     ap.add_argument("--ragged", action="store_true",
@@ -708,7 +710,7 @@ def main():
     ap.add_argument("--fit-epochs", type=int, default=4, help="epochs of the Trainer.fit measurement (0 = skip)")
     ap.add_argument("--fit-workers", type=int, default=4)
     args = ap.parse_args()
-    if args.model in ("wavlm", "w2v2") or args.ragged:        # secondary lines: no Cavg phase, no fit leg
+    if args.model in ("wavlm", "w2v2", "xlsr") or args.ragged:        # secondary lines: no Cavg phase, no fit leg
         args.cavg_steps, args.fit_epochs = 0, 0
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -842,7 +844,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_model, usable = host_info()
         log(f"cpu baseline on {usable} cores ({cpu_model})")
-        if args.model == "w2v2" or args.ragged:
+        if args.model in ("w2v2", "xlsr") or args.ragged:
             cpu = None                                   # the bounded CPU sample belongs to the two fixed-length headline workloads
         elif args.model == "wavlm":
             cpu = cpu_baseline_wavlm(module, ds, max(args.cpu_steps // 2, 3), 1, min(args.cpu_batch, 8), usable, cpu_model)
@@ -851,7 +853,7 @@ def main():
     if rank == 0:
         audio_s = world * audio_s_rank                    # ragged: true audio of this rank's batches x ranks (same length mix)
         med = sorted(chunk_ms)[len(chunk_ms) // 2]
-        if args.model in ("wavlm", "w2v2"):
+        if args.model in ("wavlm", "w2v2", "xlsr"):
             regime = {"heads": "backbone forward only (gradient stops at the features)",
                       "frozen": "encoder frozen as in the reference's first epochs: data gradients through the transformer to "
                                 "layer_norm + mask_emb",
@@ -862,6 +864,12 @@ def main():
                 workload = (f"WavLMMutiLangModel: WavLM-base width backbone ({args.blocks} transformer layers, conv extractor on raw "
                             f"{dur}@16 kHz waveforms, span masking + dropouts on; {regime}) + {N_LANGS} Conformer CTC heads d768 "
                             f"(forward + backward), Adam, batch={args.batch}/GPU")
+            elif args.model == "xlsr":
+                metric = f"audio-seconds/sec joint CTC+LID training, XLS-R 300M (wav2vec2 Large) backbone ({args.wavlm_regime}) + Conformer heads"
+                workload = (f"LidModule on Wav2vecMutiLangModel: XLS-R 300M architecture ({args.blocks} pre-LN layers d1024 / 16 heads / ffn "
+                            f"4096, layer-norm conv extractor with bias, waveform layer-norm, key padding mask, last hidden state, span "
+                            f"masking on; {regime}), {dur}@16 kHz waveforms, {N_LANGS} Conformer CTC heads d1024 (forward + backward), Adam, "
+                            f"batch={args.batch}/GPU")
             else:
                 metric = f"audio-seconds/sec joint CTC+LID training, wav2vec2-base backbone ({args.wavlm_regime}) + Conformer heads"
                 workload = (f"LidModule on Wav2vecMutiLangModel: wav2vec2-base backbone ({args.blocks} transformer layers, key padding "

@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
-"""GPU busy / idle per training step from a rocprofv3 --kernel-trace CSV (steps are delimited by novograd_apply_kernel):
-per hardware queue busy time, union-busy time (any queue running a kernel) and idle time.  Usage:
-    python tools/timeline_busy.py gpurun_out/prof6/<host>/<pid>_kernel_trace.csv
+"""GPU busy / idle per training step from a rocprofv3 --kernel-trace CSV (steps are delimited by novograd_apply_kernel, or by the
+kernel-name prefix in TIMELINE_DELIM - the backbone workloads step with torch's Adam: use wavlm_conv0_stats_kernel, the first
+kernel of their forward): per hardware queue busy time, union-busy time (any queue running a kernel) and idle time.  Usage:
+    python tools/timeline_busy.py gpurun_out/prof6/<host>/<pid>_kernel_trace.csv [step_timeline.txt]
 """
 import collections
 import csv
+import os
 import sys
 
 
 def main(path):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ends = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("novograd_apply")]
+    delim = os.environ.get("TIMELINE_DELIM", "novograd_apply")
+    ends = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(delim)]
     spans, unions, sums, mains = [], [], [], []
     for s in range(len(ends) // 2, len(ends) - 2):          # steady-state steps of the timed region
         seg = rows[ends[s] + 1:ends[s + 1] + 1]
