@@ -13,7 +13,14 @@ sumsq_chunks_kernel(const float* __restrict__ grads, const int64_t* __restrict__
   const int64_t off = work[(size_t)blockIdx.x * 3 + 1], len = work[(size_t)blockIdx.x * 3 + 2];
   const float* g = grads + off;
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < len; i += 256) { float v = g[i]; s = fmaf(v, v, s); }
+  // 16-byte loads (a chunk starts on a 32-byte boundary: tensor offsets are 8-float aligned, chunks are LIDK_OPT_CHUNK long);
+  // the last chunk of a tensor may end off a multiple of 4
+  const int64_t n4 = len >> 2;
+  for (int64_t i = threadIdx.x; i < n4; i += 256) {
+    const float4 v = load4(g + 4 * i);
+    s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+  }
+  for (int64_t i = 4 * n4 + threadIdx.x; i < len; i += 256) { float v = g[i]; s = fmaf(v, v, s); }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -91,7 +98,19 @@ novograd_apply_kernel(float* __restrict__ params, float* __restrict__ grads, flo
                       float weight_decay, float ga) {
   const int64_t t = work[(size_t)blockIdx.x * 3], off = work[(size_t)blockIdx.x * 3 + 1], len = work[(size_t)blockIdx.x * 3 + 2];
   const float sc = scale[t];
-  for (int64_t i = threadIdx.x; i < len; i += 256) {
+  const int64_t n4 = len >> 2;
+  for (int64_t i = threadIdx.x; i < n4; i += 256) {                     // 16-byte accesses on all three arenas
+    const int64_t e = off + 4 * i;
+    const float4 p = load4(params + e), gr = load4(grads + e), mo = load4(exp_avg + e);
+    float4 m, q;
+    m.x = beta1 * mo.x + (gr.x * sc + weight_decay * p.x) * ga; m.y = beta1 * mo.y + (gr.y * sc + weight_decay * p.y) * ga;
+    m.z = beta1 * mo.z + (gr.z * sc + weight_decay * p.z) * ga; m.w = beta1 * mo.w + (gr.w * sc + weight_decay * p.w) * ga;
+    q.x = p.x - lr * m.x; q.y = p.y - lr * m.y; q.z = p.z - lr * m.z; q.w = p.w - lr * m.w;
+    store4(exp_avg + e, m);
+    store4(params + e, q);
+    store4(grads + e, make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+  for (int64_t i = 4 * n4 + threadIdx.x; i < len; i += 256) {
     float p = params[off + i];
     float g = grads[off + i] * sc + weight_decay * p;
     g *= ga;
