@@ -218,6 +218,10 @@ int lidk_ffn_fwd_ln(const float* x, const void* h_in, const float* gamma, const 
  * post_norm (lidk_layernorm2_bwd).  da feeds the weight gradients (lidk_gemm_tn: dW1 = da^T h, db1 = colsum da; dW2 = dyT^T u).
  * Replaces 2 x lidk_gemm_nt + lidk_layernorm_bwd; returns LIDK_ERR_UNSUPPORTED as lidk_ffn_fwd does. */
 int lidk_ffn_bwd_partial_rows(int M);
+/* Workgroup height of lidk_ffn_fwd* / lidk_ffn_bwd* / lidk_dgrad_ln_bwd: "LIDK_FFN_RG" = 3 (48 rows, 6 waves) or 4 (64 rows, 8 waves)
+ * forces one form, 0 chooses by M (48 rows while ceil(M / 48) <= 256, one workgroup per CU in one round), negative re-reads the
+ * environment variable of that name.  lidk_ffn_bwd_partial_rows follows the setting: query it after changing this. */
+int lidk_ffn_option(const char* name, long value);
 /* lidk_ffn_bwd with a SECOND LayerNorm backward behind the PreNorm's: the pair post_norm (input rows x1, mean1, rstd1, gamma1)
  * -> this module's PreNorm (lid/conformer.py:252-259 followed by :153-171 of the next block): dv = LN'(dh; x, mean, rstd, gamma) +
  * dres, dx = LN1'(dv; x1, mean1, rstd1, gamma1), dxT = dxT_scale * dx; partial / partial1: the two LayerNorms' (dgamma | dbeta) rows.

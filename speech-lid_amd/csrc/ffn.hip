@@ -1,7 +1,7 @@
 // Fused FeedForward module (lid/conformer.py:153-171 with its PreNorm :81-89 and Scale(0.5) + residual :247-248,252-259) for the
 // model width d = 256, bf16 operands:
 //     xo = x + alpha * ( swish( LN(x) . W1^T + b1 ) . W2^T + b2 )
-// One workgroup (4 waves) owns 64 complete rows; a wave owns 16 of them for the whole kernel:
+// One workgroup owns 64 (or 48: ffn_row_groups) complete rows; a wave owns 16 of them and half of every chunk's hidden columns:
 //   * prologue: the wave normalises its rows straight into MFMA operand registers (lane (fr, fq) holds row fr, columns
 //     32*ks + 8*fq .. +7 of every 32-wide K step: 8 x bf16x8 = the A fragments of the up-projection), writes h / mean / rstd for
 //     the backward pass;
@@ -18,6 +18,7 @@
 // per workgroup.  Replaces lidk_layernorm_fwd + 2 x lidk_gemm_nt (three launches, u re-read, h re-read).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
@@ -25,6 +26,20 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // lock-step chunk order.
 static int ffn_dbg() { static const int v = getenv("LIDK_FFN_DBG") ? atoi(getenv("LIDK_FFN_DBG")) : 0; return v; }
 static int ffn_rot() { static const int v = getenv("LIDK_FFN_ROT") ? atoi(getenv("LIDK_FFN_ROT")) : 1; return v; }
+// Row groups (of 16 rows) per workgroup, one policy for the three kernels and lidk_ffn_bwd_partial_rows: 48-row workgroups when
+// that grid still fits ONE round of the chip's 256 CUs (these kernels run one workgroup per CU), else 64-row ones (fewer weight
+// streams per row).  LIDK_FFN_RG = 3 / 4 forces one form (A/B runs).
+static int g_ffn_rg = -1;
+static int ffn_row_groups(int M) {
+  if (g_ffn_rg < 0) g_ffn_rg = getenv("LIDK_FFN_RG") ? atoi(getenv("LIDK_FFN_RG")) : 0;
+  if (g_ffn_rg == 3 || g_ffn_rg == 4) return g_ffn_rg;
+  return (M + 47) / 48 <= 256 ? 3 : 4;
+}
+extern "C" int lidk_ffn_option(const char* name, long value) {
+  if (!name || strcmp(name, "LIDK_FFN_RG")) return LIDK_ERR_ARG;
+  g_ffn_rg = (int)value;                                 // 3 / 4: forced, 0: by M, negative: re-read the environment
+  return LIDK_OK;
+}
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 #define FFN_D 256
@@ -70,28 +85,44 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
 // the W2 columns.  W1 rows: LDS row rho (512 B) holds global row n(rho) with its 16-byte chunks XOR-permuted by (rho & 15); rho -> n
 // undoes the "pair" permutation that makes two adjacent accumulator tiles 8 consecutive columns.  W2 columns: LDS row = output
 // column (128 B), chunks XOR-permuted by ((row >> 1) & 7).
-struct FfnStageOff { unsigned w1[4], w2[4]; };
-__device__ __forceinline__ FfnStageOff ffn_stage_offsets(int FF, int wid, int lane) {
-  FfnStageOff o;
+// RG = row groups of 16 rows per workgroup (4: 64 rows, 8 waves; 3: 48 rows, 6 waves).  The 32 + 32 wave instructions are dealt to
+// the 2 RG waves: wave w issues instructions q = 4 w + i (RG = 4) or q = w + 6 i while q < 32 (RG = 3: two waves issue 6, four 5).
+template <int RG> struct FfnStageOff { unsigned w1[RG == 4 ? 4 : 6], w2[RG == 4 ? 4 : 6]; };
+template <int RG> __device__ __forceinline__ int ffn_stage_q(int wid, int i) { return RG == 4 ? 4 * wid + i : wid + 2 * RG * i; }
+template <int RG>
+__device__ __forceinline__ FfnStageOff<RG> ffn_stage_offsets(int FF, int wid, int lane) {
+  FfnStageOff<RG> o;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rho = 8 * wid + 2 * i + (lane >> 5), p = lane & 31, cc = p ^ (rho & 15);
+  for (int i = 0; i < (RG == 4 ? 4 : 6); ++i) {
+    const int q = ffn_stage_q<RG>(wid, i) & 31;
+    const int rho = 2 * q + (lane >> 5), p = lane & 31, cc = p ^ (rho & 15);
     const int n = (rho & 32) + 8 * ((rho >> 2) & 3) + 4 * ((rho >> 4) & 1) + (rho & 3);
     o.w1[i] = (unsigned)((n * FFN_D + cc * 8) * 2);
-    const int row = 32 * wid + 8 * i + (lane >> 3), p2 = lane & 7, c2 = p2 ^ ((row >> 1) & 7);
+    const int row = 8 * q + (lane >> 3), p2 = lane & 7, c2 = p2 ^ ((row >> 1) & 7);
     o.w2[i] = (unsigned)((row * FF + c2 * 8) * 2);
   }
   return o;
 }
+// the W2-type half of a chunk (columns c FFN_CH .. of a [256][ld] matrix) -> LDS at byte offset `dst`
+template <int RG>
+__device__ __forceinline__ void ffn_stage_cols(const bf16* __restrict__ b2, const FfnStageOff<RG>& o, unsigned dst, int wid) {
+#pragma unroll
+  for (int i = 0; i < (RG == 4 ? 4 : 6); ++i) {
+    const int q = ffn_stage_q<RG>(wid, i);
+    if (RG == 4 || q < 32) glds16s(b2, o.w2[i], dst + q * 1024);
+  }
+}
 // chunk c of W1 / W2 -> LDS buffer at byte offset `buf` (wid is an SGPR value: all address arithmetic here is scalar)
-__device__ __forceinline__ void ffn_stage(const bf16* __restrict__ W1, const bf16* __restrict__ W2, const FfnStageOff& o, int c,
+template <int RG>
+__device__ __forceinline__ void ffn_stage(const bf16* __restrict__ W1, const bf16* __restrict__ W2, const FfnStageOff<RG>& o, int c,
                                           unsigned buf, int wid) {
   const bf16* b1 = W1 + (size_t)c * FFN_CH * FFN_D;
-  const bf16* b2 = W2 + (size_t)c * FFN_CH;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) glds16s(b1, o.w1[i], buf + (8 * wid + 2 * i) * 512);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) glds16s(b2, o.w2[i], buf + FFN_CH * FFN_D * 2 + (32 * wid + 8 * i) * 128);
+  for (int i = 0; i < (RG == 4 ? 4 : 6); ++i) {
+    const int q = ffn_stage_q<RG>(wid, i);
+    if (RG == 4 || q < 32) glds16s(b1, o.w1[i], buf + q * 1024);
+  }
+  ffn_stage_cols<RG>(W2 + (size_t)c * FFN_CH, o, buf + FFN_CH * FFN_D * 2, wid);
 }
 
 // one 1 KB wave instruction of a small f32 vector (bias, LayerNorm weights) -> LDS, unpermuted
@@ -117,9 +148,13 @@ __device__ __forceinline__ void ffn_stage_rows(const float* __restrict__ x, int 
 // Latency chain of a workgroup (all of them run in lock-step, there is no second workgroup on the CU to hide behind): ONE HBM round
 // trip in the prologue - the row loads are issued first, the small vectors (b1, b2, gamma, beta) and chunk 0 follow by LDS-DMA - and
 // none in the epilogue: the residual rows the epilogue adds come back by LDS-DMA during the last chunk, into the free chunk buffer.
-template <bool LN_IN, int ABL>      // ABL (ablation builds, wrong results): 1 no fragment reads, 2 no MFMAs, 4 no bias / Swish math
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// RG = 3: 48-row workgroups of 6 waves (3 row groups x 2 halves) - the grid the launcher picks when it then fits one round of the
+// 256 CUs (M <= 12 288: 202 workgroups instead of 151 at the benchmarked M = 9 664): a workgroup's LDS fragment reads - what bounds
+// the chunk loop - and its prologue / epilogue rows fall by a quarter.
+template <bool LN_IN, int ABL, int RG>      // ABL (ablation builds, wrong results): 1 no fragment reads, 2 no MFMAs, 4 no bias / Swish math
+__global__ void __launch_bounds__(128 * RG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ffn_fwd_kernel(FfnFwd p) {
+  constexpr int NW = 2 * RG, BM = 16 * RG;
   extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];
   float* lb1 = reinterpret_cast<float*>(ffn_smem + 2 * FFN_BUF);
   const int FFp = (p.FF + 255) & ~255;                        // the b1 image is padded to whole 1 KB wave instructions
@@ -128,8 +163,8 @@ ffn_fwd_kernel(FfnFwd p) {
   float* lbet = lgam + FFN_D;
   const unsigned smem0 = (unsigned)(size_t)(lds_void_t*)ffn_smem;
   const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), half = wid >> 2, rw = wid & 3;
-  const int m0 = blockIdx.x * FFN_BM;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), half = wid >= RG ? 1 : 0, rw = wid - RG * half;
+  const int m0 = blockIdx.x * BM;
   const int m_raw = m0 + 16 * rw + fr;
   const bool m_ok = m_raw < p.M;
   const int m = m_ok ? m_raw : p.M - 1;
@@ -139,7 +174,7 @@ ffn_fwd_kernel(FfnFwd p) {
   const int rot = p.rot ? (blockIdx.x >> 3) % (p.FF / FFN_CH) : 0;
   auto chunk_of = [&](int c) __attribute__((always_inline)) { const int t = c + rot; return t >= NC ? t - NC : t; };
 
-  const FfnStageOff so = ffn_stage_offsets(p.FF, wid, lane);
+  const FfnStageOff<RG> so = ffn_stage_offsets<RG>(p.FF, wid, lane);
 
   // ---- register loads first: this lane's 64 row elements (or the ready-made h fragments)
   bf16x8 hA[8];
@@ -156,22 +191,22 @@ ffn_fwd_kernel(FfnFwd p) {
   {
     const int nb1 = FFp / 256;                                    // wave instructions for b1; then b2, gamma, beta: one each
     const unsigned vec0 = smem0 + 2 * FFN_BUF;
-    for (int k = wid; k < nb1; k += 8) ffn_stage_vec(p.b1, p.FF, vec0, k, lane);
-    if (wid == (nb1 & 7)) ffn_stage_vec(p.b2, FFN_D, vec0 + FFp * 4, 0, lane);
+    for (int k = wid; k < nb1; k += NW) ffn_stage_vec(p.b1, p.FF, vec0, k, lane);
+    if (wid == nb1 % NW) ffn_stage_vec(p.b2, FFN_D, vec0 + FFp * 4, 0, lane);
     if (LN_IN) {
-      if (wid == ((nb1 + 1) & 7)) ffn_stage_vec(p.gamma, FFN_D, vec0 + FFp * 4 + 1024, 0, lane);
-      if (wid == ((nb1 + 2) & 7)) ffn_stage_vec(p.beta, FFN_D, vec0 + FFp * 4 + 2048, 0, lane);
+      if (wid == (nb1 + 1) % NW) ffn_stage_vec(p.gamma, FFN_D, vec0 + FFp * 4 + 1024, 0, lane);
+      if (wid == (nb1 + 2) % NW) ffn_stage_vec(p.beta, FFN_D, vec0 + FFp * 4 + 2048, 0, lane);
     }
     if (p.gA) {
-      if (wid == ((nb1 + 3) & 7)) ffn_stage_vec(p.gA, FFN_D, vec0 + FFp * 4 + 3072, 0, lane);
-      if (wid == ((nb1 + 4) & 7)) ffn_stage_vec(p.bA, FFN_D, vec0 + FFp * 4 + 4096, 0, lane);
+      if (wid == (nb1 + 3) % NW) ffn_stage_vec(p.gA, FFN_D, vec0 + FFp * 4 + 3072, 0, lane);
+      if (wid == (nb1 + 4) % NW) ffn_stage_vec(p.bA, FFN_D, vec0 + FFp * 4 + 4096, 0, lane);
     }
     if (p.gB) {
-      if (wid == ((nb1 + 5) & 7)) ffn_stage_vec(p.gB, FFN_D, vec0 + FFp * 4 + 5120, 0, lane);
-      if (wid == ((nb1 + 6) & 7)) ffn_stage_vec(p.bB, FFN_D, vec0 + FFp * 4 + 6144, 0, lane);
+      if (wid == (nb1 + 5) % NW) ffn_stage_vec(p.gB, FFN_D, vec0 + FFp * 4 + 5120, 0, lane);
+      if (wid == (nb1 + 6) % NW) ffn_stage_vec(p.bB, FFN_D, vec0 + FFp * 4 + 6144, 0, lane);
     }
   }
-  if (NC > 0) ffn_stage(p.W1, p.W2, so, chunk_of(0), smem0, wid);
+  if (NC > 0) ffn_stage<RG>(p.W1, p.W2, so, chunk_of(0), smem0, wid);
 
   if (LN_IN) {
     float s = 0.f;
@@ -253,7 +288,7 @@ ffn_fwd_kernel(FfnFwd p) {
 
   if (NC > 0) {
     if (NC == 1) ffn_stage_rows(p.x, m0, p.M, smem0 + FFN_BUF, wid, lane);
-    else if (!(p.dbg & 2)) ffn_stage(p.W1, p.W2, so, chunk_of(1), smem0 + FFN_BUF, wid);
+    else if (!(p.dbg & 2)) ffn_stage<RG>(p.W1, p.W2, so, chunk_of(1), smem0 + FFN_BUF, wid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // chunk 0 (and the small vectors) landed; chunk 1 rides along
     __syncthreads();
 #pragma unroll
@@ -266,7 +301,7 @@ ffn_fwd_kernel(FfnFwd p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // BARRIER c
       __syncthreads();
       if (c + 2 < NC) {
-        if (!(p.dbg & 2)) ffn_stage(p.W1, p.W2, so, chunk_of(c + 2), smem0 + (c & 1) * FFN_BUF, wid);
+        if (!(p.dbg & 2)) ffn_stage<RG>(p.W1, p.W2, so, chunk_of(c + 2), smem0 + (c & 1) * FFN_BUF, wid);
       } else {
         ffn_stage_rows(p.x, m0, p.M, smem0 + (c & 1) * FFN_BUF, wid, lane);          // c == NC - 2: the epilogue's residual rows
       }
@@ -311,7 +346,7 @@ ffn_fwd_kernel(FfnFwd p) {
     for (int i = 0; i < 8; ++i) xch[(wid * 8 + i) * 64 + lane] = make_float4(acc2[i][0], acc2[i][1], acc2[i][2], acc2[i][3]);
   }
   __syncthreads();
-  const int pw = wid ^ 4;
+  const int pw = half ? wid - RG : wid + RG;
   float* orow = p.xo + (size_t)m * FFN_D + 4 * fq + 128 * half;
   const float* bl = lb2 + 4 * fq + 128 * half;
   const unsigned char* xrow = xt + (16 * rw + fr) * 1024;
@@ -401,31 +436,40 @@ static int ffn_fwd_launch(const float* gA, const float* bA, float* yA32, void* y
   const int lds = 2 * FFN_BUF + (((ff + 255) & ~255) + 7 * FFN_D) * 4 + 2048;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<false, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<false, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #ifdef LIDK_FFN_ABLATION
-    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true, 7, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
     attr_set = true;
   }
-  const int grid = cdiv(M, FFN_BM);
 #ifdef LIDK_FFN_ABLATION
   const int abl = (p.dbg >> 5) & 7;                // LIDK_FFN_DBG bits 32 / 64 / 128: compile-time ablations of the chunk loop
   if (!h_in && abl) {
-    if (abl == 1) ffn_fwd_kernel<true, 1><<<grid, 512, lds, as_stream(stream)>>>(p);
-    else if (abl == 2) ffn_fwd_kernel<true, 2><<<grid, 512, lds, as_stream(stream)>>>(p);
-    else if (abl == 3) ffn_fwd_kernel<true, 3><<<grid, 512, lds, as_stream(stream)>>>(p);
-    else if (abl == 4) ffn_fwd_kernel<true, 4><<<grid, 512, lds, as_stream(stream)>>>(p);
-    else ffn_fwd_kernel<true, 7><<<grid, 512, lds, as_stream(stream)>>>(p);
+    const int grid = cdiv(M, FFN_BM);
+    if (abl == 1) ffn_fwd_kernel<true, 1, 4><<<grid, 512, lds, as_stream(stream)>>>(p);
+    else if (abl == 2) ffn_fwd_kernel<true, 2, 4><<<grid, 512, lds, as_stream(stream)>>>(p);
+    else if (abl == 3) ffn_fwd_kernel<true, 3, 4><<<grid, 512, lds, as_stream(stream)>>>(p);
+    else if (abl == 4) ffn_fwd_kernel<true, 4, 4><<<grid, 512, lds, as_stream(stream)>>>(p);
+    else ffn_fwd_kernel<true, 7, 4><<<grid, 512, lds, as_stream(stream)>>>(p);
     return launch_status();
   }
 #endif
-  if (h_in) ffn_fwd_kernel<false, 0><<<grid, 512, lds, as_stream(stream)>>>(p);
-  else ffn_fwd_kernel<true, 0><<<grid, 512, lds, as_stream(stream)>>>(p);
+  if (ffn_row_groups(M) == 3) {
+    const int grid = cdiv(M, 48);
+    if (h_in) ffn_fwd_kernel<false, 0, 3><<<grid, 384, lds, as_stream(stream)>>>(p);
+    else ffn_fwd_kernel<true, 0, 3><<<grid, 384, lds, as_stream(stream)>>>(p);
+  } else {
+    const int grid = cdiv(M, FFN_BM);
+    if (h_in) ffn_fwd_kernel<false, 0, 4><<<grid, 512, lds, as_stream(stream)>>>(p);
+    else ffn_fwd_kernel<true, 0, 4><<<grid, 512, lds, as_stream(stream)>>>(p);
+  }
   return launch_status();
 }
 
@@ -472,14 +516,15 @@ struct FfnBwd {
 
 // GEMM = true: only the second product - dh = A . W with A = p.a [M][K = p.FF] (T) and p.W1T = W^T [256][K] - followed by the same
 // epilogue: the data gradient of any Linear / 1x1 conv that feeds a PreNorm (N = 256), fused with that LayerNorm's backward.
-template <bool LN_OUT, bool GEMM>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <bool LN_OUT, bool GEMM, int RG>
+__global__ void __launch_bounds__(128 * RG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ffn_bwd_kernel(FfnBwd p) {
+  constexpr int NW = 2 * RG, BM = 16 * RG, NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];
   const unsigned smem0 = (unsigned)(size_t)(lds_void_t*)ffn_smem;
   const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), half = wid >> 2, rw = wid & 3;
-  const int m0 = blockIdx.x * FFN_BM;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), half = wid >= RG ? 1 : 0, rw = wid - RG * half;
+  const int m0 = blockIdx.x * BM;
   const int m_raw = m0 + 16 * rw + fr;
   const bool m_ok = m_raw < p.M;
   const int m = m_ok ? m_raw : p.M - 1;
@@ -496,19 +541,14 @@ ffn_bwd_kernel(FfnBwd p) {
 
   // the chunk's tile of a: wave w copies rows 8 w .. + 7 (128 B each), 16-byte chunks XOR-permuted by (row & 7)
   const int a_row = 8 * wid + (lane >> 3), a_cc = (lane & 7) ^ (a_row & 7);
-  const FfnStageOff so = ffn_stage_offsets(p.FF, wid, lane);
+  const FfnStageOff<RG> so = ffn_stage_offsets<RG>(p.FF, wid, lane);
   const unsigned a_off = (unsigned)((8 * wid + (lane >> 3)) * p.FF + a_cc * 8) * 2;      // relative to the workgroup's first row of a
   const bf16* a_base = p.a + (size_t)m0 * p.FF;
-  const bool a_tail = m0 + FFN_BM > p.M;                     // last workgroup of a ragged M: per-lane pointers with the row clamped
+  const bool a_tail = m0 + BM > p.M;                     // last workgroup of a ragged M: per-lane pointers with the row clamped
   const bf16* a_src = p.a + (size_t)min(m0 + a_row, p.M - 1) * p.FF + a_cc * 8;
   auto stage = [&](int c, int b) __attribute__((always_inline)) {
-    if (GEMM) {
-      const bf16* b2 = p.W1T + (size_t)c * FFN_CH;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) glds16s(b2, so.w2[i], smem0 + b * FFN_BUF + FFN_CH * FFN_D * 2 + (32 * wid + 8 * i) * 128);
-    } else {
-      ffn_stage(p.W2T, p.W1T, so, c, smem0 + b * FFN_BUF, wid);
-    }
+    if (GEMM) ffn_stage_cols<RG>(p.W1T + (size_t)c * FFN_CH, so, smem0 + b * FFN_BUF + FFN_CH * FFN_D * 2, wid);
+    else ffn_stage<RG>(p.W2T, p.W1T, so, c, smem0 + b * FFN_BUF, wid);
     if (a_tail) glds16(a_src + c * FFN_CH, smem0 + 2 * FFN_BUF + b * FFN_ATILE + wid * 1024);
     else glds16s(a_base + c * FFN_CH, a_off, smem0 + 2 * FFN_BUF + b * FFN_ATILE + wid * 1024);
   };
@@ -636,7 +676,7 @@ ffn_bwd_kernel(FfnBwd p) {
     for (int i = 0; i < 8; ++i) xch[(wid * 8 + i) * 64 + lane] = make_float4(acc2[i][0], acc2[i][1], acc2[i][2], acc2[i][3]);
   }
   __syncthreads();
-  const int pw = wid ^ 4;
+  const int pw = half ? wid - RG : wid + RG;
   float4 dhv[8];
   if (half == 0) {
 #pragma unroll
@@ -674,7 +714,7 @@ ffn_bwd_kernel(FfnBwd p) {
   __syncthreads();                                   // everybody has read the exchanged tiles and its rows of x: the area is free
   float2* rsum = reinterpret_cast<float2*>(ffn_smem);                 // [2 rounds][wave][16 rows]
   float* dgs = reinterpret_cast<float*>(ffn_smem + 2048);             // per-column (dgamma | dbeta) terms: [row][256] each
-  float* dbs = dgs + FFN_BM * FFN_D;
+  float* dbs = dgs + BM * FFN_D;
   const int lrow = 16 * rw + fr;
   // dy: upstream gradient at the LayerNorm's output (this lane's 8 x 4 columns); xin: its input rows; -> gradient at its input,
   // and this workgroup's partial (dgamma | dbeta) row
@@ -707,13 +747,14 @@ ffn_bwd_kernel(FfnBwd p) {
       dy[i].x = rs_ * (dy[i].x - m1 - xh[i].x * m2); dy[i].y = rs_ * (dy[i].y - m1 - xh[i].y * m2);
       dy[i].z = rs_ * (dy[i].z - m1 - xh[i].z * m2); dy[i].w = rs_ * (dy[i].w - m1 - xh[i].w * m2);
     }
-    {                                                // column sums over the 64 rows: thread t -> (which = t >> 8, column = t & 255)
-      const float* src = (tid >> 8) ? dbs : dgs;
-      const int col = tid & 255;
+    // column sums over the workgroup's rows: item t -> (which = t >> 8, column = t & 255)
+    for (int t0 = tid; t0 < 2 * FFN_D; t0 += NT) {
+      const float* src = (t0 >> 8) ? dbs : dgs;
+      const int col = t0 & 255;
       float t = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < FFN_BM; ++r) t += src[r * FFN_D + col];
-      part[(size_t)blockIdx.x * 2 * FFN_D + tid] = t;
+      for (int r = 0; r < BM; ++r) t += src[r * FFN_D + col];
+      part[(size_t)blockIdx.x * 2 * FFN_D + t0] = t;
     }
   };
   ln_bwd(dhv, xin, gmv, mu, rs, p.partial, 0);
@@ -737,7 +778,7 @@ ffn_bwd_kernel(FfnBwd p) {
   }
 }
 
-extern "C" int lidk_ffn_bwd_partial_rows(int M) { return cdiv(M, FFN_BM); }
+extern "C" int lidk_ffn_bwd_partial_rows(int M) { return cdiv(M, 16 * ffn_row_groups(M)); }
 
 static int ffn_bwd_launch(const float* x1, const float* mean1, const float* rstd1, const float* gamma1, float* partial1,
                           const void* dyT, const void* a, const void* W2T, int ldw2t, const void* W1T, int ldw1t, void* da,
@@ -751,13 +792,19 @@ static int ffn_bwd_launch(const float* x1, const float* mean1, const float* rstd
   const int lds = 2 * FFN_BUF + 2 * FFN_ATILE;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<true, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<true, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const int grid = cdiv(M, FFN_BM);
-  if (dh) ffn_bwd_kernel<false, false><<<grid, 512, lds, as_stream(stream)>>>(p);
-  else ffn_bwd_kernel<true, false><<<grid, 512, lds, as_stream(stream)>>>(p);
+  if (ffn_row_groups(M) == 3) {
+    if (dh) ffn_bwd_kernel<false, false, 3><<<cdiv(M, 48), 384, lds, as_stream(stream)>>>(p);
+    else ffn_bwd_kernel<true, false, 3><<<cdiv(M, 48), 384, lds, as_stream(stream)>>>(p);
+  } else {
+    if (dh) ffn_bwd_kernel<false, false, 4><<<cdiv(M, FFN_BM), 512, lds, as_stream(stream)>>>(p);
+    else ffn_bwd_kernel<true, false, 4><<<cdiv(M, FFN_BM), 512, lds, as_stream(stream)>>>(p);
+  }
   return launch_status();
 }
 
@@ -791,9 +838,11 @@ extern "C" int lidk_dgrad_ln_bwd(const void* dy, const void* WT, int ldwt, const
   const int lds = 2 * FFN_BUF + 2 * FFN_ATILE;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<true, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<true, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  ffn_bwd_kernel<true, true><<<cdiv(M, FFN_BM), 512, lds, as_stream(stream)>>>(p);
+  if (ffn_row_groups(M) == 3) ffn_bwd_kernel<true, true, 3><<<cdiv(M, 48), 384, lds, as_stream(stream)>>>(p);
+  else ffn_bwd_kernel<true, true, 4><<<cdiv(M, FFN_BM), 512, lds, as_stream(stream)>>>(p);
   return launch_status();
 }

@@ -410,6 +410,11 @@ def ffn_bwd_partial_rows(M):
     return lib().lidk_ffn_bwd_partial_rows(M)
 
 
+def ffn_option(name: str, value: int):
+    """LIDK_FFN_RG: 3 / 4 = 48- / 64-row workgroups in the fused FeedForward kernels, 0 = by M, negative = re-read the environment."""
+    check(lib().lidk_ffn_option(name.encode(), int(value)), "ffn_option")
+
+
 def ffn_bwd(dyT, a, W1T, W2T, da, x=None, mean=None, rstd=None, gamma=None, dres=None, dx=None, dxT=None, dxT_scale=1.0,
             partial=None, dh=None, pair=None):
     """da = (dyT W2) * swish'(a); dh = da W1; then the PreNorm backward (dx / dxT / partial dgamma-dbeta rows), or dh itself when

@@ -12,6 +12,15 @@ DEV = "cuda:0"
 BF = torch.bfloat16
 
 
+@pytest.fixture(autouse=True, params=[3, 4], ids=["rows48", "rows64"])
+def _workgroup_height(request):
+    """Every test runs with both workgroup heights of csrc/ffn.hip forced (48 rows / 6 waves, 64 rows / 8 waves); the default
+    policy (by M) picks between exactly these two."""
+    ops.ffn_option("LIDK_FFN_RG", request.param)
+    yield request.param
+    ops.ffn_option("LIDK_FFN_RG", -1)
+
+
 def _case(M, ff, seed, d=256):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(M, d, generator=g) * 1.5 + 0.2

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the convolution-module kernels at the cfg2 shape (B=64, T=151, C=512, K=31), hipGraph-replayed."""
+"""Micro-benchmark of the convolution-module kernels at the cfg2 shape (B=32, T=302, C=512, K=31; env B, T), hipGraph-replayed."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "speech-lid_amd")]
@@ -7,7 +7,7 @@ import torch
 from lidk import ops, _lib as L
 
 dev = "cuda:0"
-B, T, C, K = 64, 151, 512, 31
+B, T, C, K = int(os.environ.get("B", 32)), int(os.environ.get("T", 302)), 512, 31
 M = B * T
 bf = torch.bfloat16
 

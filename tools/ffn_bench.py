@@ -62,6 +62,8 @@ def bwd3(i):
 
 
 flop = 2 * 2 * M * d * ff
+RG = os.environ.get("LIDK_FFN_RG", "by M")
+print(f"M = {M}, ff = {ff}, workgroup height LIDK_FFN_RG = {RG}: {ops.ffn_bwd_partial_rows(M)} workgroups")
 us3, us1 = t(fwd3), t(fwd1)
 print(f"forward  LN + up + down (3 launches) {us3:7.1f} us   {flop / us3 * 1e-6:6.0f} TFLOP/s")
 print(f"forward  fused lidk_ffn_fwd          {us1:7.1f} us   {flop / us1 * 1e-6:6.0f} TFLOP/s")
@@ -73,3 +75,23 @@ if hasattr(ops, "ffn_bwd"):
         ops.ffn_bwd(s["dyT"], s["a"], s["W1T"], s["W2T"], s["da"], x=s["x"], mean=s["mean"], rstd=s["rstd"], gamma=s["gam"],
                     dres=s["dres"], dx=s["dx"], dxT=s["dxT"], partial=partial)
     print(f"backward fused lidk_ffn_bwd          {t(bwd1):7.1f} us")
+
+
+def fwd1h(i):
+    s = S[i]
+    ops.ffn_fwd(s["x"], s["W1"], s["b1"], s["W2"], s["b2"], s["xo"], h_in=s["h"], a=s["a"], u=s["u"])
+
+
+def bwd1dh(i):
+    s = S[i]
+    ops.ffn_bwd(s["dyT"], s["a"], s["W1T"], s["W2T"], s["da"], dh=s["dh"])
+
+
+def dgln(i):
+    s = S[i]
+    ops.dgrad_ln_bwd(s["da"], s["W1T"], s["x"], s["mean"], s["rstd"], s["gam"], partial, dres=s["dres"], dx=s["dx"], dxT=s["dxT"])
+
+
+print(f"forward  fused, h from the previous epilogue {t(fwd1h):7.1f} us")
+print(f"backward fused, stops at dh                  {t(bwd1dh):7.1f} us")
+print(f"dgrad (K = {ff}) + LayerNorm backward          {t(dgln):7.1f} us")
