@@ -621,6 +621,201 @@ gemm_nt_bf16_dma_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, 
   }
 }
 
+// ------------------------------------------------------------------------------------ bf16 MFMA kernel, 256x256 tile, LDS-DMA
+// Round 4.  Through L2 a 128 x 128 tile moves one operand byte per 64 FLOP; at the ~21 B/clk a CU's LDS-DMA fills at that caps the
+// kernel above near a third of the MFMA peak (798 TFLOP/s at K = 3072, 470 at the XLS-R shapes).  A 256 x 256 tile halves the
+// bytes per FLOP: 8 waves as 2 x 4, a wave owns 128 x 64 of the output (32 accumulator tiles = 128 registers), K tiles of 64 in
+// two 64 KB buffers, one workgroup per CU.  Same LDS images and source-side swizzle as the 128 x 128 kernel.
+// PERSISTENT: one workgroup per CU walks tiles b, b + G, b + 2 G ... (XCD-aware order), because with one workgroup per CU nothing
+// else hides a tile's epilogue and prologue - ablation at M 16000 N 3072 K 1024 (tools/gemm_time.py, LIDK_GEMM_DBG bits 32 / 64 /
+// 128): 155 us per launch of which the K loops 82, the epilogues 67.  Here the first K tile of the NEXT tile is requested before
+// the epilogue of this one, and the epilogue's stores drain under the next K loop.
+// Stores go through LDS: straight from the accumulator layout a wave instruction writes 16 rows x 64 B (half cache lines); each
+// wave transposes its 128 x 64 block through a private 4 KB (32 rows at a time) and stores whole 128 B lines, 8 lanes per row; the
+// residual of an f32 output is added on the way out with the same full-line pattern.
+// For the transformer backbones (d = 768 / 1024, ffn 3072 / 4096, conv stack): launches with >= LIDK_GEMM_DMA256 (default 200)
+// tiles of 256 x 256.
+template <int EPI_F32>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K, int lda, int ldb,
+                           int total_tiles, Epi e) {
+  constexpr int BM = 256, BN = 256, TM = 8, TN = 4, STAGE = (BM + BN) * BK * 2;
+  typedef __attribute__((address_space(3))) void lds_v;
+  const int n_tiles = N / BN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dma_smem[];       // [2][A 32 KB | B 32 KB] + 8 x 4 KB epilogue staging
+  const unsigned smem0 = (unsigned)(size_t)(lds_v*)dma_smem;
+  const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 2, wn = wid & 3;
+  constexpr bool pair = !EPI_F32;
+  const int G = gridDim.x, slot = xcd_tile(blockIdx.x, G);
+  const int nt = K / BK;
+  // per-lane byte offsets of this wave's 4 + 4 wave instructions per K tile (tile-row 32 wid + 8 i + lane / 8, chunk lane % 8)
+  unsigned aoff[4], boff[4];
+  const bf16* abase;
+  const bf16* bbase;
+  auto set_tile = [&](int tile) __attribute__((always_inline)) {
+    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 32 * wid + 8 * i + (lane >> 3), c = (lane & 7) ^ (row & 7);
+      aoff[i] = (unsigned)(((size_t)(min(m0 + row, M - 1) - m0) * lda + c * 8) * 2);
+      const int n = pair ? (row & ~31) + (((row >> 2) & 3) << 3) + (((row >> 4) & 1) << 2) + (row & 3) : row;   // LDS row -> column
+      boff[i] = (unsigned)(((size_t)n * ldb + c * 8) * 2);
+    }
+    abase = A + (size_t)m0 * lda;
+    bbase = B + (size_t)n0 * ldb;
+  };
+  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+    const unsigned dst = smem0 + buf * STAGE + (32 * wid) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gemm_glds16s(abase + kt * BK, aoff[i], dst + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gemm_glds16s(bbase + kt * BK, boff[i], dst + BM * BK * 2 + i * 1024);
+  };
+  const bool vec = !(e.ldo & 7) && (!e.res || !(e.ldres & 3)) && (!e.out2 || !(e.ldo2 & 7)) && (!e.aux || !(e.ldaux & 7));
+  unsigned char* wl = dma_smem + 2 * STAGE + wid * 4096;
+
+  int tile = slot;
+  if (tile >= total_tiles) return;
+  set_tile(tile);
+  stage(0, 0);
+  while (true) {
+    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nt; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile t landed (this wave's pieces), barrier: everybody's; and
+      __syncthreads();                                       // every wave is done reading the other buffer
+      if (t + 1 < nt && !((e.dbg & 32) && t > 0)) stage(t + 1, (t + 1) & 1);
+      if (e.dbg & 64) continue;
+      const bf16* a = reinterpret_cast<const bf16*>(dma_smem + (t & 1) * STAGE);
+      const bf16* b = a + BM * BK;
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; kk += 4) {
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[j] = *reinterpret_cast<const bf16x8*>(&b[(wn * 64 + j * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const bf16x8*>(&a[(wm * 128 + i * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    // the next tile's first K tile is requested now: it lands while this tile's epilogue runs
+    const int next = tile + G;
+    const bool more = next < total_tiles;
+    if (more) {
+      __syncthreads();                                       // every wave is done with both stage buffers
+      set_tile(next);
+      stage(0, 0);
+    }
+    if (e.dbg & 128) {                                       // ablation: no epilogue (accumulators kept alive)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(acc[i][j]));
+    } else if (vec) {
+      if (pair) {
+        const bool two = (e.act == LIDK_ACT_SWISH || e.act == LIDK_ACT_GELU) && e.out2;
+#pragma clang loop unroll(full)
+        for (int i2 = 0; i2 < TM / 2; ++i2) {                // 32 rows at a time through the wave's 4 KB
+          uint4 pk[2][2], pp[2][2];
+#pragma clang loop unroll(full)
+          for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * i2 + ii, m = min(m0 + wm * 128 + i * 16 + fr, M - 1);
+#pragma clang loop unroll(full)
+            for (int c = 0; c < TN / 2; ++c) {
+              const int n = n0 + wn * 64 + 32 * c + 8 * fq;
+              const float4 a0 = make_float4(acc[i][2 * c][0], acc[i][2 * c][1], acc[i][2 * c][2], acc[i][2 * c][3]);
+              const float4 a1 = make_float4(acc[i][2 * c + 1][0], acc[i][2 * c + 1][1], acc[i][2 * c + 1][2], acc[i][2 * c + 1][3]);
+              float4 p0 = a0, p1 = a1;
+              const float4 v0 = epi_math4(e, m, n, a0, &p0);
+              const float4 v1 = epi_math4(e, m, n + 4, a1, &p1);
+              pk[ii][c] = pack8(v0, v1);
+              pp[ii][c] = pack8(p0, p1);
+            }
+          }
+#pragma clang loop unroll(full)
+          for (int ps = 0; ps < 2; ++ps) {
+            if (ps == 1 && !two) break;
+#pragma clang loop unroll(full)
+            for (int ii = 0; ii < 2; ++ii)
+#pragma clang loop unroll(full)
+              for (int c = 0; c < TN / 2; ++c) {
+                const int row = ii * 16 + fr;
+                *reinterpret_cast<uint4*>(wl + row * 128 + (((4 * c + fq) ^ (row & 7)) << 4)) = ps ? pp[ii][c] : pk[ii][c];
+              }
+            bf16* dst = ps ? (bf16*)e.out2 : (bf16*)e.out;
+            const int ldd = ps ? e.ldo2 : e.ldo;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int row = it * 8 + (lane >> 3), m = m0 + wm * 128 + i2 * 32 + row;
+              const uint4 v = *reinterpret_cast<const uint4*>(wl + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+              if (m < M) st16(e, dst + (size_t)m * ldd + n0 + wn * 64 + (lane & 7) * 8, v);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);                 // one slice at a time: the aux loads of all would not fit the registers
+        }
+      } else {
+        Epi e2 = e;
+        e2.res = nullptr;
+#pragma clang loop unroll(full)
+        for (int i = 0; i < TM; ++i) {                       // 16 rows x 256 B at a time
+          const int m_ = min(m0 + wm * 128 + i * 16 + fr, M - 1);
+#pragma clang loop unroll(full)
+          for (int j = 0; j < TN; ++j) {
+            float4 p0;
+            const float4 v = epi_math4(e2, m_, n0 + wn * 64 + 16 * j + 4 * fq,
+                                       make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]), &p0);
+            *reinterpret_cast<float4*>(wl + fr * 256 + (((4 * j + fq) ^ fr) << 4)) = v;
+          }
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int row = it * 4 + (lane >> 4), m = m0 + wm * 128 + i * 16 + row, n = n0 + wn * 64 + (lane & 15) * 4;
+            float4 v = *reinterpret_cast<const float4*>(wl + row * 256 + (((lane & 15) ^ row) << 4));
+            if (m < M) {
+              if (e.res) { const float4 r = load4(e.res + (size_t)m * e.ldres + n); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+              store4((float*)e.out + (size_t)m * e.ldo + n, v);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+#pragma clang loop unroll(full)
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + fr;
+        if (m >= M) continue;
+        if (pair) {
+#pragma clang loop unroll(full)
+          for (int c = 0; c < TN / 2; ++c) {
+            const int n = n0 + wn * 64 + 32 * c + 8 * fq;
+            epi_store4<bf16>(e, m, n, N, make_float4(acc[i][2 * c][0], acc[i][2 * c][1], acc[i][2 * c][2], acc[i][2 * c][3]));
+            epi_store4<bf16>(e, m, n + 4, N, make_float4(acc[i][2 * c + 1][0], acc[i][2 * c + 1][1], acc[i][2 * c + 1][2], acc[i][2 * c + 1][3]));
+          }
+        } else {
+#pragma clang loop unroll(full)
+          for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + 16 * j + 4 * fq;
+            epi_store4<bf16>(e, m, n, N, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+          }
+        }
+      }
+    }
+    if (!more) break;
+    tile = next;
+  }
+}
+
 // ------------------------------------------------------------------------------------ bf16 MFMA kernel, pipelined tiles
 // For the wide K = 256 GEMMs (ff up-projection, its data gradient, QKV, pointwise conv 1) the output stores are half of a
 // launch (ablation in DESIGN.md section 5) and, in gemm_nt_bf16_direct_kernel, purely additive: a wave keeps its slot until
@@ -971,11 +1166,12 @@ gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, int
 // Kernel-family knobs of lidk_gemm_nt: read from the environment ONCE (LIDK_GEMM_PIPEK, LIDK_GEMM_DMA, LIDK_GEMM_DMA_TILES) and
 // changed afterwards only through lidk_gemm_option - tests and the micro-benchmarks flip them inside one process.
 static int g_opt_pipek = -1, g_opt_dma = -1;
-static long g_opt_dma_tiles = -1;
+static long g_opt_dma_tiles = -1, g_opt_dma256 = -1;
 static void gemm_opts_init() {
   if (g_opt_pipek < 0) { const char* v = getenv("LIDK_GEMM_PIPEK"); g_opt_pipek = v ? atoi(v) : 1; }
   if (g_opt_dma < 0) { const char* v = getenv("LIDK_GEMM_DMA"); g_opt_dma = v ? atoi(v) : 1024; }
   if (g_opt_dma_tiles < 0) { const char* v = getenv("LIDK_GEMM_DMA_TILES"); g_opt_dma_tiles = v ? atol(v) : 384; }
+  if (g_opt_dma256 < 0) { const char* v = getenv("LIDK_GEMM_DMA256"); g_opt_dma256 = v ? atol(v) : 200; }
 }
 extern "C" int lidk_gemm_option(const char* name, long value) {
   if (!name) return LIDK_ERR_ARG;
@@ -983,6 +1179,7 @@ extern "C" int lidk_gemm_option(const char* name, long value) {
   if (!strcmp(name, "LIDK_GEMM_PIPEK")) g_opt_pipek = (int)value;
   else if (!strcmp(name, "LIDK_GEMM_DMA")) g_opt_dma = (int)value;
   else if (!strcmp(name, "LIDK_GEMM_DMA_TILES")) g_opt_dma_tiles = value;
+  else if (!strcmp(name, "LIDK_GEMM_DMA256")) g_opt_dma256 = value;
   else return LIDK_ERR_ARG;
   return LIDK_OK;                                        // (a negative value: re-read the environment on the next launch)
 }
@@ -1041,6 +1238,38 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
         else if (mode == PIPE_BIAS_SWISH_PRE) LIDK_PIPE_LAUNCH(PIPE_BIAS_SWISH_PRE);
         else LIDK_PIPE_LAUNCH(PIPE_SWISH_GRAD);
 #undef LIDK_PIPE_LAUNCH
+        return launch_status();
+      }
+    }
+    // LDS-DMA 256x256 persistent kernel (comment at the kernel): N % 256 == 0, K % 64 == 0, K >= 512, >= LIDK_GEMM_DMA256 tiles
+    // (default 200, 0 = never) that fill the last round of the chip's CUs to >= 80 % (or >= 4 rounds).  tools/gemm_bench_wavlm.py, us
+    // per launch before -> with it: XLS-R width (M 16000) qkv 213 -> 119, out 69 -> 55, fc1 + GELU 327 -> 238, fc2 204 -> 145; conv
+    // stack layers 1 / 2 838 -> 740 / 411 -> 352; d = 768 (M 9536) dgrad fc2 90 -> 71, fc1 + GELU 108 -> 111; 342 tiles (qkv at d = 768:
+    // 1.34 rounds) 61 -> 67 and 600 tiles (conv layer 3) 181 -> 203 are why the fill rule exists.
+    {
+      gemm_opts_init();
+      static int n_cu = 0;
+      if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+      }
+      const long t256 = (long)cdiv(g->M, 256) * (g->N / 256);
+      const long rounds = (t256 + n_cu - 1) / n_cu;
+      const bool filled = t256 * 5 >= rounds * n_cu * 4 || rounds >= 4 || g_opt_dma256 == 1;
+      if (direct && splitk == 1 && g_opt_dma256 > 0 && !(g->N & 255) && (g->K & 63) == 0 && g->K >= 512 && t256 >= g_opt_dma256 && filled &&
+          (size_t)256 * g->lda * 2 < (1ull << 31) && (size_t)256 * g->ldb * 2 < (1ull << 31)) {
+        static bool attr256 = false;
+        constexpr int lds256 = 2 * (256 + 256) * BK * 2 + 8 * 4096;
+        if (!attr256) {
+          (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_dma256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+          (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_dma256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+          attr256 = true;
+        }
+        const int G = (int)(t256 < n_cu ? t256 : n_cu);      // persistent: one workgroup per CU
+        if (g->out_f32) gemm_nt_bf16_dma256_kernel<1><<<G, 512, lds256, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->K, g->lda, g->ldb, (int)t256, e);
+        else gemm_nt_bf16_dma256_kernel<0><<<G, 512, lds256, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->K, g->lda, g->ldb, (int)t256, e);
         return launch_status();
       }
     }

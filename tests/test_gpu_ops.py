@@ -658,6 +658,48 @@ def test_gemm_nt_lds_dma_128_tile(mode, gemm_options):
         check("gemm_dma_gelu", out, F.gelu(ref + bias), 3e-2, 1e-2)
 
 
+@pytest.mark.parametrize("mode", ["bf16_plain", "f32_bias_res", "gelu_pre", "gelu_grad", "strided_view"])
+@pytest.mark.parametrize("N,K", [(2304, 768), (1024, 4096), (512, 1536)])
+def test_gemm_nt_lds_dma_256_tile(mode, N, K, gemm_options):
+    """N % 256 == 0, K % 64 == 0, K >= 512 and >= LIDK_GEMM_DMA256 (here forced to 1; default 200) tiles of 256 x 256 dispatch
+    gemm_nt_bf16_dma256_kernel: the transformer backbones' QKV / FFN / conv-stack shapes.  M = 4 x 256 + 77: a clamped last row tile.
+    Every epilogue the backbones use; 'strided_view': overlapping rows (lda < K), the conv feature extractor's operand form.
+    Reference: f32 matmul of the bf16-rounded operands."""
+    gemm_options("LIDK_GEMM_DMA256", 1)
+    M = 4 * 256 + 77
+    A = (torch.randn(M, K, generator=g(180)) * 0.5).bfloat16()
+    B = (torch.randn(N, K, generator=g(181)) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, generator=g(182))
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    if mode == "strided_view":
+        x = (torch.randn(2 * M + 8 * K // 256, 256, generator=g(183)) * 0.5).bfloat16()
+        Ad = x.to(DEV).as_strided((M, K), (512, 1))                 # row t = K contiguous values from input row 2 t
+        A = x.as_strided((M, K), (512, 1))
+    ref = A.float() @ B.float().t()
+    if mode in ("bf16_plain", "strided_view"):
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(Ad, Bd, out)
+        check("gemm_dma256_bf16", out, ref, 3e-2, 1e-2)
+    elif mode == "f32_bias_res":
+        res = torch.randn(M, N, generator=g(184))
+        out = torch.empty(M, N, device=DEV)
+        ops.gemm_nt(Ad, Bd, out, bias=bias.to(DEV), alpha=0.5, res=res.to(DEV))
+        check("gemm_dma256_f32", out, 0.5 * (ref + bias) + res, 2e-3, 1e-4)
+    elif mode == "gelu_grad":
+        aux = torch.randn(M, N, generator=g(185)).bfloat16()
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(Ad, Bd, out, act=L.ACT_GELU_GRAD, aux=aux.to(DEV))
+        a = aux.float().requires_grad_()
+        F.gelu(a).sum().backward()
+        check("gemm_dma256_gelu_grad", out, ref * a.grad, 3e-2, 1e-2)
+    else:
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        pre = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(Ad, Bd, out, bias=bias.to(DEV), act=L.ACT_GELU, out2=pre)
+        check("gemm_dma256_pre", pre, ref + bias, 3e-2, 1e-2)
+        check("gemm_dma256_gelu", out, F.gelu(ref + bias), 3e-2, 1e-2)
+
+
 @pytest.mark.parametrize("M,C", [(9664, 256), (453, 144), (7, 64)])
 def test_double_layernorm_equals_two_single_launches(M, C):
     """lidk_layernorm2_fwd / _bwd (post_norm of block i + the first PreNorm of block i + 1 in one pass) against two

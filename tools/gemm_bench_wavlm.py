@@ -48,11 +48,21 @@ def run(name, m, n, k, **kw):
     if kw.pop("res", False): extra["res"] = torch.randn(m, n, device=dev)
     if kw.get("act") == L.ACT_GELU: extra["out2"] = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
     us = t(lambda: ops.gemm_nt(A, Bm, out, bias=bias, **kw, **extra), n=10)
-    print(f"{name:22s} M={m} N={n:5d} K={k:5d}: {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF/s")
+    ven = t(lambda: torch.nn.functional.linear(A, Bm), n=10)          # yardstick only: the vendor GEMM torch dispatches to, no epilogue
+    print(f"{name:22s} M={m} N={n:5d} K={k:5d}: {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TF/s   (vendor GEMM, plain: {ven:7.1f} us)")
 run("qkv", M, 2304, 768)
 run("out (+res f32)", M, 768, 768, res=True, out_f32=True)
 run("fc1 (gelu, +pre)", M, 3072, 768, act=L.ACT_GELU)
 run("fc2 (+res f32)", M, 768, 3072, res=True, out_f32=True)
+run("dgrad fc1 (gelu')", M, 768, 3072)
+run("dgrad fc2", M, 3072, 768)
+if os.environ.get("XLSR", "1") == "1":
+    print("XLS-R width (M = 16 000, d = 1024, ffn 4096)")
+    M2 = 16000
+    run("qkv", M2, 3072, 1024)
+    run("out (+res f32)", M2, 1024, 1024, res=True, out_f32=True)
+    run("fc1 (gelu, +pre)", M2, 4096, 1024, act=L.ACT_GELU)
+    run("fc2 (+res f32)", M2, 1024, 4096, res=True, out_f32=True)
 
 print("weight-gradient (TN) GEMMs, M = 9536; LIDK_TN_TILE=128 forces the 128x128 tile")
 def run_tn(name, n1, n2, sk):
