@@ -29,11 +29,24 @@ __device__ __forceinline__ float wave_max(float v) {
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the GEMM epilogues were VALU-issue bound on it
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// GELU, exact erf form (torch.nn.functional.gelu default; lid/wavlm/modules.py gelu)
-__device__ __forceinline__ float gelu_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf to 1.5e-7 ABSOLUTE (Abramowitz & Stegun 7.1.26; v_rcp_f32 adds 1 ulp of t): one rcp, one exp and seven FMAs instead of
+// the ~40 instructions of erff.  GELU only ever uses 1 + erf, where that is a relative 1.5e-7 - a tenth of an f32 ulp's worth of
+// the bf16 values these epilogues store.  (With erff the GELU epilogue of the XLS-R fc1 GEMM was VALU-issue bound: 8 192
+// activations per lane and tile.)
+__device__ __forceinline__ float erf_(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  return copysignf(1.0f - p * t * __expf(-ax * ax), x);
+}
+// GELU, erf form (torch.nn.functional.gelu default; lid/wavlm/modules.py gelu)
+__device__ __forceinline__ float gelu_(float x) { return 0.5f * x * (1.0f + erf_(x * 0.70710678118654752f)); }
 // d/dx gelu(x) = Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_grad_(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+  return 0.5f * (1.0f + erf_(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
 // 4-wide load/store of activations held as T (float or bf16); p must be 4-element aligned.

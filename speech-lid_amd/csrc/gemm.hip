@@ -649,31 +649,55 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
   constexpr bool pair = !EPI_F32;
   const int G = gridDim.x, slot = xcd_tile(blockIdx.x, G);
   const int nt = K / BK;
-  // per-lane byte offsets of this wave's 4 + 4 wave instructions per K tile (tile-row 32 wid + 8 i + lane / 8, chunk lane % 8)
-  unsigned aoff[4], boff[4];
-  const bf16* abase;
-  const bf16* bbase;
+  // ROLES.  vmcnt retires a wave's loads AND stores in issue order, so a wave that has stored a tile cannot wait for the next
+  // tile's operands without waiting for those stores as well.  Waves 0-3 therefore issue every LDS-DMA load (8 + 8 wave
+  // instructions per K tile each) and no global store; waves 4-7 issue every global store (their own 128 x 64 block and, handed
+  // over through LDS, the block of wave w - 4 above it) and never wait on vmcnt in the K loop: a tile's stores drain under the next
+  // tile's K loop.
+  const bool loader = wid < 4;
+  // a loader's 8 + 8 wave instructions per K tile: tile-row 64 w + 8 i + lane / 8, 16-byte chunk (lane % 8) ^ (lane / 8).  One lane
+  // offset per operand; the row step of instruction i rides in the scalar base (A: 8 i rows; B: the LDS-row -> output-column
+  // permutation of the 8-consecutive-columns epilogue is affine in the bits of i), except in the last row tile of a ragged M,
+  // whose rows are clamped per lane.
+  const int arow0 = 64 * (wid & 3) + (lane >> 3);
+  const unsigned cofs = (unsigned)(((lane & 7) ^ (lane >> 3)) * 16);
+  const unsigned aoff0 = (unsigned)((size_t)arow0 * lda * 2) + cofs;
+  const int brow0 = pair ? (arow0 & ~31) + (((arow0 >> 2) & 3) << 3) + (((arow0 >> 4) & 1) << 2) + (arow0 & 3) : arow0;
+  const unsigned boff0 = (unsigned)((size_t)brow0 * ldb * 2) + cofs;
+  const bf16* abase = A;
+  const bf16* bbase = B;
+  int mlim = 0;                                              // last valid row of the tile, relative to its first
+  bool tail = false;
   auto set_tile = [&](int tile) __attribute__((always_inline)) {
     const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = 32 * wid + 8 * i + (lane >> 3), c = (lane & 7) ^ (row & 7);
-      aoff[i] = (unsigned)(((size_t)(min(m0 + row, M - 1) - m0) * lda + c * 8) * 2);
-      const int n = pair ? (row & ~31) + (((row >> 2) & 3) << 3) + (((row >> 4) & 1) << 2) + (row & 3) : row;   // LDS row -> column
-      boff[i] = (unsigned)(((size_t)n * ldb + c * 8) * 2);
-    }
     abase = A + (size_t)m0 * lda;
     bbase = B + (size_t)n0 * ldb;
+    mlim = M - 1 - m0;
+    tail = mlim < BM - 1;
   };
   auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
-    const unsigned dst = smem0 + buf * STAGE + (32 * wid) * 128;
+    if (loader) {
+      const unsigned dst = smem0 + buf * STAGE + (64 * wid) * 128;
+      const bf16* ak = abase + kt * BK;
+      const bf16* bk = bbase + kt * BK;
+      if (tail) {
+        int r0 = arow0;
+        asm volatile("" : "+v"(r0));                         // recomputed per call: hoisted out of the K loop these 8 offsets spill
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gemm_glds16s(abase + kt * BK, aoff[i], dst + i * 1024);
+        for (int i = 0; i < 8; ++i)
+          gemm_glds16s(ak, (unsigned)((size_t)min(r0 + 8 * i, mlim) * lda * 2) + cofs, dst + i * 1024);
+      } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gemm_glds16s(bbase + kt * BK, boff[i], dst + BM * BK * 2 + i * 1024);
+        for (int i = 0; i < 8; ++i) gemm_glds16s(ak + (size_t)(8 * i) * lda, aoff0, dst + i * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int dn = pair ? 16 * (i & 1) + 4 * ((i >> 1) & 1) + 32 * (i >> 2) : 8 * i;
+        gemm_glds16s(bk + (size_t)dn * ldb, boff0, dst + BM * BK * 2 + i * 1024);
+      }
+    }
   };
-  const bool vec = !(e.ldo & 7) && (!e.res || !(e.ldres & 3)) && (!e.out2 || !(e.ldo2 & 7)) && (!e.aux || !(e.ldaux & 7));
-  unsigned char* wl = dma_smem + 2 * STAGE + wid * 4096;
+  unsigned char* wl = dma_smem + 2 * STAGE + wid * 4096;          // this wave's staging slice; wl - 4 * 4096: the partner's (waves 4-7)
 
   int tile = slot;
   if (tile >= total_tiles) return;
@@ -687,27 +711,31 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < nt; ++t) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile t landed (this wave's pieces), barrier: everybody's; and
-      __syncthreads();                                       // every wave is done reading the other buffer
+      if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K tile t landed (the loaders' pieces = all of it); barrier:
+      __syncthreads();                                                // everybody sees it, and is done reading the other buffer
       if (t + 1 < nt && !((e.dbg & 32) && t > 0)) stage(t + 1, (t + 1) & 1);
       if (e.dbg & 64) continue;
       const bf16* a = reinterpret_cast<const bf16*>(dma_smem + (t & 1) * STAGE);
       const bf16* b = a + BM * BK;
 #pragma unroll
       for (int kk = 0; kk < BK / 8; kk += 4) {
-        bf16x8 af[TM], bfr[TN];
+        bf16x8 bfr[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           bfr[j] = *reinterpret_cast<const bf16x8*>(&b[(wn * 64 + j * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-          af[i] = *reinterpret_cast<const bf16x8*>(&a[(wm * 128 + i * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
-        __builtin_amdgcn_s_setprio(1);
+        for (int ih = 0; ih < TM; ih += 4) {                 // A fragments four row tiles at a time: 32 instead of 48 fragment registers
+          bf16x8 af[4];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < 4; ++i)
+            af[i] = *reinterpret_cast<const bf16x8*>(&a[(wm * 128 + (ih + i) * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+          __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[ih + i][j], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+        }
       }
     }
     // the next tile's first K tile is requested now: it lands while this tile's epilogue runs
@@ -723,11 +751,24 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(acc[i][j]));
-    } else if (vec) {
+    } else {
+      // Stores through LDS, whole 128 B lines, 32 rows (bf16) / 16 rows (f32) of a wave's block at a time: every wave leaves the
+      // slice in its 4 KB, barrier, waves 4-7 write out their own and wave (w - 4)'s, barrier.
       if (pair) {
         const bool two = (e.act == LIDK_ACT_SWISH || e.act == LIDK_ACT_GELU) && e.out2;
+        // the bias of this lane's 16 columns once per tile, ahead of the first store: a load issued behind stores is not
+        // returned before they are acknowledged
+        float4 bz[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int n = n0 + wn * 64 + 32 * c + 8 * fq;
+          bz[c][0] = e.bias ? load4(e.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+          bz[c][1] = e.bias ? load4(e.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        Epi eb = e;
+        eb.bias = nullptr;
 #pragma clang loop unroll(full)
-        for (int i2 = 0; i2 < TM / 2; ++i2) {                // 32 rows at a time through the wave's 4 KB
+        for (int i2 = 0; i2 < TM / 2; ++i2) {
           uint4 pk[2][2], pp[2][2];
 #pragma clang loop unroll(full)
           for (int ii = 0; ii < 2; ++ii) {
@@ -735,11 +776,13 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
 #pragma clang loop unroll(full)
             for (int c = 0; c < TN / 2; ++c) {
               const int n = n0 + wn * 64 + 32 * c + 8 * fq;
-              const float4 a0 = make_float4(acc[i][2 * c][0], acc[i][2 * c][1], acc[i][2 * c][2], acc[i][2 * c][3]);
-              const float4 a1 = make_float4(acc[i][2 * c + 1][0], acc[i][2 * c + 1][1], acc[i][2 * c + 1][2], acc[i][2 * c + 1][3]);
+              const float4 a0 = make_float4(acc[i][2 * c][0] + bz[c][0].x, acc[i][2 * c][1] + bz[c][0].y, acc[i][2 * c][2] + bz[c][0].z,
+                                            acc[i][2 * c][3] + bz[c][0].w);
+              const float4 a1 = make_float4(acc[i][2 * c + 1][0] + bz[c][1].x, acc[i][2 * c + 1][1] + bz[c][1].y,
+                                            acc[i][2 * c + 1][2] + bz[c][1].z, acc[i][2 * c + 1][3] + bz[c][1].w);
               float4 p0 = a0, p1 = a1;
-              const float4 v0 = epi_math4(e, m, n, a0, &p0);
-              const float4 v1 = epi_math4(e, m, n + 4, a1, &p1);
+              const float4 v0 = epi_math4(eb, m, n, a0, &p0);
+              const float4 v1 = epi_math4(eb, m, n + 4, a1, &p1);
               pk[ii][c] = pack8(v0, v1);
               pp[ii][c] = pack8(p0, p1);
             }
@@ -754,14 +797,22 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
                 const int row = ii * 16 + fr;
                 *reinterpret_cast<uint4*>(wl + row * 128 + (((4 * c + fq) ^ (row & 7)) << 4)) = ps ? pp[ii][c] : pk[ii][c];
               }
-            bf16* dst = ps ? (bf16*)e.out2 : (bf16*)e.out;
-            const int ldd = ps ? e.ldo2 : e.ldo;
+            __syncthreads();
+            if (!loader) {
+              bf16* dst = ps ? (bf16*)e.out2 : (bf16*)e.out;
+              const int ldd = ps ? e.ldo2 : e.ldo;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-              const int row = it * 8 + (lane >> 3), m = m0 + wm * 128 + i2 * 32 + row;
-              const uint4 v = *reinterpret_cast<const uint4*>(wl + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
-              if (m < M) st16(e, dst + (size_t)m * ldd + n0 + wn * 64 + (lane & 7) * 8, v);
+              for (int own = 1; own >= 0; --own) {             // own = 1: this wave's rows (wm = 1); 0: the partner's (wm = 0)
+                const unsigned char* src = wl - (own ? 0 : 4 * 4096);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                  const int row = it * 8 + (lane >> 3), m = m0 + own * 128 + i2 * 32 + row;
+                  const uint4 v = *reinterpret_cast<const uint4*>(src + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                  if (m < M) st16(e, dst + (size_t)m * ldd + n0 + wn * 64 + (lane & 7) * 8, v);
+                }
+              }
             }
+            __syncthreads();
           }
           __builtin_amdgcn_sched_barrier(0);                 // one slice at a time: the aux loads of all would not fit the registers
         }
@@ -778,36 +829,32 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
                                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]), &p0);
             *reinterpret_cast<float4*>(wl + fr * 256 + (((4 * j + fq) ^ fr) << 4)) = v;
           }
+          __syncthreads();
+          if (!loader) {
+            // all 8 residual loads of the slice first, then its 8 stores (a load behind a store waits for the store's acknowledgement)
+            float4 rr[2][4];
 #pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int row = it * 4 + (lane >> 4), m = m0 + wm * 128 + i * 16 + row, n = n0 + wn * 64 + (lane & 15) * 4;
-            float4 v = *reinterpret_cast<const float4*>(wl + row * 256 + (((lane & 15) ^ row) << 4));
-            if (m < M) {
-              if (e.res) { const float4 r = load4(e.res + (size_t)m * e.ldres + n); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-              store4((float*)e.out + (size_t)m * e.ldo + n, v);
+            for (int own = 1; own >= 0; --own)
+#pragma unroll
+              for (int it = 0; it < 4; ++it) {
+                const int row = it * 4 + (lane >> 4), m = min(m0 + own * 128 + i * 16 + row, M - 1), n = n0 + wn * 64 + (lane & 15) * 4;
+                rr[own][it] = e.res ? load4(e.res + (size_t)m * e.ldres + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+              }
+#pragma unroll
+            for (int own = 1; own >= 0; --own) {
+              const unsigned char* src = wl - (own ? 0 : 4 * 4096);
+#pragma unroll
+              for (int it = 0; it < 4; ++it) {
+                const int row = it * 4 + (lane >> 4), m = m0 + own * 128 + i * 16 + row, n = n0 + wn * 64 + (lane & 15) * 4;
+                float4 v = *reinterpret_cast<const float4*>(src + row * 256 + (((lane & 15) ^ row) << 4));
+                const float4 r = rr[own][it];
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                if (m < M) store4((float*)e.out + (size_t)m * e.ldo + n, v);
+              }
             }
           }
+          __syncthreads();
           __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    } else {
-#pragma clang loop unroll(full)
-      for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + fr;
-        if (m >= M) continue;
-        if (pair) {
-#pragma clang loop unroll(full)
-          for (int c = 0; c < TN / 2; ++c) {
-            const int n = n0 + wn * 64 + 32 * c + 8 * fq;
-            epi_store4<bf16>(e, m, n, N, make_float4(acc[i][2 * c][0], acc[i][2 * c][1], acc[i][2 * c][2], acc[i][2 * c][3]));
-            epi_store4<bf16>(e, m, n + 4, N, make_float4(acc[i][2 * c + 1][0], acc[i][2 * c + 1][1], acc[i][2 * c + 1][2], acc[i][2 * c + 1][3]));
-          }
-        } else {
-#pragma clang loop unroll(full)
-          for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * 64 + 16 * j + 4 * fq;
-            epi_store4<bf16>(e, m, n, N, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
-          }
         }
       }
     }
@@ -1258,7 +1305,8 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
       const long t256 = (long)cdiv(g->M, 256) * (g->N / 256);
       const long rounds = (t256 + n_cu - 1) / n_cu;
       const bool filled = t256 * 5 >= rounds * n_cu * 4 || rounds >= 4 || g_opt_dma256 == 1;
-      if (direct && splitk == 1 && g_opt_dma256 > 0 && !(g->N & 255) && (g->K & 63) == 0 && g->K >= 512 && t256 >= g_opt_dma256 && filled &&
+      const bool vec256 = !(g->ldo & 7) && (!g->res || !(g->ldres & 3)) && (!g->out2 || !(g->ldo2 & 7)) && (!g->aux || !(g->ldaux & 7));
+      if (direct && splitk == 1 && g_opt_dma256 > 0 && !(g->N & 255) && (g->K & 63) == 0 && g->K >= 512 && t256 >= g_opt_dma256 && filled && vec256 &&
           (size_t)256 * g->lda * 2 < (1ull << 31) && (size_t)256 * g->ldb * 2 < (1ull << 31)) {
         static bool attr256 = false;
         constexpr int lds256 = 2 * (256 + 256) * BK * 2 + 8 * 4096;
