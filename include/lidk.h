@@ -218,6 +218,15 @@ int lidk_ffn_fwd_ln(const float* x, const void* h_in, const float* gamma, const 
  * post_norm (lidk_layernorm2_bwd).  da feeds the weight gradients (lidk_gemm_tn: dW1 = da^T h, db1 = colsum da; dW2 = dyT^T u).
  * Replaces 2 x lidk_gemm_nt + lidk_layernorm_bwd; returns LIDK_ERR_UNSUPPORTED as lidk_ffn_fwd does. */
 int lidk_ffn_bwd_partial_rows(int M);
+/* Operand refresh of the transformer backbones after an optimizer step (speech-lid_amd/lidk/wavlm.py _refresh_inplace; the
+ * reference keeps one f32 tensor per Linear and lets autograd / AMP cast it: lid/wavlm/modules.py, s3prl wav2vec2.py).  descs =
+ * device array of n records {const float* src; bf16* dst; bf16* dstT; float* dst32; int R, C, lds, ldd, ldt, ld32, tiles_c, tile0;}
+ * (lidk_cast_transpose_desc_bytes() bytes each): src [R][C] f32 is read once and written as bf16 (dst, may be NULL), as the
+ * transposed bf16 matrix dstT [C][R] (may be NULL) and / or as f32 (dst32, may be NULL).  C % 4 == 0; R % 4 == 0 where dstT is
+ * given; leading dimensions multiples of 4.  tiles_c = ceil(C / 64), tile0 = first of the record's ceil(R / 64) * tiles_c
+ * workgroups; total_tiles = their sum over the n records (n small: a workgroup finds its record by scanning). */
+int lidk_cast_transpose_desc_bytes(void);
+int lidk_cast_transpose_grouped(const void* descs, int n, int total_tiles, void* stream);
 /* Workgroup height of lidk_ffn_fwd* / lidk_ffn_bwd* / lidk_dgrad_ln_bwd: "LIDK_FFN_RG" = 3 (48 rows, 6 waves) or 4 (64 rows, 8 waves)
  * forces one form, 0 chooses by M (48 rows while ceil(M / 48) <= 256, one workgroup per CU in one round), negative re-reads the
  * environment variable of that name.  lidk_ffn_bwd_partial_rows follows the setting: query it after changing this. */

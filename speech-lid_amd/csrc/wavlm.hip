@@ -953,3 +953,48 @@ extern "C" int lidk_wavlm_conv0_bwd(const float* wav, int B, int L, const float*
   wavlm_conv0_bwd_apply_kernel<<<grid, 256, 0, s>>>(wav, L, w, stats, gamma, beta, (const bf16*)dy0, sums, dw, dgamma, dbeta, T0, P0, C);
   return launch_status();
 }
+
+// ------------------------------------------------------------------------------------ operand refresh after an optimizer step
+// The backbones keep, per Linear, the f32 parameter (optimizer's), its bf16 copy W [N][K] (forward: out = x . W^T) and the bf16
+// transpose W^T [K][N] (data gradient as an NT GEMM).  Refreshing those with torch copies cost ~310 us per XLS-R layer (14 copy /
+// transposing-copy launches, 7.5 of a 98 ms fine-tune step).  Here one launch per layer: every record is a f32 matrix read ONCE
+// through 64 x 64 LDS tiles and written as bf16 (dst), transposed bf16 (dstT) and / or f32 (dst32: the packed q|k|v bias).
+struct CtDesc {
+  const float* src; bf16* dst; bf16* dstT; float* dst32;
+  int R, C, lds, ldd, ldt, ld32, tiles_c, tile0;          // rows, columns, leading dimensions (elements), column tiles, first tile
+};
+extern "C" int lidk_cast_transpose_desc_bytes(void) { return (int)sizeof(CtDesc); }
+
+__global__ void __launch_bounds__(256) cast_transpose_grouped_kernel(const CtDesc* __restrict__ descs, int n) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int d = 0;
+  while (d + 1 < n && descs[d + 1].tile0 <= b) ++d;         // block-uniform; n is a handful
+  const CtDesc D = descs[d];
+  const int t = b - D.tile0, r0 = (t / D.tiles_c) * 64, c0 = (t % D.tiles_c) * 64;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int rl = (tid >> 4) + 16 * it, cl = 4 * (tid & 15), r = r0 + rl, c = c0 + cl;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < D.R && c < D.C) {                               // C % 4 == 0 (host check): whole vectors in or out
+      v = load4(D.src + (size_t)r * D.lds + c);
+      if (D.dst) store4(D.dst + (size_t)r * D.ldd + c, v);
+      if (D.dst32) store4(D.dst32 + (size_t)r * D.ld32 + c, v);
+    }
+    tile[rl][cl] = v.x; tile[rl][cl + 1] = v.y; tile[rl][cl + 2] = v.z; tile[rl][cl + 3] = v.w;
+  }
+  if (!D.dstT) return;                                      // block-uniform
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int cl = (tid >> 4) + 16 * it, rl = 4 * (tid & 15), c = c0 + cl, r = r0 + rl;
+    if (c < D.C && r < D.R)                                 // R % 4 == 0 for records with a transpose (host check)
+      store4(D.dstT + (size_t)c * D.ldt + r, make_float4(tile[rl][cl], tile[rl + 1][cl], tile[rl + 2][cl], tile[rl + 3][cl]));
+  }
+}
+
+extern "C" int lidk_cast_transpose_grouped(const void* descs, int n, int total_tiles, void* stream) {
+  if (!descs || n <= 0 || total_tiles <= 0) return LIDK_ERR_ARG;
+  cast_transpose_grouped_kernel<<<total_tiles, 256, 0, as_stream(stream)>>>((const CtDesc*)descs, n);
+  return launch_status();
+}

@@ -467,6 +467,43 @@ def layernorm_param_grads_grouped(group):
     check(lib().lidk_layernorm_param_grads_grouped(_p(table), n, Cn, _stream()), "layernorm_param_grads_grouped")
 
 
+class _CtDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dstT", C.c_void_p), ("dst32", C.c_void_p), ("R", C.c_int), ("C", C.c_int),
+                ("lds", C.c_int), ("ldd", C.c_int), ("ldt", C.c_int), ("ld32", C.c_int), ("tiles_c", C.c_int), ("tile0", C.c_int)]
+
+
+def build_cast_transpose_group(entries):
+    """Descriptor table for cast_transpose_grouped.  entries: list of (src f32 [R, C], dst bf16 [R, C] | None, dstT bf16 [C, R] |
+    None, dst32 f32 [R, C] | None); views with a unit inner stride; raw pointers inside - rebuild when a tensor moves."""
+    if lib().lidk_cast_transpose_desc_bytes() != C.sizeof(_CtDesc):
+        raise LidkError("CtDesc layout mismatch between ops.py and liblidk.so")
+    arr = (_CtDesc * len(entries))()
+    tile0 = 0
+    for i, (src, dst, dstT, dst32) in enumerate(entries):
+        src2 = src if src.dim() == 2 else src.view(1, -1)
+        R, Cn = src2.shape
+        bad = Cn % 4 or src2.stride(1) != 1 or src2.dtype != torch.float32 or (R > 1 and src2.stride(0) % 4)
+        for t, shape, dt in ((dst, (R, Cn), torch.bfloat16), (dstT, (Cn, R), torch.bfloat16), (dst32, (R, Cn), torch.float32)):
+            if t is not None:
+                t2 = t if t.dim() == 2 else t.view(1, -1)
+                bad = bad or tuple(t2.shape) != shape or t2.dtype != dt or t2.stride(1) != 1 or (t2.shape[0] > 1 and t2.stride(0) % 4)
+        if bad or (dstT is not None and R % 4):
+            raise LidkError(f"cast_transpose_grouped: record {i} has an unsupported shape / stride / dtype")
+        ld = lambda t: 0 if t is None else (t.stride(0) if t.dim() == 2 else t.numel())
+        a = arr[i]
+        a.src, a.dst, a.dstT, a.dst32 = _pv(src2), _pv(dst), _pv(dstT), _pv(dst32)
+        a.R, a.C, a.lds, a.ldd, a.ldt, a.ld32 = R, Cn, ld(src2), ld(dst), ld(dstT), ld(dst32)
+        a.tiles_c, a.tile0 = -(-Cn // 64), tile0
+        tile0 += -(-R // 64) * a.tiles_c
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(entries[0][0].device), len(entries), tile0
+
+
+def cast_transpose_grouped(group):
+    table, n, tiles = group
+    check(lib().lidk_cast_transpose_grouped(_p(table), n, tiles, _stream()), "cast_transpose_grouped")
+
+
 def layernorm_bwd_partial_rows(M):
     """Partial rows lidk_layernorm_bwd / lidk_layernorm2_bwd write for M rows (what lidk_layernorm_param_grads assumes)."""
     return min(-(-M // 4), L.LN_BWD_BLOCKS)

@@ -528,3 +528,31 @@ def test_full_finetune_step_with_unfrozen_feature_extractor_against_the_referenc
     per.mean().backward()
     params = dict(m.named_parameters())
     assert all(p.grad is None for k, p in params.items() if ".feature_extractor." in k or ".post_extract_proj." in k)
+
+
+def test_cast_transpose_grouped_equals_torch_copies():
+    """lidk_cast_transpose_grouped (the backbones' operand refresh after an optimizer step): f32 parameter -> bf16 operand, its
+    transpose written into a column slice of a wider matrix, and the packed f32 bias, several records in one launch - bit-equal to
+    the torch converting / transposing copies it replaces."""
+    from lidk import ops
+    g = torch.Generator().manual_seed(5)
+    d = 192
+    ws = [torch.randn(d, d, generator=g).to(DEV) for _ in range(3)]
+    bs = [torch.randn(d, generator=g).to(DEV) for _ in range(3)]
+    w1, w2 = torch.randn(4 * d, d, generator=g).to(DEV), torch.randn(d, 4 * d + 64, generator=g).to(DEV)[:, :4 * d]   # row-strided source
+    wqkv = torch.zeros(3 * d, d, device=DEV, dtype=torch.bfloat16)
+    wqkvT = torch.zeros(d, 3 * d, device=DEV, dtype=torch.bfloat16)
+    bqkv = torch.zeros(3 * d, device=DEV)
+    o1, o1T = torch.zeros(4 * d, d, device=DEV, dtype=torch.bfloat16), torch.zeros(d, 4 * d, device=DEV, dtype=torch.bfloat16)
+    o2T = torch.zeros(4 * d, d, device=DEV, dtype=torch.bfloat16)
+    ent = []
+    for j in range(3):
+        ent.append((ws[j], wqkv[j * d:(j + 1) * d], wqkvT[:, j * d:(j + 1) * d], None))
+        ent.append((bs[j], None, None, bqkv[j * d:(j + 1) * d]))
+    ent.append((w1, o1, o1T, None))
+    ent.append((w2, None, o2T, None))
+    ops.cast_transpose_grouped(ops.build_cast_transpose_group(ent))
+    torch.cuda.synchronize()
+    W = torch.cat(ws, 0)
+    assert torch.equal(wqkv, W.bfloat16()) and torch.equal(wqkvT, W.bfloat16().t()) and torch.equal(bqkv, torch.cat(bs))
+    assert torch.equal(o1, w1.bfloat16()) and torch.equal(o1T, w1.bfloat16().t()) and torch.equal(o2T, w2.bfloat16().t())
