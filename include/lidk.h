@@ -218,6 +218,18 @@ int lidk_ffn_fwd_ln(const float* x, const void* h_in, const float* gamma, const 
  * post_norm (lidk_layernorm2_bwd).  da feeds the weight gradients (lidk_gemm_tn: dW1 = da^T h, db1 = colsum da; dW2 = dyT^T u).
  * Replaces 2 x lidk_gemm_nt + lidk_layernorm_bwd; returns LIDK_ERR_UNSUPPORTED as lidk_ffn_fwd does. */
 int lidk_ffn_bwd_partial_rows(int M);
+/* torch.optim.Adam / torch.optim.SGD over a list of f32 tensors in one launch (the reference's optimizers for the wav2vec2 / WavLM
+ * confs: lid/LidModule_ASR.py:143-150, lid/conf/xf_asr_wav2vec.yaml:25, xf_asr_extra_finetune.yaml:22).  chunks = device array of
+ * n_chunks records {float* p; const float* g; float* m; float* v; int n; int pad;} (lidk_mt_chunk_bytes() bytes each), n <=
+ * lidk_mt_chunk_elems() consecutive elements of one tensor: parameter, gradient, exp_avg / momentum buffer, exp_avg_sq (unused by
+ * SGD; m == NULL: SGD without momentum).  Update rules of torch's single-tensor implementations; bias_correction{1,2} = 1 - beta^t. */
+#define LIDK_MT_CHUNK 16384
+int lidk_mt_chunk_bytes(void);
+int lidk_mt_chunk_elems(void);
+int lidk_adam_multi(const void* chunks, int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    double bias_correction1, double bias_correction2, int maximize, void* stream);
+int lidk_sgd_multi(const void* chunks, int n_chunks, float lr, float momentum, float dampening, float weight_decay, int nesterov,
+                   int first_step, int maximize, void* stream);
 /* Operand refresh of the transformer backbones after an optimizer step (speech-lid_amd/lidk/wavlm.py _refresh_inplace; the
  * reference keeps one f32 tensor per Linear and lets autograd / AMP cast it: lid/wavlm/modules.py, s3prl wav2vec2.py).  descs =
  * device array of n records {const float* src; bf16* dst; bf16* dstT; float* dst32; int R, C, lds, ldd, ldt, ld32, tiles_c, tile0;}

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from ccml.ccml_module import CCMLModule
+from ccml.optim.multi_tensor import SGD, Adam
 from ccml.optim.novograd import Novograd
 from ccml.optim.tri_state import TriStageLRSchedule
 from lid.ConformerLangModel import ConformerMutiLangModel, CtcLossFn
@@ -57,14 +58,14 @@ class LidSuperviseModule(CCMLModule):
         params = list(self.model.parameters())
         name = self.optimizer_name
         if name == "sgd":
-            optimizer = torch.optim.SGD(params, **self.optimizer_param)
+            optimizer = SGD(params, **self.optimizer_param)
         elif name == "adam":
-            optimizer = torch.optim.Adam(params, **self.optimizer_param)
+            optimizer = Adam(params, **self.optimizer_param)
         elif name == "novograd":
             optimizer = Novograd(params, **self.optimizer_param)
         else:
             logging.warning("optimizer %s unknown, using SGD", name)
-            optimizer = torch.optim.SGD(params, **self.optimizer_param)
+            optimizer = SGD(params, **self.optimizer_param)
         if self.scheduler == "reduce":
             sched = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer=optimizer, **self.scheduler_param)
             return optimizer, sched, {"monitor": "val_loss", "interval": "epoch"}

@@ -69,6 +69,10 @@ SIGNATURES = {
     "lidk_ffn_bwd_ln2": (_I, [_P, _P, _P, _I, _P, _I, _P] + [_P] * 9 + [_P, _P, _F, _P, _P, _I, _I, _I, _I, _P]),
     "lidk_ffn_bwd_partial_rows": (_I, [_I]),
     "lidk_ffn_option": (_I, [C.c_char_p, _L]),
+    "lidk_mt_chunk_bytes": (_I, []),
+    "lidk_mt_chunk_elems": (_I, []),
+    "lidk_adam_multi": (_I, [_P, _I, _F, _F, _F, _F, _F, _D, _D, _I, _P]),
+    "lidk_sgd_multi": (_I, [_P, _I, _F, _F, _F, _F, _I, _I, _I, _P]),
     "lidk_cast_transpose_desc_bytes": (_I, []),
     "lidk_cast_transpose_grouped": (_I, [_P, _I, _I, _P]),
     "lidk_ffn_bwd": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P]),

@@ -1159,3 +1159,41 @@ def test_gemm_with_batchnorm_swish_backward_sums_in_the_epilogue():
     assert err <= 2e-6 and float(got[2 * N]) == M
     # shapes outside the pipelined kernel are refused (the engine then issues the two launches)
     assert ops.gemm_nt_bn_sums(A[:640], W, ds1[:640], c[:640], mean, rstd, gamma, beta, part2) == 0
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_multi_tensor_adam_and_sgd_follow_torch(wd):
+    """ccml.optim.multi_tensor.Adam / SGD (one lidk_adam_multi / lidk_sgd_multi launch per step) against torch.optim.Adam / SGD on the
+    same parameters and gradients for several steps: tensors of odd sizes (scalar tail, unaligned views of a flat buffer), one
+    parameter that only gets a gradient from the third step on (its own bias-correction step count), state in torch's layout."""
+    from ccml.optim.multi_tensor import SGD, Adam
+    gen = g(300)
+    shapes = [(1024, 257), (13,), (4096,), (3, 5, 7), (16384 * 2 + 5,)]
+    flat = torch.randn(sum(int(np.prod(s)) for s in shapes) + 3, generator=gen)
+    for cls, ref_cls, kw in ((Adam, torch.optim.Adam, dict(lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=wd)),
+                             (SGD, torch.optim.SGD, dict(lr=0.05, momentum=0.9, weight_decay=wd, nesterov=True)),
+                             (SGD, torch.optim.SGD, dict(lr=0.05, weight_decay=wd))):
+        ours, theirs, off = [], [], 3                                    # offset 3: views that are not 16-byte aligned
+        buf = flat.clone().to(DEV)
+        for s in shapes:
+            n = int(np.prod(s))
+            ours.append(torch.nn.Parameter(buf[off:off + n].view(s)))
+            theirs.append(torch.nn.Parameter(flat[off:off + n].clone().view(s).to(DEV)))
+            off += n
+        oa, ob = cls(ours, **kw), ref_cls(theirs, foreach=False, **kw)
+        for step in range(5):
+            for i, (a, b) in enumerate(zip(ours, theirs)):
+                if i == 1 and step < 2:
+                    a.grad = b.grad = None
+                    continue
+                gr = torch.randn(a.shape, generator=gen).to(DEV)
+                a.grad, b.grad = gr.clone(), gr.clone()
+            oa.step(); ob.step()
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(ours, theirs)):
+            err = float((a - b).abs().max())
+            assert err <= 2e-6 * max(1.0, float(b.abs().max())), (cls.__name__, kw, i, err)
+        if cls is Adam:
+            sa, sb = oa.state[ours[1]], ob.state[theirs[1]]
+            assert float(sa["step"]) == float(sb["step"]) == 3.0
+            assert float((sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max()) <= 1e-6
