@@ -1218,7 +1218,7 @@ static void gemm_opts_init() {
   if (g_opt_pipek < 0) { const char* v = getenv("LIDK_GEMM_PIPEK"); g_opt_pipek = v ? atoi(v) : 1; }
   if (g_opt_dma < 0) { const char* v = getenv("LIDK_GEMM_DMA"); g_opt_dma = v ? atoi(v) : 1024; }
   if (g_opt_dma_tiles < 0) { const char* v = getenv("LIDK_GEMM_DMA_TILES"); g_opt_dma_tiles = v ? atol(v) : 384; }
-  if (g_opt_dma256 < 0) { const char* v = getenv("LIDK_GEMM_DMA256"); g_opt_dma256 = v ? atol(v) : 200; }
+  if (g_opt_dma256 < 0) { const char* v = getenv("LIDK_GEMM_DMA256"); g_opt_dma256 = v ? atol(v) : 150; }
 }
 extern "C" int lidk_gemm_option(const char* name, long value) {
   if (!name) return LIDK_ERR_ARG;
@@ -1289,10 +1289,12 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
       }
     }
     // LDS-DMA 256x256 persistent kernel (comment at the kernel): N % 256 == 0, K % 64 == 0, K >= 512, >= LIDK_GEMM_DMA256 tiles
-    // (default 200, 0 = never) that fill the last round of the chip's CUs to >= 80 % (or >= 4 rounds).  tools/gemm_bench_wavlm.py, us
-    // per launch before -> with it: XLS-R width (M 16000) qkv 213 -> 119, out 69 -> 55, fc1 + GELU 327 -> 238, fc2 204 -> 145; conv
-    // stack layers 1 / 2 838 -> 740 / 411 -> 352; d = 768 (M 9536) dgrad fc2 90 -> 71, fc1 + GELU 108 -> 111; 342 tiles (qkv at d = 768:
-    // 1.34 rounds) 61 -> 67 and 600 tiles (conv layer 3) 181 -> 203 are why the fill rule exists.
+    // (default 150, 0 = never, 1 = always) whose last round fills >= 65 % of the CUs (or >= 3 rounds).  tools/gemm_shapes_ab.py
+    // (profiles/r04/gemm_shapes_ab.txt), default dispatch -> this kernel forced, us per launch: 189 tiles (0.74 rounds; M 16000 N 768)
+    // K 768 50 -> 46, K 3072 142 -> 101; 342 tiles (1.34) 72 -> 58; 567 (2.21) 111 -> 85; 756 (2.95) 90 -> 88; but 114 tiles (0.45)
+    // 30 -> 42 / 62 -> 94 and 282 tiles (1.10 rounds: a second round for 26 tiles) 84 -> 87 / 193 -> 207: that is the fill rule.
+    // XLS-R width (M 16000; tools/gemm_bench_wavlm.py, before the kernel -> with it): qkv 213 -> 104, out 69 -> 59, fc1 + GELU 327 ->
+    // 186, fc2 204 -> 136; conv stack layers 1 / 2 838 -> 749 / 411 -> 349.
     {
       gemm_opts_init();
       static int n_cu = 0;
@@ -1304,7 +1306,7 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
       }
       const long t256 = (long)cdiv(g->M, 256) * (g->N / 256);
       const long rounds = (t256 + n_cu - 1) / n_cu;
-      const bool filled = t256 * 5 >= rounds * n_cu * 4 || rounds >= 4 || g_opt_dma256 == 1;
+      const bool filled = t256 * 100 >= rounds * n_cu * 65 || rounds >= 3 || g_opt_dma256 == 1;
       const bool vec256 = !(g->ldo & 7) && (!g->res || !(g->ldres & 3)) && (!g->out2 || !(g->ldo2 & 7)) && (!g->aux || !(g->ldaux & 7));
       if (direct && splitk == 1 && g_opt_dma256 > 0 && !(g->N & 255) && (g->K & 63) == 0 && g->K >= 512 && t256 >= g_opt_dma256 && filled && vec256 &&
           (size_t)256 * g->lda * 2 < (1ull << 31) && (size_t)256 * g->ldb * 2 < (1ull << 31)) {
