@@ -105,6 +105,19 @@ __device__ __forceinline__ float uniform_from(uint64_t seed, uint64_t idx) {
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
+// The cheap form for per-element decisions inside MFMA kernels (attention dropout of lidk_xattn_*): three 32-bit multiplies with
+// xor-shifts ("lowbias32", the fused feature path's dither generator) of (seed, element index) -> 24-bit uniform.  splitmix64 costs
+// ~60 VALU issue slots per element on CDNA (its 64-bit multiplies are built from quarter-rate 32-bit ones) - more than the two MFMAs
+// an attention score takes part in.  Index bits above 32 are folded into the seed's high word.
+__device__ __forceinline__ float uniform32_from(uint64_t seed, uint64_t idx) {
+  uint32_t h = (uint32_t)idx * 0x9E3779B1u + (uint32_t)seed;
+  h ^= h >> 16; h *= 0x21F0AAADu;
+  h ^= (uint32_t)(seed >> 32) + (uint32_t)(idx >> 32) * 0x85EBCA6Bu;
+  h ^= h >> 15; h *= 0x735A2D97u;
+  h ^= h >> 15;
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
 // Like tr_frag, for an MFMA whose 32 contraction slots are PERMUTED: slot (fq, jj) stands for row k0 + 4*fq + jj (jj < 4) and
 // k0 + 16 + 4*fq + (jj - 4) (jj >= 4).  That is the order in which a lane holds two stacked 16x16 accumulator tiles
 // (rows 4*fq + r of the first, 16 + 4*fq + r of the second), so those accumulators - packed to bf16 - ARE the other operand:

@@ -42,7 +42,7 @@ __device__ __forceinline__ void xa_stage_rows(bf16* dst, const bf16* src, size_t
 }
 
 __device__ __forceinline__ bool xa_keep(const unsigned char* keep, const XaGeom& g, size_t e) {
-  return keep ? keep[e] != 0 : uniform_from(g.seed, (uint64_t)e) >= g.drop_p;
+  return keep ? keep[e] != 0 : uniform32_from(g.seed, (uint64_t)e) >= g.drop_p;
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward

@@ -106,14 +106,15 @@ def test_xattn_counter_based_dropout_is_the_same_mask_forward_and_backward():
     ops.xattn_fwd(qkv, out1, lse, B, T, H, dh, drop_p=p, seed=1234)
     # the same decisions, reproduced on the host from the documented generator
     idx = torch.arange(T * T, dtype=torch.int64)
-    M = (1 << 64) - 1
+    M = (1 << 32) - 1
     keep = []
-    for e in idx.tolist():
-        z = (1234 + 0x9E3779B97F4A7C15 * (e + 1)) & M
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
-        z = z ^ (z >> 31)
-        keep.append(((z >> 40) / 16777216.0) >= p)
+    for e in idx.tolist():                                             # common.h uniform32_from(seed = 1234, index e)
+        h = (e * 0x9E3779B1 + 1234) & M
+        h ^= h >> 16; h = (h * 0x21F0AAAD) & M
+        h ^= 0                                                         # seed >> 32 and index >> 32 are both zero here
+        h ^= h >> 15; h = (h * 0x735A2D97) & M
+        h ^= h >> 15
+        keep.append(((h >> 8) / 16777216.0) >= p)
     keep = torch.tensor(keep, dtype=torch.uint8).view(1, 1, T, T).to(DEV)
     out2 = torch.empty_like(out1)
     ops.xattn_fwd(qkv, out2, lse, B, T, H, dh, keep=keep, drop_p=p)
