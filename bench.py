@@ -476,9 +476,9 @@ def roofline(trainer, batches, step_fn):
     method = ("all launches of one step captured back-to-back into one hipGraph, replay time / launches between two HIP events "
               "(nothing subtracted; contains the inter-node gaps)")
     label = {"nt": ("gemm_nt (gemm_nt_bf16_pipe_kernel + gemm_nt_bf16_direct_kernel, 64x64 tiles)", ("gemm_nt_bf16_",)),
-             "ffn": ("fused FeedForward (ffn_fwd_kernel + ffn_bwd_kernel, csrc/ffn.hip: 64-row workgroups, weights by LDS-DMA)",
-                     # (the GEMM-only instantiations ffn_bwd_kernel<*, true> are lidk_dgrad_ln_bwd launches: not this family)
-                     ("ffn_fwd_kernel", "ffn_bwd_kernel<true, false>", "ffn_bwd_kernel<false, false>")),
+             "ffn": ("fused FeedForward (ffn_fwd_kernel + ffn_bwd_kernel, csrc/ffn.hip: 48-row workgroups at this M, weights by LDS-DMA)",
+                     # (the GEMM-only instantiations ffn_bwd_kernel<*, true, *> are lidk_dgrad_ln_bwd launches: not this family)
+                     ("ffn_fwd_kernel", "ffn_bwd_kernel<true, false,", "ffn_bwd_kernel<false, false,")),
              "tng": ("grouped weight-gradient GEMM (gemm_tn_grouped_dma_kernel: 128x128 tiles, 2 row chunks, operands by LDS-DMA ring)", ("gemm_tn_grouped",)),
              "tn": ("gemm_tn_bf16_kernel<64,64>", ("gemm_tn_bf16_kernel",))}
 
