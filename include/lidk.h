@@ -165,7 +165,8 @@ int lidk_gemm_nt_bn_sums(const lidk_gemm_args* g, const float* mean, const float
                          float* partial, int* nparts, int dtype, void* stream);
 /* Kernel-family knobs of lidk_gemm_nt, read from the environment once: "LIDK_GEMM_PIPEK" (tiles per workgroup of the K = 512 / 768 /
  * 1024 pipelined kernel, 0 = off), "LIDK_GEMM_DMA" (smallest K that takes the LDS-DMA 128 x 128 kernel, 0 = never),
- * "LIDK_GEMM_DMA_TILES" (its tile-count floor).  This call changes one afterwards (tests, micro-benchmarks); a negative value makes
+ * "LIDK_GEMM_DMA_TILES" (its tile-count floor), "LIDK_GEMM_DMA256" (tile-count floor of the persistent 256-row LDS-DMA kernel; 0 = never,
+ * 1 = whenever the shape allows), "LIDK_GEMM_DMA256_BN" (its tile width: 256 / 128, 0 = by the fill of the last round).  This call changes one afterwards (tests, micro-benchmarks); a negative value makes
  * the next launch re-read the environment. */
 int lidk_gemm_option(const char* name, long value);
 

@@ -635,17 +635,20 @@ gemm_nt_bf16_dma_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, 
 // residual of an f32 output is added on the way out with the same full-line pattern.
 // For the transformer backbones (d = 768 / 1024, ffn 3072 / 4096, conv stack): launches with >= LIDK_GEMM_DMA256 (default 200)
 // tiles of 256 x 256.
-template <int EPI_F32>
+// BN = 256: waves 2 x 4, a wave owns 128 x 64; BN = 128 (launches whose 256 x 256 tile count leaves a poorly filled last round):
+// waves 4 x 2, a wave owns 64 x 64, K tiles of 32 + 16 KB.
+template <int EPI_F32, int BN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K, int lda, int ldb,
                            int total_tiles, Epi e) {
-  constexpr int BM = 256, BN = 256, TM = 8, TN = 4, STAGE = (BM + BN) * BK * 2;
+  constexpr int BM = 256, NWN = BN / 64, NWM = 8 / NWN, RW = BM / NWM, TM = RW / 16, TN = 4, STAGE = (BM + BN) * BK * 2;
+  constexpr int NBI = BN / 32;                               // B-tile wave instructions per loader and K tile
   typedef __attribute__((address_space(3))) void lds_v;
   const int n_tiles = N / BN;
   extern __shared__ __attribute__((aligned(16))) unsigned char dma_smem[];       // [2][A 32 KB | B 32 KB] + 8 x 4 KB epilogue staging
   const unsigned smem0 = (unsigned)(size_t)(lds_v*)dma_smem;
   const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 2, wn = wid & 3;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid / NWN, wn = wid % NWN;
   constexpr bool pair = !EPI_F32;
   const int G = gridDim.x, slot = xcd_tile(blockIdx.x, G);
   const int nt = K / BK;
@@ -662,7 +665,8 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
   const int arow0 = 64 * (wid & 3) + (lane >> 3);
   const unsigned cofs = (unsigned)(((lane & 7) ^ (lane >> 3)) * 16);
   const unsigned aoff0 = (unsigned)((size_t)arow0 * lda * 2) + cofs;
-  const int brow0 = pair ? (arow0 & ~31) + (((arow0 >> 2) & 3) << 3) + (((arow0 >> 4) & 1) << 2) + (arow0 & 3) : arow0;
+  const int brow_l = (BN / 4) * (wid & 3) + (lane >> 3);         // this loader's first LDS row of the B tile
+  const int brow0 = pair ? (brow_l & ~31) + (((brow_l >> 2) & 3) << 3) + (((brow_l >> 4) & 1) << 2) + (brow_l & 3) : brow_l;
   const unsigned boff0 = (unsigned)((size_t)brow0 * ldb * 2) + cofs;
   const bf16* abase = A;
   const bf16* bbase = B;
@@ -691,9 +695,9 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
         for (int i = 0; i < 8; ++i) gemm_glds16s(ak + (size_t)(8 * i) * lda, aoff0, dst + i * 1024);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < NBI; ++i) {
         const int dn = pair ? 16 * (i & 1) + 4 * ((i >> 1) & 1) + 32 * (i >> 2) : 8 * i;
-        gemm_glds16s(bk + (size_t)dn * ldb, boff0, dst + BM * BK * 2 + i * 1024);
+        gemm_glds16s(bk + (size_t)dn * ldb, boff0, smem0 + buf * STAGE + BM * BK * 2 + (BN / 4) * (wid & 3) * 128 + i * 1024);
       }
     }
   };
@@ -728,7 +732,7 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
           bf16x8 af[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            af[i] = *reinterpret_cast<const bf16x8*>(&a[(wm * 128 + (ih + i) * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
+            af[i] = *reinterpret_cast<const bf16x8*>(&a[(wm * RW + (ih + i) * 16 + fr) * BK + (((kk + fq) ^ (fr & 7)) << 3)]);
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
@@ -772,7 +776,7 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
           uint4 pk[2][2], pp[2][2];
 #pragma clang loop unroll(full)
           for (int ii = 0; ii < 2; ++ii) {
-            const int i = 2 * i2 + ii, m = min(m0 + wm * 128 + i * 16 + fr, M - 1);
+            const int i = 2 * i2 + ii, m = min(m0 + wm * RW + i * 16 + fr, M - 1);
 #pragma clang loop unroll(full)
             for (int c = 0; c < TN / 2; ++c) {
               const int n = n0 + wn * 64 + 32 * c + 8 * fq;
@@ -802,11 +806,11 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
               bf16* dst = ps ? (bf16*)e.out2 : (bf16*)e.out;
               const int ldd = ps ? e.ldo2 : e.ldo;
 #pragma unroll
-              for (int own = 1; own >= 0; --own) {             // own = 1: this wave's rows (wm = 1); 0: the partner's (wm = 0)
+              for (int own = 1; own >= 0; --own) {             // own = 1: this wave's rows; 0: the partner's (wave w - 4, same columns)
                 const unsigned char* src = wl - (own ? 0 : 4 * 4096);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                  const int row = it * 8 + (lane >> 3), m = m0 + own * 128 + i2 * 32 + row;
+                  const int row = it * 8 + (lane >> 3), m = m0 + (own ? wm : wm - NWM / 2) * RW + i2 * 32 + row;
                   const uint4 v = *reinterpret_cast<const uint4*>(src + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
                   if (m < M) st16(e, dst + (size_t)m * ldd + n0 + wn * 64 + (lane & 7) * 8, v);
                 }
@@ -821,7 +825,7 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
         e2.res = nullptr;
 #pragma clang loop unroll(full)
         for (int i = 0; i < TM; ++i) {                       // 16 rows x 256 B at a time
-          const int m_ = min(m0 + wm * 128 + i * 16 + fr, M - 1);
+          const int m_ = min(m0 + wm * RW + i * 16 + fr, M - 1);
 #pragma clang loop unroll(full)
           for (int j = 0; j < TN; ++j) {
             float4 p0;
@@ -837,7 +841,7 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
             for (int own = 1; own >= 0; --own)
 #pragma unroll
               for (int it = 0; it < 4; ++it) {
-                const int row = it * 4 + (lane >> 4), m = min(m0 + own * 128 + i * 16 + row, M - 1), n = n0 + wn * 64 + (lane & 15) * 4;
+                const int row = it * 4 + (lane >> 4), m = min(m0 + (own ? wm : wm - NWM / 2) * RW + i * 16 + row, M - 1), n = n0 + wn * 64 + (lane & 15) * 4;
                 rr[own][it] = e.res ? load4(e.res + (size_t)m * e.ldres + n) : make_float4(0.f, 0.f, 0.f, 0.f);
               }
 #pragma unroll
@@ -845,7 +849,7 @@ gemm_nt_bf16_dma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ 
               const unsigned char* src = wl - (own ? 0 : 4 * 4096);
 #pragma unroll
               for (int it = 0; it < 4; ++it) {
-                const int row = it * 4 + (lane >> 4), m = m0 + own * 128 + i * 16 + row, n = n0 + wn * 64 + (lane & 15) * 4;
+                const int row = it * 4 + (lane >> 4), m = m0 + (own ? wm : wm - NWM / 2) * RW + i * 16 + row, n = n0 + wn * 64 + (lane & 15) * 4;
                 float4 v = *reinterpret_cast<const float4*>(src + row * 256 + (((lane & 15) ^ row) << 4));
                 const float4 r = rr[own][it];
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -1213,12 +1217,13 @@ gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, int
 // Kernel-family knobs of lidk_gemm_nt: read from the environment ONCE (LIDK_GEMM_PIPEK, LIDK_GEMM_DMA, LIDK_GEMM_DMA_TILES) and
 // changed afterwards only through lidk_gemm_option - tests and the micro-benchmarks flip them inside one process.
 static int g_opt_pipek = -1, g_opt_dma = -1;
-static long g_opt_dma_tiles = -1, g_opt_dma256 = -1;
+static long g_opt_dma_tiles = -1, g_opt_dma256 = -1, g_opt_dma256_bn = -1;
 static void gemm_opts_init() {
   if (g_opt_pipek < 0) { const char* v = getenv("LIDK_GEMM_PIPEK"); g_opt_pipek = v ? atoi(v) : 1; }
   if (g_opt_dma < 0) { const char* v = getenv("LIDK_GEMM_DMA"); g_opt_dma = v ? atoi(v) : 1024; }
   if (g_opt_dma_tiles < 0) { const char* v = getenv("LIDK_GEMM_DMA_TILES"); g_opt_dma_tiles = v ? atol(v) : 384; }
   if (g_opt_dma256 < 0) { const char* v = getenv("LIDK_GEMM_DMA256"); g_opt_dma256 = v ? atol(v) : 150; }
+  if (g_opt_dma256_bn < 0) { const char* v = getenv("LIDK_GEMM_DMA256_BN"); g_opt_dma256_bn = v ? atol(v) : 0; }
 }
 extern "C" int lidk_gemm_option(const char* name, long value) {
   if (!name) return LIDK_ERR_ARG;
@@ -1227,6 +1232,7 @@ extern "C" int lidk_gemm_option(const char* name, long value) {
   else if (!strcmp(name, "LIDK_GEMM_DMA")) g_opt_dma = (int)value;
   else if (!strcmp(name, "LIDK_GEMM_DMA_TILES")) g_opt_dma_tiles = value;
   else if (!strcmp(name, "LIDK_GEMM_DMA256")) g_opt_dma256 = value;
+  else if (!strcmp(name, "LIDK_GEMM_DMA256_BN")) g_opt_dma256_bn = value;
   else return LIDK_ERR_ARG;
   return LIDK_OK;                                        // (a negative value: re-read the environment on the next launch)
 }
@@ -1304,22 +1310,38 @@ extern "C" int lidk_gemm_nt(const lidk_gemm_args* g, int dtype, void* stream) {
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                    ? prop.multiProcessorCount : 256;
       }
-      const long t256 = (long)cdiv(g->M, 256) * (g->N / 256);
-      const long rounds = (t256 + n_cu - 1) / n_cu;
-      const bool filled = t256 * 100 >= rounds * n_cu * 65 || rounds >= 3 || g_opt_dma256 == 1;
+      // tile width: 256 columns.  The 256 x 128 form (LIDK_GEMM_DMA256_BN = 128; waves 4 x 2) is built and tested but is not chosen
+      // automatically: on the d = 768 shapes it loses to the 256 x 256 form or to the older kernels at every M tried
+      // (profiles/r04/gemm_shapes_ab2.txt: e.g. M 9536 N 768 K 3072 58 us without the persistent kernel, 87 / 63 with 256 / 128 columns).
+      const int force_bn = (int)g_opt_dma256_bn;
       const bool vec256 = !(g->ldo & 7) && (!g->res || !(g->ldres & 3)) && (!g->out2 || !(g->ldo2 & 7)) && (!g->aux || !(g->ldaux & 7));
-      if (direct && splitk == 1 && g_opt_dma256 > 0 && !(g->N & 255) && (g->K & 63) == 0 && g->K >= 512 && t256 >= g_opt_dma256 && filled && vec256 &&
-          (size_t)256 * g->lda * 2 < (1ull << 31) && (size_t)256 * g->ldb * 2 < (1ull << 31)) {
+      const bool shape_ok = direct && splitk == 1 && g_opt_dma256 > 0 && (g->K & 63) == 0 && g->K >= 512 && vec256 &&
+                            (size_t)256 * g->lda * 2 < (1ull << 31) && (size_t)256 * g->ldb * 2 < (1ull << 31);
+      int bn = 0;
+      long tiles = 0;
+      for (int cand = 256; cand >= 128 && shape_ok && !bn; cand >>= 1) {
+        if ((g->N % cand) || (force_bn ? force_bn != cand : cand != 256)) continue;
+        const long t = (long)cdiv(g->M, 256) * (g->N / cand), rounds = (t + n_cu - 1) / n_cu;
+        const bool filled = t * 100 >= rounds * n_cu * 65 || rounds >= 3 || g_opt_dma256 == 1;
+        if (t >= g_opt_dma256 && filled) { bn = cand; tiles = t; }
+      }
+      if (bn) {
         static bool attr256 = false;
-        constexpr int lds256 = 2 * (256 + 256) * BK * 2 + 8 * 4096;
+        constexpr int lds256 = 2 * (256 + 256) * BK * 2 + 8 * 4096, lds128 = 2 * (256 + 128) * BK * 2 + 8 * 4096;
         if (!attr256) {
-          (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_dma256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
-          (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_dma256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+          (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_dma256_kernel<0, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+          (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_dma256_kernel<1, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+          (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_dma256_kernel<0, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
+          (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_dma256_kernel<1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds128);
           attr256 = true;
         }
-        const int G = (int)(t256 < n_cu ? t256 : n_cu);      // persistent: one workgroup per CU
-        if (g->out_f32) gemm_nt_bf16_dma256_kernel<1><<<G, 512, lds256, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->K, g->lda, g->ldb, (int)t256, e);
-        else gemm_nt_bf16_dma256_kernel<0><<<G, 512, lds256, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->K, g->lda, g->ldb, (int)t256, e);
+        const int G = (int)(tiles < n_cu ? tiles : n_cu);    // persistent: one workgroup per CU
+#define LIDK_DMA256_LAUNCH(F32_, BN_, LDS_)                                                                                      \
+  gemm_nt_bf16_dma256_kernel<F32_, BN_><<<G, 512, LDS_, s>>>((const bf16*)g->A, (const bf16*)g->B, g->M, g->N, g->K, g->lda, g->ldb, \
+                                                             (int)tiles, e)
+        if (bn == 256) { if (g->out_f32) LIDK_DMA256_LAUNCH(1, 256, lds256); else LIDK_DMA256_LAUNCH(0, 256, lds256); }
+        else { if (g->out_f32) LIDK_DMA256_LAUNCH(1, 128, lds128); else LIDK_DMA256_LAUNCH(0, 128, lds128); }
+#undef LIDK_DMA256_LAUNCH
         return launch_status();
       }
     }

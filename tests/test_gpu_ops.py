@@ -659,13 +659,14 @@ def test_gemm_nt_lds_dma_128_tile(mode, gemm_options):
 
 
 @pytest.mark.parametrize("mode", ["bf16_plain", "f32_bias_res", "gelu_pre", "gelu_grad", "strided_view"])
-@pytest.mark.parametrize("N,K", [(2304, 768), (1024, 4096), (512, 1536)])
-def test_gemm_nt_lds_dma_256_tile(mode, N, K, gemm_options):
+@pytest.mark.parametrize("N,K,bn", [(2304, 768, 256), (1024, 4096, 256), (512, 1536, 256), (2304, 768, 128), (640, 1024, 128)])
+def test_gemm_nt_lds_dma_256_tile(mode, N, K, bn, gemm_options):
     """N % 256 == 0, K % 64 == 0, K >= 512 and >= LIDK_GEMM_DMA256 (here forced to 1; default 200) tiles of 256 x 256 dispatch
     gemm_nt_bf16_dma256_kernel: the transformer backbones' QKV / FFN / conv-stack shapes.  M = 4 x 256 + 77: a clamped last row tile.
     Every epilogue the backbones use; 'strided_view': overlapping rows (lda < K), the conv feature extractor's operand form.
     Reference: f32 matmul of the bf16-rounded operands."""
     gemm_options("LIDK_GEMM_DMA256", 1)
+    gemm_options("LIDK_GEMM_DMA256_BN", bn)                      # 256 x 256 tiles (waves 2 x 4) or 256 x 128 (waves 4 x 2)
     M = 4 * 256 + 77
     A = (torch.randn(M, K, generator=g(180)) * 0.5).bfloat16()
     B = (torch.randn(N, K, generator=g(181)) / K ** 0.5).bfloat16()

@@ -35,16 +35,18 @@ def case(m, n, k, mode):
     elif mode == "res": kw = dict(bias=bias, res=torch.randn(m, n, device=dev))
     elif mode == "gelu_grad": kw = dict(act=L.ACT_GELU_GRAD, aux=torch.randn(m, n, device=dev).bfloat16())
     res = []
-    for v in (-1, 1):
+    for v, bn in ((0, 0), (-1, -1), (1, 256), (1, 128)):       # persistent kernel off / default dispatch / forced 256 x 256 / forced 256 x 128
         ops.gemm_option("LIDK_GEMM_DMA256", v)
+        ops.gemm_option("LIDK_GEMM_DMA256_BN", bn)
         res.append(timed(lambda i: ops.gemm_nt(A[i], B[i], out[i], **kw)))
     ops.gemm_option("LIDK_GEMM_DMA256", -1)
+    ops.gemm_option("LIDK_GEMM_DMA256_BN", -1)
     t256 = -(-m // 256) * (n // 256)
-    print(f"M={m:6d} N={n:5d} K={k:5d} {mode:9s} tiles256={t256:5d} ({t256 / 256:5.2f} rounds): default {res[0]:7.1f} us   forced 256x256 {res[1]:7.1f} us   "
-          f"{2.0 * m * n * k / min(res) / 1e6:6.0f} TFLOP/s best")
+    print(f"M={m:6d} N={n:5d} K={k:5d} {mode:9s} tiles256={t256:5d} ({t256 / 256:5.2f} rounds): off {res[0]:7.1f}  default {res[1]:7.1f}  256x256 {res[2]:7.1f}  "
+          f"256x128 {res[3]:7.1f} us   {2.0 * m * n * k / min(res) / 1e6:6.0f} TFLOP/s best")
 
 
-for m in (9536, 16000, 24000):
+for m in (4800, 9536, 16000, 24000):
     for (n, k, mode) in ((2304, 768, "bias"), (768, 768, "res"), (3072, 768, "gelu"), (768, 3072, "res"), (768, 3072, "gelu_grad"),
                          (3072, 768, "plain"), (768, 2304, "plain")):
         case(m, n, k, mode)
